@@ -1,0 +1,157 @@
+/*
+ * libtise_hip.so -- C ABI of the MI355X (gfx950) image-realism hot path of the TISE toolbox.
+ *
+ * The reference (VinAIResearch/tise-toolbox) has no native code and no FFI: its statistics
+ * layer is numpy/scipy called from Python.  Each entry point below replaces the numpy/scipy
+ * (or Pillow) call cited next to it; the Python shims in tise_toolbox_amd/ (same function
+ * names as the reference) are the only callers and bind these symbols with ctypes
+ * (INTEGRATION.md shows the binding a reference maintainer would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every pointer named *_dev is DEVICE memory (hipMalloc or a torch CUDA tensor's
+ *     data_ptr()); everything else is host memory.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  All work is enqueued
+ *     on it; nothing synchronises unless the comment says so.
+ *   - return value: 0 = TISE_OK, negative = error (tise_status_string() names it).  No C++
+ *     exception crosses the boundary.  Data-dependent conditions (rank deficiency, non-finite
+ *     input) are reported through device-side flag words, not through the return code.
+ *   - no hidden allocation of caller-visible memory: scratch lives in handles created and
+ *     destroyed explicitly.
+ */
+#ifndef TISE_HIP_H
+#define TISE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TISE_OK 0
+#define TISE_ERR_INVALID_ARG (-1)   /* -> AssertionError / ValueError in the Python mirror   */
+#define TISE_ERR_HIP (-2)           /* a HIP runtime call failed (tise_last_hip_error())     */
+#define TISE_ERR_NO_DEVICE (-3)     /* no gfx950 device visible                              */
+#define TISE_ERR_UNSUPPORTED (-4)   /* size outside what the kernels are built for          */
+
+const char* tise_status_string(int status);
+int tise_last_hip_error(void);                 /* hipError_t of the last failing HIP call    */
+int tise_version(void);                        /* ABI version, currently 1                   */
+int tise_device_info(int* cu_count, int* gcn_arch_is_gfx950, size_t* total_mem);
+
+/* ------------------------------------------------------------------------------------------
+ * (a3) PIL-exact uint8 bilinear resize + ToTensor + input affine, fused.
+ * Replaces transforms.Resize((299,299)) + ToTensor()   image_realism/FID/fid_score.py:208-213
+ * (Pillow ImagingResample, 8bpc: 22-bit fixed-point coefficients, horizontal pass -> u8 ->
+ * vertical pass -> u8) and the per-channel affine of image_realism/FID/inception.py:120-124.
+ *
+ *   src_dev   n images, HWC uint8, contiguous (n, h, w, 3)
+ *   dst_dev   fp32, (n, 3, oh, ow) when nhwc == 0, (n, oh, ow, 3) when nhwc != 0
+ *             (the latter is torch.channels_last storage of an NCHW tensor)
+ *   lut       host pointer, 3*256 floats: lut[c*256 + v] = value written for channel c and
+ *             resized byte v (the shim fills it with fp32(v)/255 then the inception.py affine,
+ *             evaluated with the reference's own op order, so the kernel is exact by table).
+ *   u8_out_dev optional (may be NULL): the resized uint8 image (n, oh, ow, 3), for parity tests.
+ * ------------------------------------------------------------------------------------------ */
+int tise_resize_bilinear_u8(const uint8_t* src_dev, int n, int h, int w,
+                            float* dst_dev, int oh, int ow, int nhwc,
+                            const float* lut, uint8_t* u8_out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a7) Streaming activation statistics: n, s = sum_i x_i, S = sum_i x_i x_i^T in fp64 from
+ * fp32 feature rows that never leave the device.
+ * Replaces pred_arr[start:end] = pred.cpu()...  + np.mean(act, 0) + np.cov(act, rowvar=False)
+ *                                           image_realism/FID/fid_score.py:98,113,194-195
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tise_stats tise_stats_t;
+
+int tise_stats_create(int d, tise_stats_t** h);           /* allocates (d*d + d + 2) doubles, zeroed */
+int tise_stats_destroy(tise_stats_t* h);
+int tise_stats_reset(tise_stats_t* h, void* stream);
+/* accumulate `rows` feature rows: feats_dev[r*ld + c], c < d.  Callable once per batch. */
+int tise_stats_update(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream);
+/* the two halves of tise_stats_update, separately launchable (bench.py times the MFMA half alone):
+ * _cov: S += X^T X (fp64 MFMA)   _sum: s += column sums, n += rows                               */
+int tise_stats_update_cov(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream);
+int tise_stats_update_sum(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream);
+/* the contiguous fp64 buffer [S (d*d, upper triangle by 64x64 tile) | s (d) | n | pad] that a
+ * data-parallel caller hands to RCCL / torch.distributed.all_reduce(SUM). */
+int tise_stats_buffer(tise_stats_t* h, double** buf_dev, size_t* n_doubles);
+/* mu = s/n ; sigma = (S - s s^T / n) / (n - 1)   (np.cov ddof = 1).  mu_dev: d, sigma_dev: d*d */
+int tise_stats_finalize(tise_stats_t* h, double* mu_dev, double* sigma_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a6) Frechet distance.
+ * Replaces calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps)
+ *                                           image_realism/FID/fid_score.py:121-171
+ * Tr sqrtm(S1 S2) is evaluated as sum_i sqrt(lambda_i(L^T S2 L)), S1 = L L^T a diagonally
+ * pivoted Cholesky factor (rank-revealing, runs to the last positive pivot), L^T S2 L reduced
+ * to tridiagonal form by Householder reflections, eigenvalues by Sturm bisection; all fp64.
+ *
+ *   out_dev[0] = fid            out_dev[1] = tr sqrt(S1 S2)     out_dev[2] = |mu1-mu2|^2
+ *   out_dev[3] = tr S1          out_dev[4] = tr S2              out_dev[5] = rank(L) as double
+ *   out_dev[6] = number of negative eigenvalues clipped         out_dev[7] = flags as double
+ *   flags: bit0 = non-finite value met (the reference's "singular product" branch, :156-160,
+ *          is taken by the Python mirror on this bit), bit1 = sigma1 numerically rank deficient.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct tise_frechet tise_frechet_t;
+
+#define TISE_FRECHET_OUT_DOUBLES 8
+#define TISE_FLAG_NONFINITE 1
+#define TISE_FLAG_RANK_DEFICIENT 2
+
+int tise_frechet_create(int d, tise_frechet_t** h);       /* allocates ~4 d*d doubles of scratch */
+int tise_frechet_destroy(tise_frechet_t* h);
+/* Synchronises `stream` once (to read the numerical rank back). */
+int tise_frechet_distance(tise_frechet_t* h, const double* mu1_dev, const double* sigma1_dev,
+                          const double* mu2_dev, const double* sigma2_dev, double diag_offset,
+                          double* out_dev, void* stream);
+/* Optional phase timing of tise_frechet_distance with HIP events on the caller's stream.
+ * ms_host[5] = pivoted Cholesky | GEMMs | tridiagonalisation | bisection | final reduction.
+ * tise_frechet_phase_ms waits for the last recorded call to finish. */
+int tise_frechet_set_profiling(tise_frechet_t* h, int on);
+int tise_frechet_phase_ms(tise_frechet_t* h, double* ms_host, int* rank_host);
+/* Test hook: eigenvalues (ascending, n of them) of the symmetric n x n matrix a_dev (ld = n),
+ * through the same tridiagonalisation + bisection kernels.  a_dev is not modified. */
+int tise_eigvalsh(tise_frechet_t* h, const double* a_dev, int n, double* w_dev, void* stream);
+/* Test hook: pivoted Cholesky of sigma_dev (d x d).  lt_dev receives L^T (d x d, row k = column k
+ * of L, rows >= rank zero); rank_host receives the numerical rank.  Synchronises the stream. */
+int tise_pivoted_cholesky(tise_frechet_t* h, const double* sigma_dev, double* lt_dev,
+                          int* rank_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * (a8, a8', a8'') IS* reduction with temperature.
+ * Replaces tf.div(logits, T); tf.nn.softmax            IS/coco/inception_score_star_coco.py:107-108
+ *      and the split / KL / exp loop                    IS/coco/inception_score_star_coco.py:52-60
+ *          (same loop: IS/bird/inception_score_star_bird.py:97-108, slice+T :189-194;
+ *           per-row entropy form: O-IS/object_centric_inception_score.py:69-81)
+ * One-pass additive form: per split k keep A_k = sum_i sum_c p_ic log p_ic and
+ * B_kc = sum_i p_ic; score_k = exp(A_k/n_k - sum_c pbar_c log pbar_c).
+ *
+ *   split_rule 0: split k = [k*N/splits, (k+1)*N/splits)          (coco, bird)
+ *   split_rule 1: split k = [k*(N/splits), (k+1)*(N/splits)), the tail is dropped   (O-IS)
+ *   drop_first != 0: class 0 is discarded before the softmax       (bird, :189)
+ *   acc_dev: splits * (1 + C_eff) doubles, [A_0..A_{splits-1} | B row-major]; C_eff = C - drop.
+ *            Additive across calls and across GPUs (all_reduce SUM).  Caller zeroes it.
+ *   ws_dev:  scratch, at least 2*rows doubles.
+ *   Rows carry global indices idx_base .. idx_base + rows - 1 of an N_total-image set.
+ * ------------------------------------------------------------------------------------------ */
+int tise_is_update(const float* logits_dev, int64_t rows, int64_t ld, int C, double temperature,
+                   int drop_first, int64_t idx_base, int64_t n_total, int splits, int split_rule,
+                   double* acc_dev, double* ws_dev, void* stream);
+/* out_dev: 2 + splits doubles = [mean, std (ddof 0), score_0 .. score_{splits-1}] */
+int tise_is_finalize(const double* acc_dev, int C_eff, int64_t n_total, int splits, int split_rule,
+                     double* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * fp64 GEMM building block (MFMA v_mfma_f64_16x16x4_f64), exported for tests/bench only:
+ * C[m][n] (ldc) = sum_k A(m,k) * B(k,n) with A(m,k) = a[m*sam + k*sak], B(k,n) = b[k*sbk + n*sbn].
+ * ------------------------------------------------------------------------------------------ */
+int tise_gemm_f64(const double* a_dev, int64_t sam, int64_t sak, const double* b_dev, int64_t sbk,
+                  int64_t sbn, double* c_dev, int64_t ldc, int m, int n, int k, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TISE_HIP_H */

@@ -1,0 +1,286 @@
+"""GPU parity tests: every HIP entry point of libtise_hip.so against the CPU oracle, called
+through the C ABI (ctypes, tise_toolbox_amd.device).  Integer work is compared bit-exactly; fp64
+work with the tolerances written next to each assert."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fid_oracle, is_oracle, resize_oracle
+from tests import _cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(cuda_device):
+    return cuda_device
+
+
+def test_device_is_gfx950(dev):
+    import ctypes
+    from tise_toolbox_amd import _lib
+    cu, is950, mem = ctypes.c_int(), ctypes.c_int(), ctypes.c_size_t()
+    _lib.call("tise_device_info", ctypes.byref(cu), ctypes.byref(is950), ctypes.byref(mem))
+    assert is950.value == 1 and cu.value >= 200 and mem.value > 100 * 2 ** 30
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("m,n,k", [(64, 64, 16), (70, 130, 37), (1, 1, 1), (256, 192, 500), (33, 2048, 129)])
+def test_gemm_f64_layouts(dev, m, n, k):
+    from tise_toolbox_amd import device
+    rng = np.random.default_rng(m * 1000 + n)
+    a = rng.standard_normal((m, k))
+    b = rng.standard_normal((k, n))
+    ref = a @ b
+    ta, tb = torch.as_tensor(a, device=dev), torch.as_tensor(b, device=dev)
+    tol = 1e-13 * k * max(1.0, np.abs(ref).max())
+    for A in (ta, ta.t().contiguous().t()):                 # k-contiguous and m-contiguous A
+        for B in (tb, tb.t().contiguous().t()):             # n-contiguous and k-contiguous B
+            c = device.gemm_f64(A, B).cpu().numpy()
+            assert np.abs(c - ref).max() <= tol
+
+
+def test_gemm_asymmetric_identity(dev):
+    """A = I with an ASYMMETRIC B catches a transposed C write (cdna guide section 3)."""
+    from tise_toolbox_amd import device
+    n = 96
+    b = np.arange(n * n, dtype=np.float64).reshape(n, n)
+    c = device.gemm_f64(torch.eye(n, dtype=torch.float64, device=dev), torch.as_tensor(b, device=dev)).cpu().numpy()
+    np.testing.assert_array_equal(c, b)
+
+
+# ------------------------------------------------------------------------------------------- resize
+def test_resize_golden_bit_exact(dev, golden_dir):
+    from tise_toolbox_amd import device
+    g = np.load(os.path.join(golden_dir, "pil_resize_299.npz"))
+    names = [k[3:] for k in g.files if k.startswith("in_")]
+    lut = device.make_lut(True)
+    for k in names:
+        src = torch.as_tensor(g["in_" + k], device=dev).unsqueeze(0)
+        for cl in (True, False):
+            out, u8 = device.resize_bilinear_u8(src, (299, 299), lut, channels_last=cl, return_u8=True)
+            np.testing.assert_array_equal(u8[0].cpu().numpy(), g["out_" + k], err_msg=f"{k} cl={cl}")
+            # fused ToTensor + inception.py:120-124 affine: bit-exact against the numpy restatement
+            want = resize_oracle.normalize_input(resize_oracle.to_tensor(g["out_" + k]))
+            got = out[0].cpu().numpy()
+            assert got.shape == (3, 299, 299)
+            np.testing.assert_array_equal(got, want, err_msg=f"{k} cl={cl} float")
+            assert out.is_contiguous(memory_format=torch.channels_last if cl else torch.contiguous_format)
+
+
+@pytest.mark.parametrize("h,w", [(256, 256), (64, 48), (299, 299), (300, 299), (299, 301), (517, 31), (1024, 768), (7, 5)])
+def test_resize_random_sizes_vs_oracle(dev, h, w):
+    from tise_toolbox_amd import device
+    rng = np.random.default_rng(h * 7 + w)
+    n = 3
+    imgs = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
+    out, u8 = device.resize_bilinear_u8(torch.as_tensor(imgs, device=dev), (299, 299), device.make_lut(False),
+                                        channels_last=True, return_u8=True)
+    for i in range(n):
+        want = resize_oracle.resize_bilinear_u8(imgs[i], 299, 299)
+        np.testing.assert_array_equal(u8[i].cpu().numpy(), want)
+        np.testing.assert_array_equal(out[i].cpu().numpy(), resize_oracle.to_tensor(want))
+
+
+def test_resize_batch_and_empty(dev):
+    from tise_toolbox_amd import device
+    imgs = _cases.smooth_images(5, 256, 256, seed=1)
+    out, u8 = device.resize_bilinear_u8(torch.as_tensor(imgs, device=dev), return_u8=True)
+    for i in range(5):
+        np.testing.assert_array_equal(u8[i].cpu().numpy(), resize_oracle.resize_bilinear_u8(imgs[i], 299, 299))
+    empty = device.resize_bilinear_u8(torch.empty((0, 256, 256, 3), dtype=torch.uint8, device=dev))
+    assert tuple(empty.shape) == (0, 3, 299, 299)
+
+
+# ------------------------------------------------------------------------------------------- statistics
+@pytest.mark.parametrize("n,d,chunks", [(35, 24, [35]), (300, 64, [100, 7, 193]), (500, 192, [250, 250]),
+                                        (257, 2048, [50, 50, 50, 107]), (64, 768, [1, 63])])
+def test_stats_match_np_cov(dev, n, d, chunks):
+    from tise_toolbox_amd import device
+    x = _cases.pool3_like_features(n, d, seed=n + d)
+    acc = device.StatsAccumulator(d, dev)
+    lo = 0
+    for c in chunks:
+        acc.update(torch.as_tensor(x[lo:lo + c], device=dev))
+        lo += c
+    assert acc.count() == n
+    mu, sigma = acc.finalize()
+    mu_ref, sigma_ref = fid_oracle.calculate_activation_statistics(x)       # np.mean / np.cov on float64
+    scale = np.abs(sigma_ref).max()
+    assert np.abs(mu.cpu().numpy() - mu_ref).max() <= 1e-14 * max(1.0, np.abs(mu_ref).max())
+    # S - n mu mu^T cancels ~1 digit; 1e-12 relative to the largest covariance entry
+    assert np.abs(sigma.cpu().numpy() - sigma_ref).max() <= 1e-12 * scale
+    s = sigma.cpu().numpy()
+    np.testing.assert_array_equal(s, s.T)                                    # mirrored tiles: exactly symmetric
+
+
+def test_stats_golden_fake_model(dev, golden_dir):
+    """G2: features produced by the reference's own get_activations loop -> its mu/sigma."""
+    from tise_toolbox_amd import device
+    g = np.load(os.path.join(golden_dir, "actstats_fake_model.npz"))
+    feats32 = g["feats32"]
+    np.testing.assert_array_equal(feats32.astype(np.float64), g["act"])      # fp32 -> fp64 widening is exact
+    acc = device.StatsAccumulator(feats32.shape[1], dev)
+    bs = int(g["batch_size"])
+    for i in range(0, feats32.shape[0], bs):
+        acc.update(torch.as_tensor(feats32[i:i + bs], device=dev))
+    mu, sigma = acc.finalize()
+    np.testing.assert_allclose(mu.cpu().numpy(), g["mu"], rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(sigma.cpu().numpy(), g["sigma"], rtol=0, atol=1e-12 * np.abs(g["sigma"]).max())
+
+
+def test_stats_strided_rows_reset_and_merge(dev):
+    from tise_toolbox_amd import device
+    d = 192
+    x = _cases.pool3_like_features(400, d, seed=5)
+    wide = torch.zeros((400, d + 64), dtype=torch.float32, device=dev)
+    wide[:, :d] = torch.as_tensor(x, device=dev)
+    a = device.StatsAccumulator(d, dev)
+    a.update(wide[:, :d])                                      # ld > d
+    b1, b2 = device.StatsAccumulator(d, dev), device.StatsAccumulator(d, dev)
+    b1.update(torch.as_tensor(x[:150], device=dev))
+    b2.update(torch.as_tensor(x[150:], device=dev))
+    merged = b1.buffer() + b2.buffer()                         # what the all-reduce computes
+    np.testing.assert_allclose(merged.cpu().numpy(), a.buffer().cpu().numpy(), rtol=1e-13, atol=1e-13)
+    a.reset()
+    assert a.count() == 0 and float(a.buffer().abs().max()) == 0.0
+    a.update(torch.empty((0, d), dtype=torch.float32, device=dev))   # empty batch is a no-op
+    assert a.count() == 0
+
+
+# ------------------------------------------------------------------------------------------- linear algebra pieces
+@pytest.mark.parametrize("d,kind", [(8, "fullrank"), (64, "fullrank"), (64, "rankdef"), (192, "rankdef"), (300, "fullrank")])
+def test_pivoted_cholesky_reconstructs(dev, d, kind):
+    from tise_toolbox_amd import device
+    _, s1, _, _ = _cases.frechet_case(d, kind, seed=d)
+    solver = device.FrechetSolver(d, dev)
+    lt, r = solver.pivoted_cholesky(s1)
+    lt = lt.cpu().numpy()
+    rank_ref = np.linalg.matrix_rank(s1)
+    assert rank_ref <= r <= d
+    if kind == "fullrank":
+        assert r == d
+    assert np.abs(lt[r:]).max() == 0.0 if r < d else True
+    rec = lt.T @ lt
+    assert np.abs(rec - s1).max() <= 1e-13 * d * np.abs(s1).max()
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 65, 200, 515])
+def test_eigvalsh_matches_lapack(dev, n):
+    from tise_toolbox_amd import device
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n, n))
+    a = a @ a.T / n + np.diag(rng.uniform(0, 1, n))
+    if n > 16:                                           # clustered + zero eigenvalues
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        lam = np.concatenate([np.zeros(n // 3), np.full(n // 3, 0.5), rng.uniform(0, 3, n - 2 * (n // 3))])
+        a = (q * lam) @ q.T
+        a = (a + a.T) / 2
+    solver = device.FrechetSolver(max(n, 8), dev)
+    w = solver.eigvalsh(torch.as_tensor(a, device=dev)).cpu().numpy()
+    ref = np.linalg.eigvalsh(a)
+    assert np.all(np.diff(w) >= -1e-300)                 # ascending
+    assert np.abs(w - ref).max() <= 5e-14 * n * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------------------------------- Frechet distance
+@pytest.mark.parametrize("d", [8, 64, 192])
+@pytest.mark.parametrize("kind", ["fullrank", "rankdef", "identical", "shifted"])
+def test_frechet_golden(dev, golden_dir, d, kind):
+    """G1: inputs + the reference's own calculate_frechet_distance output."""
+    from tise_toolbox_amd import fid_score
+    g = np.load(os.path.join(golden_dir, f"frechet_d{d}_{kind}.npz"))
+    got = fid_score.calculate_frechet_distance(g["mu1"], g["sigma1"], g["mu2"], g["sigma2"])
+    assert isinstance(got, np.float64)
+    # north_star budget is |dFID| <= 1e-3; the device path is expected far inside it
+    assert abs(got - float(g["fid"])) <= 2e-5, (got, float(g["fid"]))
+    if kind == "fullrank":
+        assert abs(got - float(g["fid"])) <= 1e-9
+    res = fid_score.calculate_frechet_distance.last_result
+    assert res["flags"] & 1 == 0
+    assert (res["rank"] < d) == (kind == "rankdef")
+
+
+@pytest.mark.parametrize("kind", ["fullrank", "rankdef"])
+def test_frechet_d2048_vs_reference_scalar(dev, golden_dir, kind):
+    """G5: BASELINE's d = 2048, incl. the N = 1000 < d rank-deficient case of config 1."""
+    from tise_toolbox_amd import fid_score
+    g = np.load(os.path.join(golden_dir, f"frechet_d2048_{kind}.npz"))
+    mu1, s1, mu2, s2 = _cases.frechet_case_2048(kind, int(g["n1"]), int(g["n2"]))
+    got = fid_score.calculate_frechet_distance(mu1, s1, mu2, s2)
+    ref = float(g["fid"])
+    assert abs(got - ref) <= 1e-3                        # the stated tolerance
+    assert abs(got - ref) <= (1e-9 if kind == "fullrank" else 1e-4), (got, ref)
+    res = fid_score.calculate_frechet_distance.last_result
+    assert res["rank"] == 2048 if kind == "fullrank" else res["rank"] < 1100
+
+
+def test_frechet_properties(dev):
+    from tise_toolbox_amd import fid_score
+    d = 128
+    x = _cases.pool3_like_features(700, d, seed=9)
+    y = _cases.pool3_like_features(650, d, seed=10, shift=0.1)
+    m1, s1 = _cases.stats(x)
+    m2, s2 = _cases.stats(y)
+    f12 = fid_score.calculate_frechet_distance(m1, s1, m2, s2)
+    f21 = fid_score.calculate_frechet_distance(m2, s2, m1, s1)
+    assert abs(f12 - f21) <= 1e-9 * max(1.0, f12)        # symmetric in its arguments
+    f11 = fid_score.calculate_frechet_distance(m1, s1, m1, s1)
+    assert abs(f11) <= 1e-9                              # FID(X, X) ~ 0 (may be slightly negative: no clamp)
+    perm = np.random.default_rng(0).permutation(700)     # permutation invariance of the statistics
+    m1p, s1p = _cases.stats(x[perm])
+    assert abs(fid_score.calculate_frechet_distance(m1p, s1p, m2, s2) - f12) <= 1e-9
+    assert abs(f12 - fid_oracle.calculate_frechet_distance(m1, s1, m2, s2)) <= 1e-9
+
+
+def test_frechet_errors_and_nonfinite(dev, capsys):
+    from tise_toolbox_amd import fid_score
+    with pytest.raises(AssertionError):
+        fid_score.calculate_frechet_distance(np.zeros(3), np.eye(3), np.zeros(4), np.eye(4))
+    with pytest.raises(AssertionError):
+        fid_score.calculate_frechet_distance(np.zeros(3), np.eye(3), np.zeros(3), np.eye(4))
+    s = np.eye(4)
+    s[1, 1] = np.nan
+    out = fid_score.calculate_frechet_distance(np.zeros(4), s, np.zeros(4), np.eye(4))
+    assert "adding 1e-06 to diagonal of cov estimates" in capsys.readouterr().out      # fid_score.py:157-158
+    assert not np.isfinite(out)
+    # scalars / 1-d input go through atleast_1d / atleast_2d like the reference (:143-147)
+    assert abs(fid_score.calculate_frechet_distance(1.0, 4.0, 3.0, 9.0) - (4.0 + 4.0 + 9.0 - 2 * 6.0)) <= 1e-12
+
+
+# ------------------------------------------------------------------------------------------- IS*
+@pytest.mark.parametrize("name", ["coco", "ois", "bird"])
+def test_is_golden(dev, golden_dir, name):
+    from tise_toolbox_amd import inception_score as isc
+    g = np.load(os.path.join(golden_dir, f"is_reduce_{name}.npz"))
+    rule = "ois" if str(g["rule"]) == "ois" else "coco"
+    mean, std, scores = isc.inception_score_from_logits(g["logits"], float(g["temperature"]), int(g["splits"]), rule,
+                                                        bool(g["drop_first"]), return_scores=True)
+    # |dIS| <= 1e-4 is the north_star budget against the reference arithmetic (fp32 for coco/bird)
+    assert abs(mean - float(g["mean32"])) <= 1e-4 and abs(std - float(g["std32"])) <= 1e-4
+    # against exact (fp64) evaluation of the same formula the kernel is at rounding level
+    assert abs(mean - float(g["mean64"])) <= 1e-11 and abs(std - float(g["std64"])) <= 1e-11
+    assert np.all(scores >= 1.0 - 1e-12) and np.all(scores <= g["logits"].shape[1])    # 1 <= IS <= C
+
+
+@pytest.mark.parametrize("n,c,splits,rule", [(1000, 1000, 10, "coco"), (997, 80, 10, "ois"), (23, 51, 10, "coco"),
+                                             (10, 7, 10, "coco"), (64, 1008, 3, "coco")])
+def test_is_sharded_updates_match_oracle(dev, n, c, splits, rule):
+    """Rows arrive in ragged chunks that straddle split borders (the data-parallel case)."""
+    from tise_toolbox_amd import device
+    rng = np.random.default_rng(n + c)
+    logits = (rng.standard_normal((n, c)) * 2.5).astype(np.float32)
+    T = is_oracle.T_OIS if rule == "ois" else is_oracle.T_COCO
+    acc = device.InceptionScoreAccumulator(c, n, T, splits, rule, False, dev)
+    cuts = sorted(set([0, n] + list(rng.integers(0, n + 1, 4))))
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        acc.update(torch.as_tensor(logits[lo:hi], device=dev), lo)
+    mean, std, _ = acc.finalize()
+    m64, s64 = is_oracle.inception_score_from_logits(logits, T, splits, rule, dtype=np.float64)
+    assert abs(mean - m64) <= 1e-10 and abs(std - s64) <= 1e-10
+    A, B = is_oracle.is_sums(logits, T, 0, n, splits, rule)
+    got = acc.acc.cpu().numpy()
+    np.testing.assert_allclose(got[:splits], A, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got[splits:].reshape(splits, c), B, rtol=1e-12, atol=1e-13)

@@ -1,0 +1,165 @@
+"""GPU end-to-end parity: uint8 images -> resize -> InceptionV3 -> statistics -> FID / IS* on the
+device, against the CPU oracle run on the SAME images and the SAME (seeded) weights.
+
+Tolerances are north_star's: |dFID| <= 1e-3, |dIS| <= 1e-4.  The conv stack itself is third-party
+arithmetic (torchvision) with no reference golden vectors: "parity unpinned" for that stage means
+GPU-vs-own-CPU-fp32, which is what is checked here.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fid_oracle, inception_oracle, is_oracle, resize_oracle
+from tests import _cases
+
+pytestmark = pytest.mark.gpu
+
+N_GEN, N_REF = 48, 40
+
+
+@pytest.fixture(scope="module")
+def setup(cuda_device):
+    from tise_toolbox_amd.engine import RealismEngine
+    from tise_toolbox_amd.inception import build_inception3
+    eng = RealismEngine(dims=2048, seed=0, with_logits=True)
+    sd = {k: v.float() for k, v in build_inception3(seed=0).state_dict().items()}
+    gen = _cases.smooth_images(N_GEN, 256, 256, seed=0)
+    ref = _cases.smooth_images(N_REF, 256, 256, seed=1, shift=0.15)
+
+    def oracle_feats(imgs):
+        xs = np.stack([resize_oracle.to_tensor(resize_oracle.resize_bilinear_u8(im, 299, 299)) for im in imgs])
+        feats, logits = [], []
+        for i in range(0, len(xs), 8):
+            o = inception_oracle.inception_forward(sd, torch.from_numpy(xs[i:i + 8]))[3]
+            feats.append(o.flatten(1).numpy())
+            logits.append(inception_oracle.logits_from_pool3(sd, o).numpy())
+        return np.concatenate(feats), np.concatenate(logits)
+
+    fg, lg = oracle_feats(gen)
+    fr, _ = oracle_feats(ref)
+    return dict(eng=eng, gen=gen, ref=ref, fg=fg, lg=lg, fr=fr, dev=cuda_device)
+
+
+def test_features_match_cpu_fp32(setup):
+    eng, dev = setup["eng"], setup["dev"]
+    feats, logits = eng.features_from_u8(torch.as_tensor(setup["gen"], device=dev))
+    f = feats.cpu().numpy()
+    err = np.abs(f - setup["fg"]).max()
+    scale = np.abs(setup["fg"]).max()
+    print("pool3 max abs err", err, "scale", scale)
+    assert err <= 2e-4 * scale            # fp32 conv stack, different summation order + BN folding
+    lerr = np.abs(logits.cpu().numpy() - setup["lg"]).max()
+    assert lerr <= 2e-3 * max(1.0, np.abs(setup["lg"]).max())
+
+
+def test_fid_end_to_end_matches_oracle(setup):
+    """Device: accumulate -> finalize -> Frechet.  Oracle: np.mean/np.cov -> scipy sqrtm (reference form).
+    N << d: both covariances are rank deficient (BASELINE config 1 situation)."""
+    from tise_toolbox_amd import fid_score
+    eng, dev = setup["eng"], setup["dev"]
+    eng.begin(n_total=N_GEN)
+    for i in range(0, N_GEN, 16):
+        eng.step_u8(torch.as_tensor(setup["gen"][i:i + 16], device=dev), i)
+    eng.reduce()
+    mu_g, sig_g = eng.statistics()
+    is_dev = eng.inception_score()
+    eng.begin(n_total=N_REF)
+    for i in range(0, N_REF, 8):
+        eng.step_u8(torch.as_tensor(setup["ref"][i:i + 8], device=dev), i)
+    mu_r, sig_r = eng.statistics()
+    fid_dev = fid_score.calculate_frechet_distance(mu_g, sig_g, mu_r, sig_r)
+
+    m1, s1 = fid_oracle.calculate_activation_statistics(setup["fg"])
+    m2, s2 = fid_oracle.calculate_activation_statistics(setup["fr"])
+    fid_cpu = fid_oracle.calculate_frechet_distance(m1, s1, m2, s2)
+    print("FID device", fid_dev, "oracle", fid_cpu)
+    assert abs(fid_dev - fid_cpu) <= 1e-3
+    is_cpu = is_oracle.inception_score_from_logits(setup["lg"], is_oracle.T_COCO, 10, "coco", dtype=np.float32)
+    print("IS device", is_dev, "oracle", is_cpu)
+    assert abs(is_dev[0] - is_cpu[0]) <= 1e-4 and abs(is_dev[1] - is_cpu[1]) <= 1e-4
+
+
+def test_reference_api_functions(setup, tmp_path, capsys):
+    """The drop-in functions with the reference's calling conventions (float CHW batches in [0,1])."""
+    from tise_toolbox_amd import fid_score
+    from tise_toolbox_amd.inception import InceptionV3
+    model = InceptionV3([3], seed=0)
+    bs = 8
+    x = np.stack([resize_oracle.to_tensor(resize_oracle.resize_bilinear_u8(im, 299, 299)) for im in setup["gen"][:20]])
+    loader = [torch.from_numpy(x[i * bs:(i + 1) * bs]) for i in range(20 // bs)]       # drop_last: 16 of 20 used
+    act = fid_score.get_activations(loader, model, bs, 2048, cuda=True, verbose=True)
+    assert " done" in capsys.readouterr().out
+    assert act.dtype == np.float64 and act.shape == (16, 2048)
+    assert np.abs(act - setup["fg"][:16]).max() <= 2e-4 * np.abs(setup["fg"]).max()
+    mu, sigma = fid_score.calculate_activation_statistics(loader, model, bs, 2048, cuda=True, verbose=False)
+    mu_ref, sigma_ref = fid_oracle.calculate_activation_statistics(act)
+    np.testing.assert_allclose(mu, mu_ref, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(sigma, sigma_ref, rtol=0, atol=1e-12)
+    from tise_toolbox_amd import _lib
+    with pytest.raises(_lib.TiseLibraryError):
+        fid_score.get_activations(loader, model, bs, 2048, cuda=False)
+    # lower blocks: spatial maps are average-pooled (fid_score.py:110-111)
+    m192 = InceptionV3([1], seed=0)
+    a192 = fid_score.get_activations(loader[:1], m192, bs, 192, cuda=True, verbose=False)
+    assert a192.shape == (8, 192)
+
+
+def test_cli_end_to_end(setup, tmp_path, capsys):
+    """fid_score CLI on directories of PNGs + an .npz, result text and value vs the oracle pipeline."""
+    from PIL import Image
+    from tise_toolbox_amd import fid_score, img_data
+    gdir, rdir = tmp_path / "gen", tmp_path / "ref" / "sub"
+    gdir.mkdir()
+    rdir.mkdir(parents=True)
+    for i in range(21):
+        Image.fromarray(setup["gen"][i]).save(gdir / f"{i:05d}.png")
+    (gdir / "notes.txt").write_text("ignored")
+    for i in range(18):
+        Image.fromarray(setup["ref"][i]).save(rdir / f"{i:05d}.png")
+    npz = tmp_path / "ref_stats.npz"
+    out1 = tmp_path / "o1.txt"
+    v1 = fid_score.main(["--batch-size", "5", "--path1", str(tmp_path / "ref"), "--path2", str(gdir),
+                         "--saved_file", str(out1), "--gpu", "0", "--num-workers", "2", "--save-stats", str(tmp_path / "gen_stats.npz")])
+    assert out1.read_text() == f"FID: {v1}"
+    # oracle pipeline on the same files, same walk order, same drop-last rule
+    def oracle_stats(root, bs):
+        files = img_data.get_filenames(str(root))
+        files = files[:fid_oracle.n_used_images(len(files), bs)]
+        idx = []
+        pool = {"gen": setup["gen"], "ref": setup["ref"]}
+        feats = setup["fg"] if "gen" in str(root) else setup["fr"]
+        for f in files:
+            idx.append(int(os.path.basename(f).split(".")[0]))
+        return fid_oracle.calculate_activation_statistics(feats[idx])
+    m1, s1 = oracle_stats(tmp_path / "ref", 5)
+    m2, s2 = oracle_stats(gdir, 5)
+    want = fid_oracle.calculate_frechet_distance(m1, s1, m2, s2)
+    assert abs(v1 - want) <= 1e-3
+    # .npz branch (fid_score.py:200-203) with stats written by --save-stats
+    np.savez(npz, mu=m1, sigma=s1)
+    out2 = tmp_path / "o2.txt"
+    v2 = fid_score.main(["--batch-size", "5", "--path1", str(npz), "--path2", str(gdir), "--saved_file", str(out2),
+                         "--label", "O-FID", "--num-workers", "0"])
+    assert out2.read_text().startswith("O-FID: ") and abs(v2 - want) <= 1e-3
+    g = np.load(tmp_path / "gen_stats.npz")
+    np.testing.assert_allclose(g["mu"], m2, atol=1e-5)
+    with pytest.raises(RuntimeError, match="Invalid path"):
+        fid_score.main(["--path1", str(tmp_path / "missing"), "--path2", str(gdir)])
+
+
+def test_is_cli(setup, tmp_path):
+    from PIL import Image
+    from tise_toolbox_amd import inception_score as isc, img_data
+    d = tmp_path / "imgs"
+    d.mkdir()
+    for i in range(30):
+        Image.fromarray(setup["gen"][i]).save(d / f"{i:05d}.png")
+    out = tmp_path / "is.txt"
+    mean, std = isc.main(["--image_folder", str(d), "--saved_file", str(out), "--batch-size", "7"])
+    assert out.read_text() == "[Inception Score] mean: {:.5f} std: {:.5f}".format(mean, std)
+    files = img_data.get_filenames(str(d))
+    idx = [int(os.path.basename(f).split(".")[0]) for f in files]
+    want = is_oracle.inception_score_from_logits(setup["lg"][idx], is_oracle.T_COCO, 10, "coco", dtype=np.float32)
+    assert abs(mean - want[0]) <= 1e-4 and abs(std - want[1]) <= 1e-4

@@ -1,0 +1,122 @@
+"""CPU: the oracle restatement against the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fid_oracle, is_oracle, resize_oracle
+from tests import _cases
+
+
+@pytest.mark.parametrize("d", [8, 64, 192])
+@pytest.mark.parametrize("kind", ["fullrank", "rankdef", "identical", "shifted"])
+def test_frechet_matches_reference(golden_dir, d, kind):
+    g = np.load(os.path.join(golden_dir, f"frechet_d{d}_{kind}.npz"))
+    got = fid_oracle.calculate_frechet_distance(g["mu1"], g["sigma1"], g["mu2"], g["sigma2"])
+    # same scipy, same statements: agreement to rounding of the last few ulps of the traces
+    assert abs(got - float(g["fid"])) <= 1e-9 * max(1.0, abs(float(g["fid"])))
+    sym = fid_oracle.calculate_frechet_distance_symmetric(g["mu1"], g["sigma1"], g["mu2"], g["sigma2"])
+    assert abs(sym - float(g["fid"])) <= 1e-6
+
+
+def test_frechet_cases_regenerate(golden_dir):
+    """_cases.frechet_case must regenerate exactly the matrices stored in the fixtures."""
+    g = np.load(os.path.join(golden_dir, "frechet_d64_fullrank.npz"))
+    mu1, s1, mu2, s2 = _cases.frechet_case(64, "fullrank", seed=64)
+    np.testing.assert_array_equal(s1, g["sigma1"])
+    np.testing.assert_array_equal(mu2, g["mu2"])
+
+
+def test_frechet_shape_asserts():
+    with pytest.raises(AssertionError):
+        fid_oracle.calculate_frechet_distance(np.zeros(3), np.eye(3), np.zeros(4), np.eye(4))
+
+
+def test_activation_statistics_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "actstats_fake_model.npz"))
+    bs, d = int(g["batch_size"]), int(g["dims"])
+    data, w = g["data"], g["w"]
+    n_batches = data.shape[0] // bs
+    loader = [data[i * bs:(i + 1) * bs] for i in range(n_batches)]
+
+    def forward(b):
+        y = np.maximum(b.reshape(b.shape[0], -1).astype(np.float32) @ w.astype(np.float32), 0.0)
+        return y.reshape(b.shape[0], d, 2, 2)
+
+    act = fid_oracle.get_activations(loader, forward, bs, d)
+    assert act.dtype == np.float64 and act.shape == g["act"].shape == (fid_oracle.n_used_images(37, bs), d)
+    np.testing.assert_allclose(act, g["act"], rtol=0, atol=2e-6)      # fp32 matmul order differs (torch vs numpy)
+    mu, sigma = fid_oracle.calculate_activation_statistics(g["act"])
+    np.testing.assert_allclose(mu, g["mu"], rtol=1e-14, atol=0)
+    np.testing.assert_allclose(sigma, g["sigma"], rtol=1e-13, atol=1e-18)
+    # additive form used on the device
+    x = g["act"]
+    mu2, sigma2 = fid_oracle.statistics_from_sums(x.shape[0], x.sum(0), x.T @ x)
+    np.testing.assert_allclose(mu2, g["mu"], rtol=1e-13)
+    np.testing.assert_allclose(sigma2, g["sigma"], rtol=1e-9, atol=1e-13)
+
+
+def test_drop_last_bookkeeping():
+    assert fid_oracle.n_used_images(30000, 50) == 30000
+    assert fid_oracle.n_used_images(1000, 64) == 960
+    assert fid_oracle.n_used_images(37, 5) == 35
+    assert fid_oracle.n_used_images(3, 5) == 0
+
+
+@pytest.mark.parametrize("name", ["coco", "ois", "bird"])
+def test_is_reduction_vectors(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"is_reduce_{name}.npz"))
+    logits, T = g["logits"], float(g["temperature"])
+    rule, drop = str(g["rule"]), bool(g["drop_first"])
+    m32, s32 = is_oracle.inception_score_from_logits(logits, T, 10, rule, drop, dtype=np.float32)
+    m64, s64 = is_oracle.inception_score_from_logits(logits, T, 10, rule, drop, dtype=np.float64)
+    assert m32 == pytest.approx(float(g["mean32"]), abs=1e-6) and s32 == pytest.approx(float(g["std32"]), abs=1e-6)
+    assert m64 == pytest.approx(float(g["mean64"]), abs=1e-12) and s64 == pytest.approx(float(g["std64"]), abs=1e-12)
+    assert abs(m32 - m64) < 1e-4 and abs(s32 - s64) < 1e-4          # the north_star budget covers fp32 vs fp64
+    # additive one-pass form (what the kernel accumulates) == the reference loop, in two shards
+    n = logits.shape[0]
+    cut = n // 3
+    A1, B1 = is_oracle.is_sums(logits[:cut], T, 0, n, 10, rule, drop)
+    A2, B2 = is_oracle.is_sums(logits[cut:], T, cut, n, 10, rule, drop)
+    m, s = is_oracle.is_finalize(A1 + A2, B1 + B2, n, 10, rule)
+    assert m == pytest.approx(m64, abs=1e-10) and s == pytest.approx(s64, abs=1e-10)
+
+
+def test_ois_form_equals_coco_form_when_divisible():
+    rng = np.random.default_rng(0)
+    logits = rng.standard_normal((200, 40)).astype(np.float32)
+    a = is_oracle.inception_score_from_logits(logits, is_oracle.T_OIS, 10, "ois", dtype=np.float64)
+    b = is_oracle.inception_score_from_logits(logits, is_oracle.T_OIS, 10, "coco", dtype=np.float64)
+    assert a[0] == pytest.approx(b[0], abs=1e-9) and a[1] == pytest.approx(b[1], abs=1e-9)
+
+
+def test_pil_resize_bit_exact(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pil_resize_299.npz"))
+    names = [k[3:] for k in g.files if k.startswith("in_")]
+    assert len(names) >= 6
+    for k in names:
+        got = resize_oracle.resize_bilinear_u8(g["in_" + k], 299, 299)
+        np.testing.assert_array_equal(got, g["out_" + k], err_msg=k)
+
+
+def test_pil_resize_against_installed_pillow():
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    for h, w in [(256, 256), (31, 517), (640, 480)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((299, 299), Image.BILINEAR))
+        np.testing.assert_array_equal(resize_oracle.resize_bilinear_u8(img, 299, 299), ref)
+
+
+def test_d2048_cases_regenerate(golden_dir):
+    """The d=2048 fixtures store only the reference scalar; check the regenerated inputs match the
+    probes stored beside it (guards against generator drift)."""
+    for kind in ("fullrank", "rankdef"):
+        g = np.load(os.path.join(golden_dir, f"frechet_d2048_{kind}.npz"))
+        mu1, s1, mu2, s2 = _cases.frechet_case_2048(kind, int(g["n1"]), int(g["n2"]))
+        np.testing.assert_allclose(s1[:4, :4], g["sigma1_probe"], rtol=1e-12)
+        np.testing.assert_allclose(s2[:4, :4], g["sigma2_probe"], rtol=1e-12)
+        assert np.trace(s1) == pytest.approx(float(g["trace1"]), rel=1e-12)

@@ -1,0 +1,46 @@
+"""Build recipe for libtise_hip.so (hipcc, gfx950 only, in-tree output).
+
+``python -m tise_toolbox_amd.build`` or ``__graft_entry__.build()``.  The library is
+written next to this file so that it travels with the source tree (it is git-ignored).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libtise_hip.so")
+SOURCES = ["capi.hip", "stats.hip", "resize.hip", "is_score.hip", "frechet.hip"]
+HEADERS = ["common.h", "gemm_tile.h", os.path.join("..", "..", "include", "tise_hip.h")]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.getmtime(p) > t for p in deps if os.path.exists(p))
+
+
+def build(force=False, verbose=True):
+    """Compile every HIP source for gfx950 into tise_toolbox_amd/libtise_hip.so."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
+           "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print("[tise build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,43 @@
+// Library-level entry points of libtise_hip.so: status strings, last HIP error, device probe.
+#include <atomic>
+#include "common.h"
+
+static std::atomic<int> g_last_hip_error{0};
+
+extern "C" {
+
+void tise_set_last_hip_error(int e) { g_last_hip_error.store(e); }
+
+int tise_last_hip_error(void) { return g_last_hip_error.load(); }
+
+int tise_version(void) { return 1; }
+
+const char* tise_status_string(int status) {
+    switch (status) {
+        case TISE_OK: return "ok";
+        case TISE_ERR_INVALID_ARG: return "invalid argument";
+        case TISE_ERR_HIP: return "HIP runtime error";
+        case TISE_ERR_NO_DEVICE: return "no gfx950 device";
+        case TISE_ERR_UNSUPPORTED: return "unsupported size";
+        default: return "unknown status";
+    }
+}
+
+int tise_device_info(int* cu_count, int* gcn_arch_is_gfx950, size_t* total_mem) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { tise_set_last_hip_error((int)e); return TISE_ERR_NO_DEVICE; }
+    int dev = 0;
+    TISE_HIP_CHECK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    TISE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (gcn_arch_is_gfx950) {
+        const char* a = prop.gcnArchName;
+        *gcn_arch_is_gfx950 = (a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0') ? 1 : 0;
+    }
+    if (total_mem) *total_mem = prop.totalGlobalMem;
+    return TISE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,291 @@
+// PIL-exact uint8 bilinear resize fused with ToTensor() and the InceptionV3 input affine.
+//
+// Replaces transforms.Resize((299, 299)) + transforms.ToTensor() (reference
+// image_realism/FID/fid_score.py:208-213 -> Pillow Image.resize(BILINEAR), 8 bits per channel) and the
+// per-channel affine of image_realism/FID/inception.py:120-124.  Pillow's algorithm (Resample.c):
+// per output coordinate a window [xmin, xmin+cnt) of normalised triangle weights rounded to 22-bit
+// integers; out = clip8((sum src*k + 2^21) >> 22); horizontal pass first, stored as uint8, then
+// the vertical pass on that uint8 image.  Integer arithmetic => the kernel is bit-exact.
+//
+// One workgroup produces RT output rows of one image: it stages the source rows those output
+// rows depend on in LDS (16-byte coalesced loads), runs the horizontal pass LDS->LDS, then the
+// vertical pass LDS->registers, maps each byte through a 3x256 fp32 table (v/255 then the affine,
+// tabulated on the host with the reference's own op order) and stores fp32 rows coalesced, either
+// planar NCHW or interleaved NHWC (torch.channels_last storage).
+//
+// Bound: HBM.  Algorithmic bytes per image: h*w*3 read + oh*ow*3*4 written
+// (256x256 -> 299x299: 196 608 + 1 072 812 = 1 269 420 B).
+#include <math.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
+#include "common.h"
+
+#define PRECISION_BITS 22
+
+namespace {
+
+struct CoeffTable {
+    int in_size, out_size, ksize;
+    std::vector<int> bounds;   // out_size * 2 : (min, count)
+    std::vector<int> kk;       // out_size * ksize
+};
+
+double bilinear_filter(double x) {
+    if (x < 0.0) x = -x;
+    return x < 1.0 ? 1.0 - x : 0.0;
+}
+
+// Resample.c precompute_coeffs() + normalize_coeffs_8bpc()
+void precompute_coeffs(int in_size, int out_size, CoeffTable& t) {
+    double scale = (double)in_size / out_size;
+    double filterscale = scale < 1.0 ? 1.0 : scale;
+    double support = 1.0 * filterscale;
+    int ksize = (int)ceil(support) * 2 + 1;
+    t.in_size = in_size; t.out_size = out_size; t.ksize = ksize;
+    t.bounds.assign((size_t)out_size * 2, 0);
+    t.kk.assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; ++xx) {
+        double center = (xx + 0.5) * scale;
+        double ww = 0.0;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) {
+            double w = bilinear_filter((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; ++x) {
+            if (ww != 0.0) k[x] /= ww;
+            double v = k[x];
+            t.kk[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << PRECISION_BITS)) : (int)(0.5 + v * (1 << PRECISION_BITS));
+        }
+        t.bounds[xx * 2 + 0] = xmin;
+        t.bounds[xx * 2 + 1] = xmax;
+    }
+}
+
+struct DevPlan {
+    int h, w, oh, ow;
+    int ksx, ksy;
+    int rt;          // output rows per workgroup
+    int span;        // max source rows any row tile needs
+    int* dev;        // bounds_x[ow*2] | kx[ow*ksx] | bounds_y[oh*2] | ky[oh*ksy] | tile_y0[ntiles]
+    int off_kx, off_by, off_ky, off_t0, ntiles;
+};
+
+std::mutex g_plan_mu;
+std::vector<DevPlan> g_plans;
+
+int get_plan(int h, int w, int oh, int ow, DevPlan* out) {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    for (const DevPlan& p : g_plans)
+        if (p.h == h && p.w == w && p.oh == oh && p.ow == ow) { *out = p; return TISE_OK; }
+    CoeffTable tx, ty;
+    precompute_coeffs(w, ow, tx);
+    precompute_coeffs(h, oh, ty);
+    DevPlan p;
+    p.h = h; p.w = w; p.oh = oh; p.ow = ow; p.ksx = tx.ksize; p.ksy = ty.ksize;
+    // pick the row tile so staged source rows + horizontal-pass rows fit comfortably in LDS
+    const size_t lds_budget = 144 * 1024;
+    int rt = 8;
+    int span = 0;
+    for (;; rt >>= 1) {
+        span = 0;
+        for (int y0 = 0; y0 < oh; y0 += rt) {
+            int y1 = (y0 + rt < oh) ? y0 + rt : oh;
+            int lo = ty.bounds[y0 * 2], hi = 0;
+            for (int y = y0; y < y1; ++y) {
+                int e = ty.bounds[y * 2] + ty.bounds[y * 2 + 1];
+                if (e > hi) hi = e;
+                if (ty.bounds[y * 2] < lo) lo = ty.bounds[y * 2];
+            }
+            if (hi - lo > span) span = hi - lo;
+        }
+        size_t need = (size_t)span * ((size_t)((w * 3 + 15) & ~15) + (size_t)((ow * 3 + 3) & ~3)) + 3 * 256 * 4;
+        if (need <= lds_budget) break;
+        if (rt == 1) return TISE_ERR_UNSUPPORTED;
+    }
+    p.rt = rt; p.span = span;
+    p.ntiles = (oh + rt - 1) / rt;
+    std::vector<int> host;
+    host.insert(host.end(), tx.bounds.begin(), tx.bounds.end());
+    p.off_kx = (int)host.size();
+    host.insert(host.end(), tx.kk.begin(), tx.kk.end());
+    p.off_by = (int)host.size();
+    host.insert(host.end(), ty.bounds.begin(), ty.bounds.end());
+    p.off_ky = (int)host.size();
+    host.insert(host.end(), ty.kk.begin(), ty.kk.end());
+    p.off_t0 = (int)host.size();
+    for (int t = 0; t < p.ntiles; ++t) {
+        int lo = ty.bounds[(t * rt) * 2];
+        int y1 = (t * rt + rt < oh) ? t * rt + rt : oh;
+        for (int y = t * rt; y < y1; ++y) if (ty.bounds[y * 2] < lo) lo = ty.bounds[y * 2];
+        host.push_back(lo);
+    }
+    p.dev = nullptr;
+    TISE_HIP_CHECK(hipMalloc((void**)&p.dev, host.size() * sizeof(int)));
+    TISE_HIP_CHECK(hipMemcpy(p.dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (g_plans.size() >= 64) { hipFree(g_plans.front().dev); g_plans.erase(g_plans.begin()); }
+    g_plans.push_back(p);
+    *out = p;
+    return TISE_OK;
+}
+
+// device copies of the 3x256 fp32 byte->value tables, keyed by content (a run uses one or two)
+struct LutEntry { float host[3 * 256]; float* dev; };
+std::mutex g_lut_mu;
+std::vector<LutEntry*> g_luts;
+
+int get_lut(const float* lut, float** dev) {
+    std::lock_guard<std::mutex> lk(g_lut_mu);
+    for (LutEntry* e : g_luts)
+        if (memcmp(e->host, lut, sizeof(e->host)) == 0) { *dev = e->dev; return TISE_OK; }
+    LutEntry* e = new LutEntry;
+    memcpy(e->host, lut, sizeof(e->host));
+    e->dev = nullptr;
+    hipError_t err = hipMalloc((void**)&e->dev, sizeof(e->host));
+    if (err == hipSuccess) err = hipMemcpy(e->dev, e->host, sizeof(e->host), hipMemcpyHostToDevice);
+    if (err != hipSuccess) { tise_set_last_hip_error((int)err); if (e->dev) hipFree(e->dev); delete e; return TISE_ERR_HIP; }
+    g_luts.push_back(e);
+    *dev = e->dev;
+    return TISE_OK;
+}
+
+__device__ __forceinline__ uint8_t clip8(int v) {
+    v >>= PRECISION_BITS;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
+    const uint8_t* __restrict__ src, int h, int w, float* __restrict__ dst, int oh, int ow, int nhwc,
+    const int* __restrict__ plan, int ksx, int ksy, int off_kx, int off_by, int off_ky, int off_t0, int rt, int span,
+    const float* __restrict__ lut, uint8_t* __restrict__ u8_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int src_pitch = (w * 3 + 15) & ~15;
+    const int tmp_pitch = (ow * 3 + 3) & ~3;
+    float* lut_s = reinterpret_cast<float*>(smem);                       // 3*256 floats
+    unsigned char* srow = smem + 3 * 256 * 4;                            // span x src_pitch
+    unsigned char* trow = srow + (size_t)span * src_pitch;               // span x tmp_pitch
+    const int* bx = plan;
+    const int* kx = plan + off_kx;
+    const int* by = plan + off_by;
+    const int* ky = plan + off_ky;
+
+    const int img = blockIdx.y;
+    const int tile = blockIdx.x;
+    const int oy0 = tile * rt;
+    const int oy1 = min(oy0 + rt, oh);
+    const int ys0 = plan[off_t0 + tile];
+    // last source row needed by this tile
+    int ys1 = 0;
+    for (int y = oy0; y < oy1; ++y) ys1 = max(ys1, by[2 * y] + by[2 * y + 1]);
+    const int nrows = ys1 - ys0;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < 3 * 256; i += 256) lut_s[i] = lut[i];
+
+    // stage source rows [ys0, ys1): rows are contiguous in memory (w*3 bytes each)
+    const uint8_t* sbase = src + ((size_t)img * h + ys0) * (size_t)w * 3;
+    const int row_bytes = w * 3;
+    const size_t tot = (size_t)nrows * row_bytes;
+    if ((((uintptr_t)sbase) & 15) == 0 && (row_bytes & 15) == 0) {
+        const int vec_per_row = row_bytes >> 4;
+        for (int i = tid; i < nrows * vec_per_row; i += 256) {
+            const int r = i / vec_per_row, c = i - r * vec_per_row;
+            *reinterpret_cast<uint4*>(srow + (size_t)r * src_pitch + c * 16) =
+                *reinterpret_cast<const uint4*>(sbase + (size_t)r * row_bytes + c * 16);
+        }
+    } else {
+        for (size_t i = tid; i < tot; i += 256) {
+            const int r = (int)(i / row_bytes), c = (int)(i - (size_t)r * row_bytes);
+            srow[(size_t)r * src_pitch + c] = sbase[i];
+        }
+    }
+    __syncthreads();
+
+    // horizontal pass: trow[r][ox*3+c] for every staged row (skipped, i.e. a copy, when w == ow: Pillow
+    // only resamples an axis whose size changes)
+    const int hcount = nrows * ow * 3;
+    if (w == ow) {
+        for (int i = tid; i < hcount; i += 256) {
+            const int r = i / (ow * 3), e = i - r * (ow * 3);
+            trow[(size_t)r * tmp_pitch + e] = srow[(size_t)r * src_pitch + e];
+        }
+    } else {
+        for (int i = tid; i < hcount; i += 256) {
+            const int r = i / (ow * 3), e = i - r * (ow * 3);
+            const int ox = e / 3, c = e - ox * 3;
+            const int xmin = bx[2 * ox], cnt = bx[2 * ox + 1];
+            const int* k = kx + ox * ksx;
+            const unsigned char* sp = srow + (size_t)r * src_pitch + xmin * 3 + c;
+            int ss = 1 << (PRECISION_BITS - 1);
+            for (int x = 0; x < cnt; ++x) ss += (int)sp[x * 3] * k[x];
+            trow[(size_t)r * tmp_pitch + e] = clip8(ss);
+        }
+    }
+    __syncthreads();
+
+    // vertical pass + table + store
+    const int orows = oy1 - oy0;
+    const int ocount = orows * ow * 3;
+    for (int i = tid; i < ocount; i += 256) {
+        int oy, ox, c;
+        if (nhwc) {                     // i = (oy, ox, c): interleaved output is contiguous in i
+            oy = i / (ow * 3);
+            const int e = i - oy * (ow * 3);
+            ox = e / 3; c = e - ox * 3;
+        } else {                        // i = (c, oy, ox): planar rows contiguous in ox
+            c = i / (orows * ow);
+            const int e = i - c * (orows * ow);
+            oy = e / ow; ox = e - oy * ow;
+        }
+        const int y = oy0 + oy;
+        uint8_t v;
+        if (h == oh) {
+            v = trow[(size_t)(y - ys0) * tmp_pitch + ox * 3 + c];
+        } else {
+            const int ymin = by[2 * y], cnt = by[2 * y + 1];
+            const int* k = ky + y * ksy;
+            const unsigned char* tp = trow + (size_t)(ymin - ys0) * tmp_pitch + ox * 3 + c;
+            int ss = 1 << (PRECISION_BITS - 1);
+            for (int yy = 0; yy < cnt; ++yy) ss += (int)tp[(size_t)yy * tmp_pitch] * k[yy];
+            v = clip8(ss);
+        }
+        const float f = lut_s[c * 256 + v];
+        if (nhwc) dst[(((size_t)img * oh + y) * ow + ox) * 3 + c] = f;
+        else dst[(((size_t)img * 3 + c) * oh + y) * ow + ox] = f;
+        if (u8_out) u8_out[(((size_t)img * oh + y) * ow + ox) * 3 + c] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int tise_resize_bilinear_u8(const uint8_t* src_dev, int n, int h, int w, float* dst_dev, int oh, int ow,
+                                       int nhwc, const float* lut, uint8_t* u8_out_dev, void* stream) {
+    if (n < 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || !lut || (n > 0 && (!src_dev || !dst_dev)))
+        return TISE_ERR_INVALID_ARG;
+    if (n == 0) return TISE_OK;
+    if (n > 65535) return TISE_ERR_UNSUPPORTED;
+    DevPlan p;
+    int rc = get_plan(h, w, oh, ow, &p);
+    if (rc != TISE_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float* lut_dev = nullptr;
+    rc = get_lut(lut, &lut_dev);
+    if (rc != TISE_OK) return rc;
+    const size_t lds = 3 * 256 * 4 + (size_t)p.span * (((w * 3 + 15) & ~15) + ((ow * 3 + 3) & ~3));
+    if (lds > 48 * 1024)
+        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_bilinear_u8_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(resize_bilinear_u8_kernel, dim3(p.ntiles, n), dim3(256), lds, st, src_dev, h, w, dst_dev, oh, ow,
+                       nhwc, p.dev, p.ksx, p.ksy, p.off_kx, p.off_by, p.off_ky, p.off_t0, p.rt, p.span, lut_dev,
+                       u8_out_dev);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}

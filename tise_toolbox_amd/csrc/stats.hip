@@ -1,0 +1,168 @@
+// Streaming fp64 activation statistics {n, s = sum x, S = sum x x^T} from fp32 feature rows.
+//
+// Replaces pred.cpu().numpy() -> float64 pred_arr, np.mean(act, 0), np.cov(act, rowvar=False)
+// (reference image_realism/FID/fid_score.py:98,113,194-195): feature rows stay in HBM, each
+// batch is folded into additive sufficient statistics, and (mu, sigma) fall out at the end:
+//     mu = s / n          sigma = (S - s s^T / n) / (n - 1)          (np.cov, ddof = 1)
+//
+// Buffer layout (one allocation, handed as-is to the RCCL all-reduce):
+//     [ S : d*d doubles, row-major, only 64x64 tiles with tile_col >= tile_row are written |
+//       s : d doubles | n : 1 double | pad : 1 double ]
+//
+// Kernels
+//   syrk_f32_upper_kernel  S += X^T X.  fp32 rows are widened exactly to fp64 on the way into
+//       LDS (every fp32*fp32 product is exact in fp64), contraction on v_mfma_f64_16x16x4_f64.
+//       Bound: fp64 MFMA.  Algorithmic work per feature row: d*(d+64) flop (upper tiles only).
+//   colsum_f32_kernel      s += sum_rows X, n += rows.  Bound: HBM (reads X once: 4*d B/row).
+//   stats_finalize_kernel  mu, sigma (mirrors the upper tiles).  Bound: HBM, 3*8*d*d bytes.
+#include <new>
+#include "common.h"
+#include "gemm_tile.h"
+
+struct tise_stats {
+    int d;
+    int tiles;        // ceil(d / 64)
+    double* buf;      // device: S | s | n | pad
+    size_t n_doubles;
+};
+
+// XCD-aware, bijective remap of a linear block id: blocks that share id % 8 share an XCD (and
+// its L2), so give each XCD one contiguous run of the tile list (cdna guide T1, bijective form).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__global__ __launch_bounds__(256) void syrk_f32_upper_kernel(const float* __restrict__ X, int64_t ld, int rows,
+                                                             int d, int tiles, double* __restrict__ S) {
+    __shared__ double lds[GT_LDS_DOUBLES];
+    const int nwg = tiles * (tiles + 1) / 2;
+    int t = xcd_remap(blockIdx.x, nwg);
+    // decode upper-triangular tile (tm <= tn) from the row-major list
+    int tm = 0;
+    while (t >= tiles - tm) { t -= tiles - tm; ++tm; }
+    const int tn = tm + t;
+    double4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // A(m,k) = X[k][m0+m], B(k,n) = X[k][n0+n]
+    gemm_tile_64x64<float, float>(X, 1, ld, X, ld, 1, d, d, rows, tm * 64, tn * 64, acc, lds);
+    gemm_tile_store<true>(S, d, d, d, tm * 64, tn * 64, acc);
+}
+
+// 256 threads = 64 columns x 4 row phases; fixed summation order => bitwise reproducible.
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ X, int64_t ld, int rows, int d,
+                                                         double* __restrict__ s, double* __restrict__ n) {
+    __shared__ double part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ph = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (c < d)
+        for (int r = ph; r < rows; r += 4) acc += (double)X[(int64_t)r * ld + c];
+    part[ph][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (ph == 0 && c < d) s[c] += ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n += (double)rows;
+}
+
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const double* __restrict__ S, const double* __restrict__ s,
+                                                             const double* __restrict__ n, int d,
+                                                             double* __restrict__ mu, double* __restrict__ sigma) {
+    const double nn = *n;
+    const int64_t total = (int64_t)d * d;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / d), j = (int)(e % d);
+        // S holds tile (ti, tj) only for tj >= ti; inside a diagonal tile the full 64x64 block is present
+        const int ti = i >> 6, tj = j >> 6;
+        const double sij = (tj >= ti) ? S[(int64_t)i * d + j] : S[(int64_t)j * d + i];
+        sigma[e] = (sij - s[i] * s[j] / nn) / (nn - 1.0);
+        if (j == 0) mu[i] = s[i] / nn;
+    }
+}
+
+extern "C" {
+
+int tise_stats_create(int d, tise_stats_t** out) {
+    if (d <= 0 || d > 8192 || out == nullptr) return TISE_ERR_INVALID_ARG;
+    tise_stats* h = new (std::nothrow) tise_stats;
+    if (!h) return TISE_ERR_INVALID_ARG;
+    h->d = d;
+    h->tiles = ceil_div(d, 64);
+    h->n_doubles = (size_t)d * d + d + 2;
+    h->buf = nullptr;
+    hipError_t e = hipMalloc((void**)&h->buf, h->n_doubles * sizeof(double));
+    if (e != hipSuccess) { tise_set_last_hip_error((int)e); delete h; return TISE_ERR_HIP; }
+    e = hipMemset(h->buf, 0, h->n_doubles * sizeof(double));
+    if (e != hipSuccess) { tise_set_last_hip_error((int)e); hipFree(h->buf); delete h; return TISE_ERR_HIP; }
+    *out = h;
+    return TISE_OK;
+}
+
+int tise_stats_destroy(tise_stats_t* h) {
+    if (!h) return TISE_OK;
+    hipFree(h->buf);
+    delete h;
+    return TISE_OK;
+}
+
+int tise_stats_reset(tise_stats_t* h, void* stream) {
+    if (!h) return TISE_ERR_INVALID_ARG;
+    TISE_HIP_CHECK(hipMemsetAsync(h->buf, 0, h->n_doubles * sizeof(double), (hipStream_t)stream));
+    return TISE_OK;
+}
+
+static int stats_check(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld) {
+    if (!h || (!feats_dev && rows > 0) || rows < 0 || ld < h->d || rows > (int64_t)1 << 30) return TISE_ERR_INVALID_ARG;
+    return TISE_OK;
+}
+
+int tise_stats_update_cov(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream) {
+    int rc = stats_check(h, feats_dev, rows, ld);
+    if (rc != TISE_OK || rows == 0) return rc;
+    const int nwg = h->tiles * (h->tiles + 1) / 2;
+    hipLaunchKernelGGL(syrk_f32_upper_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, feats_dev, ld, (int)rows,
+                       h->d, h->tiles, h->buf);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+int tise_stats_update_sum(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream) {
+    int rc = stats_check(h, feats_dev, rows, ld);
+    if (rc != TISE_OK || rows == 0) return rc;
+    double* s = h->buf + (size_t)h->d * h->d;
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3(h->tiles), dim3(256), 0, (hipStream_t)stream, feats_dev, ld, (int)rows,
+                       h->d, s, s + h->d);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+int tise_stats_update(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream) {
+    int rc = tise_stats_update_cov(h, feats_dev, rows, ld, stream);
+    if (rc != TISE_OK) return rc;
+    return tise_stats_update_sum(h, feats_dev, rows, ld, stream);
+}
+
+int tise_stats_buffer(tise_stats_t* h, double** buf_dev, size_t* n_doubles) {
+    if (!h || !buf_dev || !n_doubles) return TISE_ERR_INVALID_ARG;
+    *buf_dev = h->buf;
+    *n_doubles = h->n_doubles;
+    return TISE_OK;
+}
+
+int tise_stats_finalize(tise_stats_t* h, double* mu_dev, double* sigma_dev, void* stream) {
+    if (!h || !mu_dev || !sigma_dev) return TISE_ERR_INVALID_ARG;
+    const int d = h->d;
+    const double* S = h->buf;
+    const double* s = h->buf + (size_t)d * d;
+    const double* n = s + d;
+    int blocks = (int)((((int64_t)d * d) + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, S, s, n, d, mu_dev, sigma_dev);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,272 @@
+"""Torch-tensor front ends of the libtise_hip.so entry points.
+
+PyTorch is only plumbing here (device memory, streams): every function passes raw
+``data_ptr()`` values and the current HIP stream through the C ABI; the arithmetic is in
+``csrc/*.hip``.  All functions raise if the tensors are not on a GPU -- there is no CPU
+path in the product (see ``_lib.TiseLibraryError``).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# image_realism/FID/inception.py:120-124 (applied to [0,1] pixels)
+NORM_SCALE = (0.229 / 0.5, 0.224 / 0.5, 0.225 / 0.5)
+NORM_BIAS = ((0.485 - 0.5) / 0.5, (0.456 - 0.5) / 0.5, (0.406 - 0.5) / 0.5)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.TiseLibraryError("tise_toolbox_amd runs on MI355X only: tensor is not on a HIP device")
+
+
+def make_lut(normalize_input=True, scale_pm1=False):
+    """3x256 fp32 table: byte -> network input value, with the reference's own op order.
+
+    ToTensor (fid_score.py:211): fp32(v) / 255 (true division, fp32).  Then either the
+    inception.py:120-124 affine ``x * (s/0.5) + (m-0.5)/0.5`` (fp32 multiply, fp32 add, Python
+    scalars rounded to fp32 first, as torch does for tensor-scalar ops) or, for O-IS,
+    Normalize((.5,.5,.5),(.5,.5,.5)) = (x - 0.5) / 0.5 (object_centric_inception_score.py:91).
+    """
+    v = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    lut = np.empty((3, 256), dtype=np.float32)
+    for c in range(3):
+        if scale_pm1:
+            lut[c] = (v - np.float32(0.5)) / np.float32(0.5)
+        elif normalize_input:
+            lut[c] = v * np.float32(NORM_SCALE[c]) + np.float32(NORM_BIAS[c])
+        else:
+            lut[c] = v
+    return np.ascontiguousarray(lut)
+
+
+def resize_bilinear_u8(src_u8, out_hw=(299, 299), lut=None, channels_last=True, return_u8=False):
+    """(N,H,W,3) uint8 CUDA tensor -> (N,3,oh,ow) fp32 network input (PIL-exact bilinear).
+
+    Fuses transforms.Resize + ToTensor (fid_score.py:208-213) and the input affine
+    (inception.py:120-124) through ``lut`` (see make_lut).  With ``channels_last`` the
+    result is an NCHW tensor in torch.channels_last memory format.
+    """
+    _require_cuda(src_u8)
+    if src_u8.dtype != torch.uint8 or src_u8.dim() != 4 or src_u8.shape[3] != 3:
+        raise ValueError("src_u8 must be (N,H,W,3) uint8")
+    src_u8 = src_u8.contiguous()
+    n, h, w, _ = src_u8.shape
+    oh, ow = out_hw
+    if lut is None:
+        lut = make_lut(True)
+    lut = np.ascontiguousarray(lut, dtype=np.float32)
+    if channels_last:
+        store = torch.empty((n, oh, ow, 3), dtype=torch.float32, device=src_u8.device)
+        out = store.permute(0, 3, 1, 2)
+    else:
+        store = torch.empty((n, 3, oh, ow), dtype=torch.float32, device=src_u8.device)
+        out = store
+    u8 = torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=src_u8.device) if return_u8 else None
+    _lib.call("tise_resize_bilinear_u8", _ptr(src_u8), n, h, w, _ptr(store), oh, ow, 1 if channels_last else 0,
+              lut.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _ptr(u8) if u8 is not None else None, _stream())
+    return (out, u8) if return_u8 else out
+
+
+class StatsAccumulator:
+    """fp64 running {n, sum x, sum x x^T} on the device (tise_stats_* in include/tise_hip.h)."""
+
+    def __init__(self, dims, device=None):
+        self.dims = int(dims)
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise _lib.TiseLibraryError("StatsAccumulator needs a HIP device")
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.call("tise_stats_create", self.dims, ctypes.byref(self._h))
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            _lib.load().tise_stats_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        _lib.call("tise_stats_reset", self._h, _stream())
+
+    def update(self, feats):
+        """feats: (rows, dims) fp32 CUDA tensor (row stride may exceed dims)."""
+        _require_cuda(feats)
+        if feats.dim() != 2 or feats.shape[1] != self.dims or feats.dtype != torch.float32:
+            raise ValueError(f"feats must be (rows,{self.dims}) float32")
+        if feats.stride(1) != 1:
+            feats = feats.contiguous()
+        _lib.call("tise_stats_update", self._h, _ptr(feats), feats.shape[0], feats.stride(0), _stream())
+
+    def update_parts(self, feats, cov=True, col_sum=True):
+        """The two kernels of update() separately (bench.py brackets the MFMA one with HIP events)."""
+        if cov:
+            _lib.call("tise_stats_update_cov", self._h, _ptr(feats), feats.shape[0], feats.stride(0), _stream())
+        if col_sum:
+            _lib.call("tise_stats_update_sum", self._h, _ptr(feats), feats.shape[0], feats.stride(0), _stream())
+
+    def buffer(self):
+        """The contiguous fp64 device buffer [S | s | n | pad] as a torch tensor VIEW (no copy);
+        this is what the data-parallel driver all-reduces over RCCL."""
+        p = ctypes.c_void_p()
+        n = ctypes.c_size_t()
+        _lib.call("tise_stats_buffer", self._h, ctypes.byref(p), ctypes.byref(n))
+        return _wrap_device_doubles(p.value, n.value, self.device, owner=self)
+
+    def count(self):
+        return float(self.buffer()[self.dims * self.dims + self.dims].item())
+
+    def finalize(self):
+        """-> (mu (d,), sigma (d,d)) fp64 CUDA tensors; np.mean / np.cov(ddof=1) of everything fed."""
+        mu = torch.empty(self.dims, dtype=torch.float64, device=self.device)
+        sigma = torch.empty((self.dims, self.dims), dtype=torch.float64, device=self.device)
+        _lib.call("tise_stats_finalize", self._h, _ptr(mu), _ptr(sigma), _stream())
+        return mu, sigma
+
+
+def _wrap_device_doubles(ptr, n, device, owner=None):
+    """Zero-copy torch view of `n` doubles at device address `ptr` (__cuda_array_interface__)."""
+    class _Holder:
+        pass
+    holder = _Holder()
+    holder.__cuda_array_interface__ = {
+        "shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 3, "strides": None,
+    }
+    holder._owner = owner
+    t = torch.as_tensor(holder, device=device)
+    return t
+
+
+class FrechetSolver:
+    """Device Frechet distance (tise_frechet_* in include/tise_hip.h)."""
+
+    def __init__(self, dims, device=None):
+        self.dims = int(dims)
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise _lib.TiseLibraryError("FrechetSolver needs a HIP device")
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.call("tise_frechet_create", self.dims, ctypes.byref(self._h))
+
+    def close(self):
+        if self._h:
+            _lib.load().tise_frechet_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _prep(self, t, shape):
+        t = torch.as_tensor(t, dtype=torch.float64, device=self.device).contiguous()
+        if tuple(t.shape) != shape:
+            raise ValueError(f"expected shape {shape}, got {tuple(t.shape)}")
+        return t
+
+    def distance(self, mu1, sigma1, mu2, sigma2, diag_offset=0.0):
+        """-> dict(fid, tr_covmean, diff2, tr1, tr2, rank, n_negative, flags); one device->host read."""
+        d = self.dims
+        mu1 = self._prep(mu1, (d,)); mu2 = self._prep(mu2, (d,))
+        sigma1 = self._prep(sigma1, (d, d)); sigma2 = self._prep(sigma2, (d, d))
+        out = torch.empty(_lib.TISE_FRECHET_OUT_DOUBLES, dtype=torch.float64, device=self.device)
+        _lib.call("tise_frechet_distance", self._h, _ptr(mu1), _ptr(sigma1), _ptr(mu2), _ptr(sigma2),
+                  float(diag_offset), _ptr(out), _stream())
+        o = out.cpu().numpy()
+        return {"fid": np.float64(o[0]), "tr_covmean": float(o[1]), "diff2": float(o[2]), "tr1": float(o[3]),
+                "tr2": float(o[4]), "rank": int(o[5]), "n_negative": int(o[6]), "flags": int(o[7])}
+
+    def set_profiling(self, on=True):
+        _lib.call("tise_frechet_set_profiling", self._h, 1 if on else 0)
+
+    def phase_ms(self):
+        """HIP-event phase times of the last distance() call: dict(pchol, gemm, sytrd, bisect, finish, rank)."""
+        ms = (ctypes.c_double * 5)()
+        r = ctypes.c_int()
+        _lib.call("tise_frechet_phase_ms", self._h, ms, ctypes.byref(r))
+        return {"pchol": ms[0], "gemm": ms[1], "sytrd": ms[2], "bisect": ms[3], "finish": ms[4], "rank": r.value}
+
+    def eigvalsh(self, a):
+        a = torch.as_tensor(a, dtype=torch.float64, device=self.device).contiguous()
+        n = a.shape[0]
+        w = torch.empty(n, dtype=torch.float64, device=self.device)
+        _lib.call("tise_eigvalsh", self._h, _ptr(a), n, _ptr(w), _stream())
+        return w
+
+    def pivoted_cholesky(self, sigma):
+        sigma = self._prep(sigma, (self.dims, self.dims))
+        lt = torch.empty_like(sigma)
+        r = ctypes.c_int()
+        _lib.call("tise_pivoted_cholesky", self._h, _ptr(sigma), _ptr(lt), ctypes.byref(r), _stream())
+        return lt, r.value
+
+
+class InceptionScoreAccumulator:
+    """Per-split additive IS* sums on the device (tise_is_update / tise_is_finalize)."""
+
+    RULES = {"coco": 0, "bird": 0, "ois": 1}
+
+    def __init__(self, num_classes, n_total, temperature, splits=10, rule="coco", drop_first_class=False, device=None):
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise _lib.TiseLibraryError("InceptionScoreAccumulator needs a HIP device")
+        self.C = int(num_classes)
+        self.drop = 1 if drop_first_class else 0
+        self.Ce = self.C - self.drop
+        self.n_total = int(n_total)
+        self.T = float(temperature)
+        self.splits = int(splits)
+        self.rule = self.RULES[rule] if isinstance(rule, str) else int(rule)
+        self.acc = torch.zeros(self.splits * (1 + self.Ce), dtype=torch.float64, device=self.device)
+        self._ws = None
+
+    def update(self, logits, idx_base):
+        """logits: (rows, C) fp32 CUDA tensor whose rows have global indices idx_base..idx_base+rows-1."""
+        _require_cuda(logits)
+        if logits.dim() != 2 or logits.shape[1] != self.C or logits.dtype != torch.float32:
+            raise ValueError(f"logits must be (rows,{self.C}) float32")
+        if logits.stride(1) != 1:
+            logits = logits.contiguous()
+        rows = logits.shape[0]
+        if self._ws is None or self._ws.numel() < 2 * rows:
+            self._ws = torch.empty(2 * max(rows, 1024), dtype=torch.float64, device=self.device)
+        _lib.call("tise_is_update", _ptr(logits), rows, logits.stride(0), self.C, self.T, self.drop, int(idx_base),
+                  self.n_total, self.splits, self.rule, _ptr(self.acc), _ptr(self._ws), _stream())
+
+    def finalize(self):
+        """-> (mean, std, scores[splits]) as Python floats / numpy."""
+        out = torch.empty(2 + self.splits, dtype=torch.float64, device=self.device)
+        _lib.call("tise_is_finalize", _ptr(self.acc), self.Ce, self.n_total, self.splits, self.rule, _ptr(out), _stream())
+        o = out.cpu().numpy()
+        return float(o[0]), float(o[1]), o[2:].copy()
+
+
+def gemm_f64(a, b):
+    """C = A @ B in fp64 through the MFMA tile kernel (any strides); test/bench helper."""
+    _require_cuda(a, b)
+    m, k = a.shape
+    k2, n = b.shape
+    assert k == k2 and a.dtype == torch.float64 and b.dtype == torch.float64
+    c = torch.empty((m, n), dtype=torch.float64, device=a.device)
+    _lib.call("tise_gemm_f64", _ptr(a), a.stride(0), a.stride(1), _ptr(b), b.stride(0), b.stride(1), _ptr(c), n,
+              m, n, k, _stream())
+    return c

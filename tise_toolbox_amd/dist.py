@@ -1,0 +1,65 @@
+"""Data-parallel plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL on ROCm).
+
+The reference evaluators are single-process (no collective anywhere), so this
+layer is new: images are independent through decode / resize / trunk, and both reductions are
+additive -- FID in {n, sum x, sum x x^T} (fp64, 33.57 MB at d = 2048), IS* in per-split
+{A_k, B_kc} (80 KB) -- so the only exchange is ONE all-reduce(SUM) per image set at the end.
+
+Sharding rule: the global file list (os.walk order) is cut to
+n_used = (N // batch) * batch (DataLoader(drop_last=True), fid_score.py:215-217), then split
+into contiguous index ranges, one per rank; IS* split membership is computed from the GLOBAL
+index, so a shard may straddle split borders.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment (no-op for world size 1)."""
+    rank, world, local_rank = env_world()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def n_used_images(n_images, batch_size):
+    """fid_score.py:90-96,215-217: the tail N mod batch_size (in walk order) is dropped."""
+    if batch_size <= 0:
+        raise ValueError("batch_size must be positive")
+    return (n_images // batch_size) * batch_size
+
+
+def shard_range(n, rank, world):
+    """Contiguous [lo, hi) of rank `rank` over n items; sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    hi = lo + base + (1 if rank < rem else 0)
+    return lo, hi
+
+
+def all_reduce_sum_(t):
+    """In-place SUM all-reduce of a tensor (fp64 sufficient statistics); identity for world size 1."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def is_main():
+    return (not (dist.is_available() and dist.is_initialized())) or dist.get_rank() == 0

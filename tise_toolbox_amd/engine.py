@@ -1,0 +1,142 @@
+"""Device pipeline of the image-realism hot path: uint8 batch -> resize -> InceptionV3 -> statistics.
+
+One ``RealismEngine`` per process / GPU.  A step takes a batch of decoded uint8 images that is
+already in HBM and
+  1. resizes it to 299x299 and applies ToTensor + the input affine      (csrc/resize.hip)
+  2. runs the InceptionV3 trunk to pool3 (+ the fc head for IS*)        (PyTorch-ROCm / MIOpen, fp32)
+  3. folds the pool3 rows into fp64 {n, sum x, sum x x^T}               (csrc/stats.hip, fp64 MFMA)
+  4. folds the logits into the per-split IS* sums                        (csrc/is_score.hip)
+Nothing returns to the host until ``finish()``, which all-reduces the sufficient statistics
+over RCCL (world size > 1), finalises (mu, sigma) and evaluates the Frechet distance on device
+(csrc/frechet.hip).
+
+Reference path replaced: the loop of ``get_activations`` (image_realism/FID/fid_score.py:99-113:
+batch.cuda(); model(batch); pred.cpu().numpy() per batch), ``np.mean``/``np.cov`` (:194-195),
+``calculate_frechet_distance`` (:121-171) and the IS* loop
+(image_realism/IS/coco/inception_score_star_coco.py:44-60).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib, device, dist as tdist
+from .inception import InceptionV3
+
+T_COCO = 0.9091363549232483    # image_realism/IS/coco/inception_score_star_coco.py:107
+T_BIRD = 0.5980541706085205    # image_realism/IS/bird/inception_score_star_bird.py:192
+T_OIS = 2.1737587451934814     # object_fidelity/O-IS/object_centric_inception_score.py:55
+
+
+def require_gpu():
+    _lib.load()
+    if not torch.cuda.is_available():
+        raise _lib.TiseLibraryError(
+            "no HIP device visible: tise_toolbox_amd is the MI355X path of the TISE image-realism metrics and "
+            "has no CPU fallback (the reference's --gpu '' CPU mode is not provided)")
+
+
+class RealismEngine:
+    def __init__(self, dims=2048, device_index=None, weights=None, num_classes=1000, seed=0,
+                 channels_last=None, fold_bn=True, with_logits=False, model=None, normalize_input=True,
+                 lut=None):
+        require_gpu()
+        if device_index is None:
+            device_index = torch.cuda.current_device()
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv solver per shape
+        self.dims = dims
+        self.with_logits = with_logits
+        if channels_last is None:
+            channels_last = os.environ.get("TISE_CHANNELS_LAST", "1") != "0"
+        self.channels_last = channels_last
+        if model is None:
+            block = InceptionV3.BLOCK_INDEX_BY_DIM[dims]
+            model = InceptionV3([block], weights=weights, num_classes=num_classes, seed=seed,
+                                normalize_input=normalize_input)
+        self.model = model.to(self.device).eval()
+        if channels_last:
+            self.model = self.model.to(memory_format=torch.channels_last)
+        if fold_bn and hasattr(self.model, "fold_bn"):
+            self.model.fold_bn(torch.channels_last if channels_last else torch.contiguous_format)
+        if lut is None:
+            lut = device.make_lut(normalize_input=getattr(self.model, "normalize_input", True))
+        self.lut = lut
+        self.stats = None
+        self.is_acc = None
+
+    # ---- per-batch device work -----------------------------------------------------------------
+    @torch.no_grad()
+    def features_from_u8(self, batch_u8):
+        """(B,H,W,3) uint8 on the device -> pool3 (B,dims) fp32 [and logits (B,C)]."""
+        x = device.resize_bilinear_u8(batch_u8, (299, 299), self.lut, channels_last=self.channels_last)
+        return self._trunk(x, prenormalized=True)
+
+    @torch.no_grad()
+    def features_from_float(self, batch):
+        """(B,3,H,W) fp32 in [0,1] (the reference's DataLoader output) -> pool3 (B,dims) fp32."""
+        x = batch.to(self.device, non_blocking=True).float()
+        if self.channels_last:
+            x = x.contiguous(memory_format=torch.channels_last)
+        return self._trunk(x, prenormalized=False)
+
+    def _trunk(self, x, prenormalized):
+        pred = self.model(x, prenormalized=prenormalized)[0]
+        if pred.shape[2] != 1 or pred.shape[3] != 1:                 # fid_score.py:110-111
+            pred = F.adaptive_avg_pool2d(pred, output_size=(1, 1))
+        feats = pred.reshape(pred.shape[0], -1)
+        if feats.stride(1) != 1:
+            feats = feats.contiguous()
+        logits = self.model.logits(feats) if self.with_logits else None
+        return feats, logits
+
+    # ---- accumulation ---------------------------------------------------------------------------
+    def begin(self, n_total=None, temperature=T_COCO, splits=10, rule="coco", drop_first_class=False):
+        self.stats = device.StatsAccumulator(self.dims, self.device)
+        self.is_acc = None
+        if self.with_logits:
+            if n_total is None:
+                raise ValueError("IS* needs the global image count (split membership is by global index)")
+            c = self.model.fc.out_features
+            self.is_acc = device.InceptionScoreAccumulator(c, n_total, temperature, splits, rule,
+                                                           drop_first_class, self.device)
+
+    def step_u8(self, batch_u8, idx_base=0):
+        feats, logits = self.features_from_u8(batch_u8)
+        self.stats.update(feats)
+        if self.is_acc is not None:
+            self.is_acc.update(logits, idx_base)
+        return feats
+
+    def step_float(self, batch, idx_base=0):
+        feats, logits = self.features_from_float(batch)
+        self.stats.update(feats)
+        if self.is_acc is not None:
+            self.is_acc.update(logits, idx_base)
+        return feats
+
+    def reduce(self):
+        """One all-reduce(SUM) per accumulator over RCCL (no-op for a single process)."""
+        tdist.all_reduce_sum_(self.stats.buffer())
+        if self.is_acc is not None:
+            tdist.all_reduce_sum_(self.is_acc.acc)
+
+    def statistics(self):
+        """(mu, sigma) fp64 CUDA tensors of everything accumulated (after reduce())."""
+        return self.stats.finalize()
+
+    def inception_score(self):
+        mean, std, _ = self.is_acc.finalize()
+        return mean, std
+
+
+_SOLVERS = {}
+
+
+def frechet_solver(dims, dev):
+    key = (int(dims), str(dev))
+    if key not in _SOLVERS:
+        _SOLVERS[key] = device.FrechetSolver(dims, dev)
+    return _SOLVERS[key]

@@ -1,0 +1,303 @@
+"""InceptionV3 feature extractor on PyTorch-ROCm (mirror of the reference wrapper).
+
+Reference interface: ``image_realism/FID/inception.py:6-134`` (class ``InceptionV3``:
+``BLOCK_INDEX_BY_DIM``, ``output_blocks``, ``resize_input``, ``normalize_input``,
+``requires_grad``; ``forward(inp) -> list[Tensor]``).  The reference cuts its four
+blocks out of ``torchvision.models.inception_v3(pretrained=True)`` (:57); torchvision
+is not a dependency here, so ``Inception3`` below is an own definition of that
+published topology whose ``state_dict`` keys and shapes are torchvision's, so the
+reference's weight files (``inception_v3_google-1a9a5a14.pth``, and the 80-class
+fine-tune of ``object_fidelity/O-FID/inception.py:58-64``) load unchanged.
+
+``north_star`` assigns the conv stack to PyTorch-ROCm (MIOpen), fp32.  What is new
+here for MI355X: eval-mode BatchNorm is folded into the conv (one kernel per
+layer, no separate normalisation pass), the whole trunk runs channels-last so the
+HIP resize kernel can emit the input layout directly, and the input affine of
+``inception.py:120-124`` is fused into that resize kernel's lookup table.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class BasicConv2d(nn.Module):
+    """conv(bias=False) -> BatchNorm(eps=1e-3) -> ReLU; torchvision key names ``conv``/``bn``."""
+
+    def __init__(self, cin, cout, **kw):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, bias=False, **kw)
+        self.bn = nn.BatchNorm2d(cout, eps=0.001)
+        self._folded = None
+
+    def forward(self, x):
+        if self._folded is not None:
+            w, b = self._folded
+            return F.relu_(F.conv2d(x, w, b, self.conv.stride, self.conv.padding))
+        return F.relu(self.bn(self.conv(x)), inplace=True)
+
+    @torch.no_grad()
+    def fold(self, memory_format=torch.contiguous_format):
+        """Fold eval-mode BN into the conv: w' = w*g/sqrt(v+eps), b' = beta - mean*g/sqrt(v+eps)."""
+        bn = self.bn
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        w = (self.conv.weight * scale.view(-1, 1, 1, 1)).contiguous(memory_format=memory_format)
+        b = (bn.bias - bn.running_mean * scale).contiguous()
+        self._folded = (w, b)
+
+    def unfold(self):
+        self._folded = None
+
+
+class InceptionA(nn.Module):
+    def __init__(self, cin, pool_features):
+        super().__init__()
+        self.branch1x1 = BasicConv2d(cin, 64, kernel_size=1)
+        self.branch5x5_1 = BasicConv2d(cin, 48, kernel_size=1)
+        self.branch5x5_2 = BasicConv2d(48, 64, kernel_size=5, padding=2)
+        self.branch3x3dbl_1 = BasicConv2d(cin, 64, kernel_size=1)
+        self.branch3x3dbl_2 = BasicConv2d(64, 96, kernel_size=3, padding=1)
+        self.branch3x3dbl_3 = BasicConv2d(96, 96, kernel_size=3, padding=1)
+        self.branch_pool = BasicConv2d(cin, pool_features, kernel_size=1)
+
+    def forward(self, x):
+        b1 = self.branch1x1(x)
+        b5 = self.branch5x5_2(self.branch5x5_1(x))
+        b3 = self.branch3x3dbl_3(self.branch3x3dbl_2(self.branch3x3dbl_1(x)))
+        bp = self.branch_pool(F.avg_pool2d(x, kernel_size=3, stride=1, padding=1))
+        return torch.cat([b1, b5, b3, bp], 1)
+
+
+class InceptionB(nn.Module):
+    def __init__(self, cin):
+        super().__init__()
+        self.branch3x3 = BasicConv2d(cin, 384, kernel_size=3, stride=2)
+        self.branch3x3dbl_1 = BasicConv2d(cin, 64, kernel_size=1)
+        self.branch3x3dbl_2 = BasicConv2d(64, 96, kernel_size=3, padding=1)
+        self.branch3x3dbl_3 = BasicConv2d(96, 96, kernel_size=3, stride=2)
+
+    def forward(self, x):
+        b3 = self.branch3x3(x)
+        bd = self.branch3x3dbl_3(self.branch3x3dbl_2(self.branch3x3dbl_1(x)))
+        bp = F.max_pool2d(x, kernel_size=3, stride=2)
+        return torch.cat([b3, bd, bp], 1)
+
+
+class InceptionC(nn.Module):
+    def __init__(self, cin, c7):
+        super().__init__()
+        self.branch1x1 = BasicConv2d(cin, 192, kernel_size=1)
+        self.branch7x7_1 = BasicConv2d(cin, c7, kernel_size=1)
+        self.branch7x7_2 = BasicConv2d(c7, c7, kernel_size=(1, 7), padding=(0, 3))
+        self.branch7x7_3 = BasicConv2d(c7, 192, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_1 = BasicConv2d(cin, c7, kernel_size=1)
+        self.branch7x7dbl_2 = BasicConv2d(c7, c7, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_3 = BasicConv2d(c7, c7, kernel_size=(1, 7), padding=(0, 3))
+        self.branch7x7dbl_4 = BasicConv2d(c7, c7, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7dbl_5 = BasicConv2d(c7, 192, kernel_size=(1, 7), padding=(0, 3))
+        self.branch_pool = BasicConv2d(cin, 192, kernel_size=1)
+
+    def forward(self, x):
+        b1 = self.branch1x1(x)
+        b7 = self.branch7x7_3(self.branch7x7_2(self.branch7x7_1(x)))
+        bd = self.branch7x7dbl_1(x)
+        bd = self.branch7x7dbl_5(self.branch7x7dbl_4(self.branch7x7dbl_3(self.branch7x7dbl_2(bd))))
+        bp = self.branch_pool(F.avg_pool2d(x, kernel_size=3, stride=1, padding=1))
+        return torch.cat([b1, b7, bd, bp], 1)
+
+
+class InceptionD(nn.Module):
+    def __init__(self, cin):
+        super().__init__()
+        self.branch3x3_1 = BasicConv2d(cin, 192, kernel_size=1)
+        self.branch3x3_2 = BasicConv2d(192, 320, kernel_size=3, stride=2)
+        self.branch7x7x3_1 = BasicConv2d(cin, 192, kernel_size=1)
+        self.branch7x7x3_2 = BasicConv2d(192, 192, kernel_size=(1, 7), padding=(0, 3))
+        self.branch7x7x3_3 = BasicConv2d(192, 192, kernel_size=(7, 1), padding=(3, 0))
+        self.branch7x7x3_4 = BasicConv2d(192, 192, kernel_size=3, stride=2)
+
+    def forward(self, x):
+        b3 = self.branch3x3_2(self.branch3x3_1(x))
+        b7 = self.branch7x7x3_4(self.branch7x7x3_3(self.branch7x7x3_2(self.branch7x7x3_1(x))))
+        bp = F.max_pool2d(x, kernel_size=3, stride=2)
+        return torch.cat([b3, b7, bp], 1)
+
+
+class InceptionE(nn.Module):
+    def __init__(self, cin):
+        super().__init__()
+        self.branch1x1 = BasicConv2d(cin, 320, kernel_size=1)
+        self.branch3x3_1 = BasicConv2d(cin, 384, kernel_size=1)
+        self.branch3x3_2a = BasicConv2d(384, 384, kernel_size=(1, 3), padding=(0, 1))
+        self.branch3x3_2b = BasicConv2d(384, 384, kernel_size=(3, 1), padding=(1, 0))
+        self.branch3x3dbl_1 = BasicConv2d(cin, 448, kernel_size=1)
+        self.branch3x3dbl_2 = BasicConv2d(448, 384, kernel_size=3, padding=1)
+        self.branch3x3dbl_3a = BasicConv2d(384, 384, kernel_size=(1, 3), padding=(0, 1))
+        self.branch3x3dbl_3b = BasicConv2d(384, 384, kernel_size=(3, 1), padding=(1, 0))
+        self.branch_pool = BasicConv2d(cin, 192, kernel_size=1)
+
+    def forward(self, x):
+        b1 = self.branch1x1(x)
+        b3 = self.branch3x3_1(x)
+        b3 = torch.cat([self.branch3x3_2a(b3), self.branch3x3_2b(b3)], 1)
+        bd = self.branch3x3dbl_2(self.branch3x3dbl_1(x))
+        bd = torch.cat([self.branch3x3dbl_3a(bd), self.branch3x3dbl_3b(bd)], 1)
+        bp = self.branch_pool(F.avg_pool2d(x, kernel_size=3, stride=1, padding=1))
+        return torch.cat([b1, b3, bd, bp], 1)
+
+
+class InceptionAux(nn.Module):
+    """Present only so torchvision state_dicts load with strict=True; never run."""
+
+    def __init__(self, cin, num_classes):
+        super().__init__()
+        self.conv0 = BasicConv2d(cin, 128, kernel_size=1)
+        self.conv1 = BasicConv2d(128, 768, kernel_size=5)
+        self.fc = nn.Linear(768, num_classes)
+
+
+class Inception3(nn.Module):
+    """The torchvision ``Inception3`` module tree (names, shapes) without its forward."""
+
+    def __init__(self, num_classes=1000, aux_logits=True):
+        super().__init__()
+        self.Conv2d_1a_3x3 = BasicConv2d(3, 32, kernel_size=3, stride=2)
+        self.Conv2d_2a_3x3 = BasicConv2d(32, 32, kernel_size=3)
+        self.Conv2d_2b_3x3 = BasicConv2d(32, 64, kernel_size=3, padding=1)
+        self.Conv2d_3b_1x1 = BasicConv2d(64, 80, kernel_size=1)
+        self.Conv2d_4a_3x3 = BasicConv2d(80, 192, kernel_size=3)
+        self.Mixed_5b = InceptionA(192, pool_features=32)
+        self.Mixed_5c = InceptionA(256, pool_features=64)
+        self.Mixed_5d = InceptionA(288, pool_features=64)
+        self.Mixed_6a = InceptionB(288)
+        self.Mixed_6b = InceptionC(768, c7=128)
+        self.Mixed_6c = InceptionC(768, c7=160)
+        self.Mixed_6d = InceptionC(768, c7=160)
+        self.Mixed_6e = InceptionC(768, c7=192)
+        if aux_logits:
+            self.AuxLogits = InceptionAux(768, num_classes)
+        self.Mixed_7a = InceptionD(768)
+        self.Mixed_7b = InceptionE(1280)
+        self.Mixed_7c = InceptionE(2048)
+        self.fc = nn.Linear(2048, num_classes)
+
+
+@torch.no_grad()
+def seeded_init_(net, seed=0):
+    """Deterministic stand-in weights (no pretrained file exists offline).
+
+    He-normal conv weights and a mildly non-trivial BN so activations keep O(1)
+    scale through the 94 conv layers; drawn on CPU from one generator so CPU and
+    GPU runs see identical parameters.  Throughput is weight-independent; scores
+    obtained with these weights are only comparable between paths run on them.
+    """
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for name, m in net.named_modules():
+        if isinstance(m, nn.Conv2d):
+            fan_in = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+            m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+        elif isinstance(m, nn.BatchNorm2d):
+            m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=g))
+            m.bias.copy_(0.05 * torch.randn(m.bias.shape, generator=g))
+            m.running_mean.copy_(0.05 * torch.randn(m.running_mean.shape, generator=g))
+            m.running_var.copy_(1.0 + 0.1 * torch.rand(m.running_var.shape, generator=g))
+        elif isinstance(m, nn.Linear):
+            m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (4.0 / m.in_features ** 0.5))
+            m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+    return net
+
+
+def build_inception3(weights=None, num_classes=1000, seed=0):
+    """Construct ``Inception3`` and load ``weights`` (a torchvision-format state_dict
+    path) or, when ``weights`` is None, the seeded stand-in parameters."""
+    net = Inception3(num_classes=num_classes, aux_logits=True)
+    if weights is not None:
+        sd = torch.load(weights, map_location="cpu")
+        if isinstance(sd, dict) and "state_dict" in sd:
+            sd = sd["state_dict"]
+        net.load_state_dict(sd, strict=True)
+    else:
+        seeded_init_(net, seed)
+    return net.eval()
+
+
+class InceptionV3(nn.Module):
+    """Drop-in for the reference wrapper (``image_realism/FID/inception.py:6``).
+
+    Extra keyword arguments (all optional, defaults reproduce the reference call
+    ``InceptionV3([block_idx])``): ``weights`` (state_dict path; the reference
+    downloads the torchvision file, there is no network here), ``num_classes``
+    (80 for the O-FID/O-IS fine-tune, ``O-FID/inception.py:58-64``), ``seed``.
+    """
+
+    DEFAULT_BLOCK_INDEX = 3
+    BLOCK_INDEX_BY_DIM = {64: 0, 192: 1, 768: 2, 2048: 3}   # inception.py:14-19
+
+    def __init__(self, output_blocks=[DEFAULT_BLOCK_INDEX], resize_input=True, normalize_input=True,
+                 requires_grad=False, weights=None, num_classes=1000, seed=0):
+        super().__init__()
+        self.resize_input = resize_input
+        self.normalize_input = normalize_input
+        self.output_blocks = sorted(output_blocks)
+        self.last_needed_block = max(output_blocks)
+        assert self.last_needed_block <= 3, "Last possible output block index is 3"   # inception.py:53
+
+        inception = build_inception3(weights, num_classes, seed)
+        self.blocks = nn.ModuleList()
+        self.blocks.append(nn.Sequential(                                   # inception.py:59-66
+            inception.Conv2d_1a_3x3, inception.Conv2d_2a_3x3, inception.Conv2d_2b_3x3,
+            nn.MaxPool2d(kernel_size=3, stride=2)))
+        if self.last_needed_block >= 1:                                     # :68-71
+            self.blocks.append(nn.Sequential(
+                inception.Conv2d_3b_1x1, inception.Conv2d_4a_3x3, nn.MaxPool2d(kernel_size=3, stride=2)))
+        if self.last_needed_block >= 2:                                     # :73-85
+            self.blocks.append(nn.Sequential(
+                inception.Mixed_5b, inception.Mixed_5c, inception.Mixed_5d, inception.Mixed_6a,
+                inception.Mixed_6b, inception.Mixed_6c, inception.Mixed_6d, inception.Mixed_6e))
+        if self.last_needed_block >= 3:                                     # :87-95
+            self.blocks.append(nn.Sequential(
+                inception.Mixed_7a, inception.Mixed_7b, inception.Mixed_7c,
+                nn.AdaptiveAvgPool2d(output_size=(1, 1))))
+        # classifier head: not part of the reference FID wrapper; IS* needs the logits
+        # (north_star: PyTorch InceptionV3 logits with the IS* temperature).
+        self.fc = inception.fc
+        for p in self.parameters():                                         # :97-98
+            p.requires_grad = requires_grad
+        self._input_prenormalized = False
+
+    def fold_bn(self, memory_format=torch.contiguous_format):
+        for m in self.modules():
+            if isinstance(m, BasicConv2d):
+                m.fold(memory_format)
+        return self
+
+    def unfold_bn(self):
+        for m in self.modules():
+            if isinstance(m, BasicConv2d):
+                m.unfold()
+        return self
+
+    def forward(self, inp, prenormalized=False):
+        """inception.py:100-134.  ``prenormalized=True`` is the fused device path: the
+        input is already 299x299 with the :120-124 affine applied by the resize kernel."""
+        outp = []
+        x = inp
+        if not prenormalized:
+            if self.resize_input and tuple(x.shape[-2:]) != (299, 299):
+                # :117-118; for 299x299 input align_corners bilinear is the identity map
+                x = F.interpolate(x, size=(299, 299), mode="bilinear", align_corners=True)
+            if self.normalize_input:                                        # :120-124
+                x = x.clone()
+                x[:, 0] = x[:, 0] * (0.229 / 0.5) + (0.485 - 0.5) / 0.5
+                x[:, 1] = x[:, 1] * (0.224 / 0.5) + (0.456 - 0.5) / 0.5
+                x[:, 2] = x[:, 2] * (0.225 / 0.5) + (0.406 - 0.5) / 0.5
+        for idx, block in enumerate(self.blocks):                           # :126-132
+            x = block(x)
+            if idx in self.output_blocks:
+                outp.append(x)
+            if idx == self.last_needed_block:
+                break
+        return outp
+
+    def logits(self, pool3):
+        """fc head on pool3 features (B,2048[,1,1]) -> (B, num_classes)."""
+        return self.fc(pool3.flatten(1))
