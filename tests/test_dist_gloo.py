@@ -1,0 +1,99 @@
+"""CPU, world_size 2, gloo: the data-parallel path -- contiguous index shards, one all-reduce(SUM) of the
+fp64 sufficient statistics [S | s | n] and of the IS* split sums, finalisation equal to the single-process
+result.  (On the GPU box the same code runs with backend "nccl" = RCCL; the per-shard sums are then
+produced by the HIP kernels instead of the numpy emulation used here.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from oracle import fid_oracle, is_oracle
+    from tests import _cases
+    from tise_toolbox_amd import dist as tdist
+    r, w, _ = tdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world) and dist.get_backend() == "gloo"
+    d, n_files, bs, C, splits = 48, 1003, 50, 37, 10
+    files = [f"{i:05d}.png" for i in range(n_files)]
+    shard, base = tdist.shard_files(files, bs, rank, world)
+    feats = _cases.pool3_like_features(n_files, d, seed=11)                 # row i = features of file i
+    logits = (np.random.default_rng(5).standard_normal((n_files, C)) * 2).astype(np.float32)
+    n_used = tdist.n_used_images(n_files, bs)
+    idx = np.arange(base, base + len(shard))
+    x = feats[idx].astype(np.float64)
+    # the device buffer layout [S (d*d) | s (d) | n | pad]
+    buf = torch.zeros(d * d + d + 2, dtype=torch.float64)
+    buf[:d * d] = torch.from_numpy((x.T @ x).reshape(-1))
+    buf[d * d:d * d + d] = torch.from_numpy(x.sum(0))
+    buf[d * d + d] = len(idx)
+    A, B = is_oracle.is_sums(logits[idx], is_oracle.T_COCO, base, n_used, splits, "coco")
+    acc = torch.from_numpy(np.concatenate([A, B.reshape(-1)]))
+    tdist.all_reduce_sum_(buf)
+    tdist.all_reduce_sum_(acc)
+    tdist.barrier()
+    if tdist.is_main():
+        S = buf[:d * d].numpy().reshape(d, d)
+        s = buf[d * d:d * d + d].numpy()
+        n = float(buf[d * d + d])
+        mu, sigma = fid_oracle.statistics_from_sums(n, s, S)
+        mu_ref, sigma_ref = fid_oracle.calculate_activation_statistics(feats[:n_used])
+        a = acc.numpy()
+        is_m, is_s = is_oracle.is_finalize(a[:splits], a[splits:].reshape(splits, C), n_used, splits, "coco")
+        ref_m, ref_s = is_oracle.inception_score_from_logits(logits[:n_used], is_oracle.T_COCO, splits, "coco", dtype=np.float64)
+        q.put({"n": n, "n_used": n_used, "mu_err": float(np.abs(mu - mu_ref).max()),
+               "sigma_err": float(np.abs(sigma - sigma_ref).max() / np.abs(sigma_ref).max()),
+               "is_err": max(abs(is_m - ref_m), abs(is_s - ref_s)), "shard": (base, len(shard))})
+    else:
+        q.put({"shard": (base, len(shard))})
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_allreduce_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    main = [o for o in outs if "n" in o][0]
+    assert main["n"] == main["n_used"] == 1000                                # 1003 files, batch 50 -> 3 dropped
+    assert sorted(o["shard"] for o in outs) == [(0, 500), (500, 500)]
+    assert main["mu_err"] <= 1e-14 and main["sigma_err"] <= 1e-12 and main["is_err"] <= 1e-10
+
+
+def test_shard_files_global_drop_last():
+    from tise_toolbox_amd import dist as tdist
+    files = list(range(1003))
+    got = []
+    for r in range(8):
+        shard, base = tdist.shard_files(files, 50, r, 8)
+        assert len(shard) % 50 == 0 and (not shard or shard[0] == base)
+        got += shard
+    assert got == files[:1000]
+    shard, base = tdist.shard_files(list(range(30)), 64, 0, 2)                 # N < batch: nothing is used
+    assert shard == [] and base == 0

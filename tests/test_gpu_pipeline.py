@@ -95,8 +95,9 @@ def test_reference_api_functions(setup, tmp_path, capsys):
     assert np.abs(act - setup["fg"][:16]).max() <= 2e-4 * np.abs(setup["fg"]).max()
     mu, sigma = fid_score.calculate_activation_statistics(loader, model, bs, 2048, cuda=True, verbose=False)
     mu_ref, sigma_ref = fid_oracle.calculate_activation_statistics(act)
-    np.testing.assert_allclose(mu, mu_ref, rtol=0, atol=1e-12)
-    np.testing.assert_allclose(sigma, sigma_ref, rtol=0, atol=1e-12)
+    # two separate forward passes: MIOpen may pick different (equally valid) fp32 summation orders
+    np.testing.assert_allclose(mu, mu_ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(sigma, sigma_ref, rtol=0, atol=1e-6)
     from tise_toolbox_amd import _lib
     with pytest.raises(_lib.TiseLibraryError):
         fid_score.get_activations(loader, model, bs, 2048, cuda=False)

@@ -1,0 +1,140 @@
+"""CPU: host-side logic that mirrors the reference's conventions (file walking, drop-last, sharding,
+lookup table, CLI surface, state_dict compatibility)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import fid_oracle, resize_oracle
+
+
+def test_get_filenames_rule(tmp_path):
+    """img_data.py:27-35: substring match on 'jpg' / 'png' anywhere in the NAME, recursive, os.walk order."""
+    from tise_toolbox_amd import img_data
+    for name in ["a.png", "b.jpg", "c.jpeg", "d.png.txt", "e.PNG", "f.txt", "sub/g.png", "jpg_notes.md"]:
+        p = tmp_path / name
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(b"x")
+    (tmp_path / "dir.png").mkdir()                     # directories are not files (:33)
+    got = img_data.get_filenames(str(tmp_path))
+    want = []
+    for path, subdirs, files in os.walk(str(tmp_path)):
+        for name in files:
+            if name.rfind("jpg") != -1 or name.rfind("png") != -1:
+                want.append(os.path.join(path, name))
+    assert got == want
+    base = sorted(os.path.relpath(p, tmp_path) for p in got)
+    assert base == ["a.png", "b.jpg", "d.png.txt", "jpg_notes.md", "sub/g.png"]
+
+
+def test_drop_last_and_sharding():
+    from tise_toolbox_amd import dist as tdist
+    for n, bs in [(30000, 50), (1000, 64), (37, 5), (3, 5)]:
+        assert tdist.n_used_images(n, bs) == fid_oracle.n_used_images(n, bs)
+    for n in (0, 1, 7, 600, 601):
+        for world in (1, 2, 3, 8):
+            ranges = [tdist.shard_range(n, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+            sizes = [hi - lo for lo, hi in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    assert [tdist.shard_range(600, r, 8) for r in range(8)][3] == (225, 300)      # 30k / bs 50 / 8 GPUs
+
+
+def test_lut_matches_reference_op_order():
+    """ToTensor (/255, fp32) then inception.py:120-124 (fp32 mul, fp32 add) evaluated by torch itself."""
+    from tise_toolbox_amd import device
+    v = torch.arange(256, dtype=torch.uint8)
+    x = v.float().div(255)                                              # torchvision ToTensor
+    x = x.view(1, 1, 1, 256).repeat(1, 3, 1, 1).clone()
+    x[:, 0] = x[:, 0] * (0.229 / 0.5) + (0.485 - 0.5) / 0.5
+    x[:, 1] = x[:, 1] * (0.224 / 0.5) + (0.456 - 0.5) / 0.5
+    x[:, 2] = x[:, 2] * (0.225 / 0.5) + (0.406 - 0.5) / 0.5
+    lut = device.make_lut(True)
+    np.testing.assert_array_equal(lut, x[0, :, 0, :].numpy())
+    np.testing.assert_array_equal(device.make_lut(False)[1], v.float().div(255).numpy())
+    t = torch.from_numpy(np.arange(256, dtype=np.float32) / np.float32(255))
+    np.testing.assert_array_equal(device.make_lut(False, scale_pm1=True)[2], ((t - 0.5) / 0.5).numpy())
+    np.testing.assert_array_equal(resize_oracle.normalize_input(np.tile(lut_in(), (1, 1)))[...], lut_norm(lut))
+
+
+def lut_in():
+    return (np.arange(256, dtype=np.float32) / np.float32(255)).reshape(1, 1, 256).repeat(3, 0)
+
+
+def lut_norm(lut):
+    return lut.reshape(3, 1, 256)
+
+
+def test_state_dict_is_torchvision_compatible():
+    """Key names / shapes of torchvision.models.inception_v3 (the file the reference downloads)."""
+    from tise_toolbox_amd.inception import Inception3
+    sd = Inception3().state_dict()
+    assert sum(v.numel() for k, v in sd.items() if "num_batches_tracked" not in k and "running" not in k) == 27161264
+    for k, shape in {"Conv2d_1a_3x3.conv.weight": (32, 3, 3, 3), "Conv2d_1a_3x3.bn.running_var": (32,),
+                     "Mixed_5b.branch5x5_2.conv.weight": (64, 48, 5, 5), "Mixed_6a.branch3x3.conv.weight": (384, 288, 3, 3),
+                     "Mixed_6b.branch7x7_2.conv.weight": (128, 128, 1, 7), "Mixed_6e.branch7x7dbl_5.conv.weight": (192, 192, 1, 7),
+                     "AuxLogits.conv1.conv.weight": (768, 128, 5, 5), "AuxLogits.fc.weight": (1000, 768),
+                     "Mixed_7a.branch7x7x3_4.conv.weight": (192, 192, 3, 3), "Mixed_7c.branch3x3dbl_3b.conv.weight": (384, 384, 3, 1),
+                     "fc.weight": (1000, 2048), "fc.bias": (1000,)}.items():
+        assert tuple(sd[k].shape) == shape, k
+    sd80 = Inception3(num_classes=80).state_dict()                       # O-FID/inception.py:58-64
+    assert tuple(sd80["fc.weight"].shape) == (80, 2048) and tuple(sd80["AuxLogits.fc.weight"].shape) == (80, 768)
+
+
+def test_wrapper_matches_reference_interface_and_oracle():
+    from oracle import inception_oracle
+    from tise_toolbox_amd.inception import InceptionV3, build_inception3
+    assert InceptionV3.BLOCK_INDEX_BY_DIM == {64: 0, 192: 1, 768: 2, 2048: 3} and InceptionV3.DEFAULT_BLOCK_INDEX == 3
+    with pytest.raises(AssertionError):
+        InceptionV3([4])
+    m = InceptionV3([0, 1, 2, 3], seed=0)
+    assert not any(p.requires_grad for p in m.parameters())
+    x = torch.rand(2, 3, 64, 80)                                         # resize_input path (align_corners=True upsample)
+    outs = m(x)
+    assert [tuple(o.shape) for o in outs] == [(2, 64, 73, 73), (2, 192, 35, 35), (2, 768, 17, 17), (2, 2048, 1, 1)]
+    sd = build_inception3(seed=0).state_dict()
+    ref = inception_oracle.inception_forward(sd, x)
+    for a, b in zip(outs, ref):
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+    only2 = InceptionV3([2], seed=0)
+    assert len(only2.blocks) == 3 and tuple(only2(x)[0].shape) == (2, 768, 17, 17)
+    m.fold_bn()
+    for a, b in zip(m(x), ref):
+        assert (a - b).abs().max().item() <= 1e-3 * max(1.0, b.abs().max().item())
+
+
+def test_cli_surface():
+    from tise_toolbox_amd import fid_score, inception_score
+    a = fid_score._build_parser().parse_args(["--path1", "a.npz", "--path2", "imgs", "--batch-size", "50", "-c", "3",
+                                              "--dims", "768", "--saved_file", "o.txt"])
+    assert (a.batch_size, a.dims, a.gpu, a.path1, a.path2, a.saved_file) == (50, 768, "3", "a.npz", "imgs", "o.txt")
+    assert fid_score._build_parser().get_default("batch_size") == 64 and fid_score._build_parser().get_default("dims") == 2048
+    with pytest.raises(SystemExit):
+        fid_score._build_parser().parse_args(["--dims", "100", "--path1", "a", "--path2", "b"])
+    b = inception_score._build_parser().parse_args(["--image_folder", "d", "--saved_file", "s.txt", "--gpu", "1"])
+    assert (b.image_folder, b.saved_file, b.gpu, b.splits) == ("d", "s.txt", 1, 10)
+    assert b.temperature == 0.9091363549232483
+
+
+def test_missing_path_raises_like_reference(tmp_path):
+    from tise_toolbox_amd import fid_score
+    with pytest.raises(RuntimeError, match="Invalid path: "):
+        fid_score.calculate_fid_given_paths([str(tmp_path / "nope"), str(tmp_path)], 50, "0", 2048)
+
+
+def test_dataset_yields_uint8_hwc(tmp_path):
+    from PIL import Image
+    from tise_toolbox_amd import img_data
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    Image.fromarray(a).save(tmp_path / "a.png")
+    Image.fromarray(a[..., 0]).save(tmp_path / "gray.png")               # gray -> convert("RGB") (img_data.py:21)
+    ds = img_data.Dataset(str(tmp_path))
+    items = {os.path.basename(f): ds[i] for i, f in enumerate(ds.file_names)}
+    np.testing.assert_array_equal(items["a.png"].numpy(), a)
+    assert items["gray.png"].shape == (20, 30, 3) and items["gray.png"].dtype == torch.uint8
+    np.testing.assert_array_equal(items["gray.png"].numpy()[..., 2], a[..., 0])
+    assert isinstance(img_data.collate_u8([items["a.png"], items["gray.png"]]), torch.Tensor)
+    assert isinstance(img_data.collate_u8([items["a.png"], items["a.png"][:10]]), list)

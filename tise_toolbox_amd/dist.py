@@ -49,6 +49,14 @@ def shard_range(n, rank, world):
     return lo, hi
 
 
+def shard_files(files, batch_size, rank, world):
+    """The slice of the (os.walk-ordered) file list that rank `rank` evaluates: the drop-last rule is
+    applied GLOBALLY (fid_score.py:215-217), then whole batches are dealt out as contiguous ranges."""
+    n_used = n_used_images(len(files), batch_size)
+    lo, hi = shard_range(n_used // batch_size, rank, world)
+    return files[lo * batch_size:hi * batch_size], lo * batch_size
+
+
 def all_reduce_sum_(t):
     """In-place SUM all-reduce of a tensor (fp64 sufficient statistics); identity for world size 1."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -6,9 +6,9 @@ already in HBM and
   2. runs the InceptionV3 trunk to pool3 (+ the fc head for IS*)        (PyTorch-ROCm / MIOpen, fp32)
   3. folds the pool3 rows into fp64 {n, sum x, sum x x^T}               (csrc/stats.hip, fp64 MFMA)
   4. folds the logits into the per-split IS* sums                        (csrc/is_score.hip)
-Nothing returns to the host until ``finish()``, which all-reduces the sufficient statistics
-over RCCL (world size > 1), finalises (mu, sigma) and evaluates the Frechet distance on device
-(csrc/frechet.hip).
+Nothing returns to the host until the end: ``reduce()`` all-reduces the sufficient statistics over
+RCCL (world size > 1), ``statistics()`` finalises (mu, sigma) and the Frechet distance is evaluated
+on the device (csrc/frechet.hip).
 
 Reference path replaced: the loop of ``get_activations`` (image_realism/FID/fid_score.py:99-113:
 batch.cuda(); model(batch); pred.cpu().numpy() per batch), ``np.mean``/``np.cov`` (:194-195),
@@ -23,6 +23,10 @@ import torch.nn.functional as F
 
 from . import _lib, device, dist as tdist
 from .inception import InceptionV3
+
+# MIOpen's find mode also times its reference "naive" direct convolution (~120 ms per call at batch
+# 500, ~40 s per process); it can never win, so keep it out of the search.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
 
 T_COCO = 0.9091363549232483    # image_realism/IS/coco/inception_score_star_coco.py:107
 T_BIRD = 0.5980541706085205    # image_realism/IS/bird/inception_score_star_bird.py:192
@@ -46,7 +50,9 @@ class RealismEngine:
             device_index = torch.cuda.current_device()
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
-        torch.backends.cudnn.benchmark = True          # MIOpen find mode: pick the fastest conv solver per shape
+        # MIOpen find mode (time every applicable solver once per conv shape, keep the fastest);
+        # TISE_MIOPEN_FIND=0 falls back to MIOpen's immediate-mode heuristic (faster start-up)
+        torch.backends.cudnn.benchmark = os.environ.get("TISE_MIOPEN_FIND", "1") != "0"
         self.dims = dims
         self.with_logits = with_logits
         if channels_last is None:

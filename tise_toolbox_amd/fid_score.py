@@ -194,10 +194,8 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
         f.close()
         return m, s
     files = img_data.get_filenames(path)                  # os.walk order (img_data.py:27-35)
-    n_used = tdist.n_used_images(len(files), batch_size)  # drop_last=True (:215-217)
     rank, world, _ = tdist.env_world()
-    lo, hi = tdist.shard_range(n_used // batch_size, rank, world)       # shard whole batches
-    shard = files[lo * batch_size:hi * batch_size]
+    shard, _ = tdist.shard_files(files, batch_size, rank, world)       # drop_last=True (:215-217), whole batches
     dataset = img_data.Dataset(path, transform=None, file_names=shard)
     dataloader = torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=False, drop_last=True,
                                              num_workers=num_workers, collate_fn=img_data.collate_u8,

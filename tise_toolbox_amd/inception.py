@@ -181,15 +181,38 @@ class Inception3(nn.Module):
         self.fc = nn.Linear(2048, num_classes)
 
 
+def _trunk_forward(net, x):
+    """pool3 features of an ``Inception3`` module tree (used only to calibrate stand-in weights)."""
+    x = net.Conv2d_2b_3x3(net.Conv2d_2a_3x3(net.Conv2d_1a_3x3(x)))
+    x = F.max_pool2d(x, kernel_size=3, stride=2)
+    x = net.Conv2d_4a_3x3(net.Conv2d_3b_1x1(x))
+    x = F.max_pool2d(x, kernel_size=3, stride=2)
+    for name in ("Mixed_5b", "Mixed_5c", "Mixed_5d", "Mixed_6a", "Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e",
+                 "Mixed_7a", "Mixed_7b", "Mixed_7c"):
+        x = getattr(net, name)(x)
+    return F.adaptive_avg_pool2d(x, (1, 1)).flatten(1)
+
+
+_SEEDED_CACHE = {}
+
+
 @torch.no_grad()
 def seeded_init_(net, seed=0):
     """Deterministic stand-in weights (no pretrained file exists offline).
 
-    He-normal conv weights and a mildly non-trivial BN so activations keep O(1)
-    scale through the 94 conv layers; drawn on CPU from one generator so CPU and
-    GPU runs see identical parameters.  Throughput is weight-independent; scores
-    obtained with these weights are only comparable between paths run on them.
+    He-normal conv weights, then a data-dependent BatchNorm calibration: one train-mode pass over a
+    fixed synthetic batch sets every BN's running mean/variance to the statistics of its own input,
+    as in a trained network.  Without it a 94-layer random ReLU stack maps every image to almost
+    the same feature vector (FID ~ 0, IS ~ 1) and the parity tests would test nothing; with it the
+    features are image dependent.  The classifier bias is centred on the calibration batch so the
+    logits are image dependent too.  Everything is drawn and computed on the CPU from one
+    generator, so CPU and GPU runs see identical parameters.  Throughput is weight-independent;
+    scores obtained with these weights are only comparable between paths run on them.
     """
+    key = (seed, net.fc.out_features)
+    if key in _SEEDED_CACHE:
+        net.load_state_dict(_SEEDED_CACHE[key])
+        return net
     g = torch.Generator(device="cpu").manual_seed(seed)
     for name, m in net.named_modules():
         if isinstance(m, nn.Conv2d):
@@ -197,12 +220,41 @@ def seeded_init_(net, seed=0):
             m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5)
         elif isinstance(m, nn.BatchNorm2d):
             m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=g))
-            m.bias.copy_(0.05 * torch.randn(m.bias.shape, generator=g))
-            m.running_mean.copy_(0.05 * torch.randn(m.running_mean.shape, generator=g))
-            m.running_var.copy_(1.0 + 0.1 * torch.rand(m.running_var.shape, generator=g))
-        elif isinstance(m, nn.Linear):
-            m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (4.0 / m.in_features ** 0.5))
             m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+            m.running_mean.zero_()
+            m.running_var.fill_(1.0)
+        elif isinstance(m, nn.Linear):
+            m.weight.copy_(torch.randn(m.weight.shape, generator=g) * 0.3)
+            m.bias.zero_()
+    # calibration batch: smooth random fields in [0,1], already through the inception.py:120-124 affine
+    n_cal = 8
+    x = torch.rand((n_cal, 3, 10, 10), generator=g)
+    x = F.interpolate(x, size=(299, 299), mode="bicubic", align_corners=False).clamp_(0.0, 1.0)
+    x = x + 0.05 * torch.rand((n_cal, 3, 299, 299), generator=g)
+    x[:, 0] = x[:, 0] * (0.229 / 0.5) + (0.485 - 0.5) / 0.5
+    x[:, 1] = x[:, 1] * (0.224 / 0.5) + (0.456 - 0.5) / 0.5
+    x[:, 2] = x[:, 2] * (0.225 / 0.5) + (0.406 - 0.5) / 0.5
+    bns = [m for m in net.modules() if isinstance(m, nn.BatchNorm2d)]
+    old = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0                     # running stats := statistics of this one batch
+    was_training = net.training
+    net.train()
+    _trunk_forward(net, x)
+    # bring pool3 to the magnitude of real InceptionV3 features (mean ~0.25) so that FID values -- and
+    # with them the absolute |dFID| <= 1e-3 budget -- sit in the range the reference publishes (2..200)
+    for name in ("branch1x1", "branch3x3_2a", "branch3x3_2b", "branch3x3dbl_3a", "branch3x3dbl_3b", "branch_pool"):
+        bn = getattr(net.Mixed_7c, name).bn
+        bn.weight.mul_(0.35)
+        bn.bias.mul_(0.35)
+    net.eval()
+    feats = _trunk_forward(net, x)
+    for m, mom in zip(bns, old):
+        m.momentum = mom
+    net.fc.bias.copy_(-(net.fc.weight @ feats.mean(0)))
+    if was_training:
+        net.train()
+    _SEEDED_CACHE[key] = {k: v.clone() for k, v in net.state_dict().items()}
     return net
 
 
