@@ -145,6 +145,28 @@ int tise_is_finalize(const double* acc_dev, int C_eff, int64_t n_total, int spli
                      double* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * (a5, epilogues) Fused channels-last fp32 epilogues around the MIOpen convolutions of the
+ * InceptionV3 trunk (image_realism/FID/inception.py:59-95 via torchvision BasicConv2d = conv ->
+ * BatchNorm(eval) -> ReLU, InceptionA/C/E branch_pool = avg_pool2d(3,1,1) -> 1x1 conv,
+ * InceptionB/D branch_pool and the stem = max_pool2d(3,2), torch.cat of the branches).
+ * BatchNorm is folded into the conv weights and the per-channel bias by the caller.
+ * All tensors are NHWC fp32; x is addressed as x[pixel*x_ld + x_off + c] and out as
+ * out[pixel*out_ld + out_off + c], c < C, so a kernel can read a channel slice of a fused 1x1
+ * conv output and write straight into the channel slice of a block's concatenated output.
+ * C, offsets and leading dimensions must be multiples of 4.
+ * ------------------------------------------------------------------------------------------ */
+/* out = max(x + bias, 0); may run in place (out == x, same ld/off). */
+int tise_bias_relu_nhwc(const float* x_dev, int64_t x_ld, int x_off, int64_t pixels, int C,
+                        const float* bias_dev, float* out_dev, int64_t out_ld, int out_off, void* stream);
+/* out = max(avgpool3x3(stride 1, pad 1, count_include_pad)(x) + bias, 0) over an (n,h,w) grid. */
+int tise_avgpool3_bias_relu_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
+                                 const float* bias_dev, float* out_dev, int64_t out_ld, int out_off, void* stream);
+/* out (n, (h-3)/2+1, (w-3)/2+1) = maxpool3x3(stride 2)(x); with bias_dev != NULL the input is a raw
+ * conv output and max(. + bias, 0) is applied (ReLU and max commute). */
+int tise_maxpool3s2_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
+                         const float* bias_dev, float* out_dev, int64_t out_ld, int out_off, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * fp64 GEMM building block (MFMA v_mfma_f64_16x16x4_f64), exported for tests/bench only:
  * C[m][n] (ldc) = sum_k A(m,k) * B(k,n) with A(m,k) = a[m*sam + k*sak], B(k,n) = b[k*sbk + n*sbn].
  * ------------------------------------------------------------------------------------------ */

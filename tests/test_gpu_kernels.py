@@ -284,3 +284,64 @@ def test_is_sharded_updates_match_oracle(dev, n, c, splits, rule):
     got = acc.acc.cpu().numpy()
     np.testing.assert_allclose(got[:splits], A, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(got[splits:].reshape(splits, c), B, rtol=1e-12, atol=1e-13)
+
+
+# ------------------------------------------------------------------------------------------- trunk epilogues
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def test_bias_relu_slices_exact(dev):
+    """Reads a channel slice of a wider raw tensor, writes a channel slice of a concat buffer; exact."""
+    from tise_toolbox_amd.trunk import FusedTrunk
+    g = torch.Generator(device="cpu").manual_seed(0)
+    raw = torch.randn((3, 7, 5, 176), generator=g).to(dev)
+    bias = torch.randn(176, generator=g).to(dev)
+    out = torch.full((3, 7, 5, 256), -7.0, device=dev)
+    FusedTrunk._bias_relu(raw, bias[64:112], 64, 48, out, 128)
+    want = torch.relu(raw[..., 64:112] + bias[64:112])
+    assert torch.equal(out[..., 128:176], want)
+    assert torch.all(out[..., :128] == -7.0) and torch.all(out[..., 176:] == -7.0)      # nothing else touched
+    packed = FusedTrunk._bias_relu(raw, bias[112:176], 112, 64)
+    assert packed.shape == (3, 7, 5, 64) and torch.equal(packed, torch.relu(raw[..., 112:176] + bias[112:176]))
+    r2 = raw.clone()
+    same = FusedTrunk._bias_relu(r2, bias)                                                # in place
+    assert same.data_ptr() == r2.data_ptr() and torch.equal(r2, torch.relu(raw + bias))
+
+
+def test_avgpool_and_maxpool_vs_torch(dev):
+    import torch.nn.functional as F
+    from tise_toolbox_amd.trunk import FusedTrunk
+    g = torch.Generator(device="cpu").manual_seed(1)
+    raw = torch.randn((2, 9, 11, 96), generator=g).to(dev)
+    bias = torch.randn(32, generator=g).to(dev)
+    out = torch.zeros((2, 9, 11, 64), device=dev)
+    FusedTrunk._avgpool_bias_relu(raw, bias, 48, 32, out, 16)
+    x = raw[..., 48:80].permute(0, 3, 1, 2)
+    want = torch.relu(F.avg_pool2d(x, 3, 1, 1) + bias.view(1, -1, 1, 1)).permute(0, 2, 3, 1)     # count_include_pad=True
+    assert (out[..., 16:48] - want).abs().max().item() <= 1e-6
+    xin = torch.randn((2, 13, 9, 48), generator=g).to(dev)
+    b48 = torch.randn(48, generator=g).to(dev)
+    got = FusedTrunk._maxpool(xin, b48)
+    want = F.max_pool2d(torch.relu(xin.permute(0, 3, 1, 2) + b48.view(1, -1, 1, 1)), 3, 2).permute(0, 2, 3, 1)
+    assert got.shape == (2, 6, 4, 48) and torch.equal(got, want.contiguous())
+    cat = torch.zeros((2, 6, 4, 64), device=dev)
+    FusedTrunk._maxpool(xin, None, cat, 16)
+    assert torch.equal(cat[..., 16:], F.max_pool2d(xin.permute(0, 3, 1, 2), 3, 2).permute(0, 2, 3, 1))
+
+
+@pytest.mark.parametrize("dims", [2048, 768, 192, 64])
+def test_fused_trunk_matches_module_graph(dev, dims):
+    """MIOpen convs + fused HIP epilogues (1x1 fusion, pool/conv commutation, no cat) vs the plain
+    torchvision-order module graph on the same device and weights."""
+    from tise_toolbox_amd.inception import InceptionV3
+    from tise_toolbox_amd.trunk import FusedTrunk
+    torch.backends.cudnn.benchmark = False
+    m = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[dims]], seed=0).to(dev).eval()
+    x = torch.rand((6, 3, 299, 299), device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        want = m(x, prenormalized=True)[0]
+        got = FusedTrunk(m, dev)(x)
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    assert err <= 2e-4 * want.abs().max().item(), err

@@ -57,6 +57,11 @@ SIGNATURES = {
     "tise_is_update": (c_int, [c_void_p, c_int64, c_int64, c_int, c_double, c_int, c_int64, c_int64, c_int, c_int,
                                 c_void_p, c_void_p, c_void_p]),
     "tise_is_finalize": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "tise_bias_relu_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "tise_avgpool3_bias_relu_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                              c_int64, c_int, c_void_p]),
+    "tise_maxpool3s2_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64,
+                                      c_int, c_void_p]),
     "tise_gemm_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                c_int, c_int, c_int, c_void_p]),
 }

@@ -1,0 +1,159 @@
+// Fused epilogues for the InceptionV3 trunk (channels-last fp32), HBM-bound.
+//
+// The convolutions themselves run in MIOpen (north_star assigns the conv stack to PyTorch-ROCm).
+// rocprofv3 of the first version (profiles/r01a_*) showed that 35 % of a step was NOT convolution:
+// per conv one bias-add pass and one ReLU pass over the output (PyTorch adds the bias of a MIOpen
+// conv as a separate elementwise kernel), torch.cat copies of every branch, and a slow NHWC
+// avg_pool2d over the full-width block input.  These kernels do that work in ONE pass per tensor:
+//
+//   bias_relu_nhwc        out[p][off+c] = max(x[p][xoff+c] + b[c], 0)   -- reads a channel slice of a
+//                         (possibly wider, fused-1x1) raw conv output and writes straight into the
+//                         channel slice of the block's concatenated output (no torch.cat), or in place.
+//   avgpool3_bias_relu    3x3 / stride 1 / pad 1 / count_include_pad average, + bias, ReLU.  Used AFTER
+//                         the 1x1 conv of the pool branch: avg-pool and a 1x1 convolution are both
+//                         linear and commute (also at the zero-padded border), so the pool runs on
+//                         32..192 channels instead of 192..2048 (reference graph order: pool, then conv,
+//                         torchvision InceptionA/C/E branch_pool).
+//   maxpool3s2            3x3 / stride 2 max pool, optionally max(. + b, 0) first (ReLU and max commute),
+//                         writing into a concat slice (InceptionB/D pool branch) or a packed tensor (stem).
+//
+// All are float4-vectorised along the channel dimension (every channel count / offset in the
+// network is a multiple of 16).  Algorithmic bytes: one read + one write of the tensor (+8 neighbour
+// reads served by L2 for the pools).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 f4_bias_relu(float4 v, float4 b) {
+    v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f);
+    v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+    return v;
+}
+
+// grid.x over (pixel, c4) pairs; C4 = C/4
+__global__ __launch_bounds__(256) void bias_relu_nhwc_kernel(const float* __restrict__ x, int64_t x_ld, int x_off,
+                                                             int64_t pixels, int C4, const float* __restrict__ bias,
+                                                             float* __restrict__ out, int64_t out_ld, int out_off) {
+    const int64_t total = pixels * C4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = e / C4;
+        const int c4 = (int)(e - p * C4);
+        const float4 v = *reinterpret_cast<const float4*>(x + p * x_ld + x_off + 4 * c4);
+        const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
+        *reinterpret_cast<float4*>(out + p * out_ld + out_off + 4 * c4) = f4_bias_relu(v, b);
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool3_bias_relu_nhwc_kernel(const float* __restrict__ x, int64_t x_ld,
+                                                                      int x_off, int N, int H, int W, int C4,
+                                                                      const float* __restrict__ bias,
+                                                                      float* __restrict__ out, int64_t out_ld,
+                                                                      int out_off) {
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = e / C4;
+        const int c4 = (int)(e - p * C4);
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dh = -1; dh <= 1; ++dh) {
+            const int hh = h + dh;
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int dw = -1; dw <= 1; ++dw) {
+                const int ww = w + dw;
+                if (ww < 0 || ww >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + (p + (int64_t)dh * W + dw) * x_ld + x_off + 4 * c4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        s.x /= 9.f; s.y /= 9.f; s.z /= 9.f; s.w /= 9.f;      // count_include_pad=True: always / 9
+        const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c4);
+        *reinterpret_cast<float4*>(out + p * out_ld + out_off + 4 * c4) = f4_bias_relu(s, b);
+    }
+}
+
+template <bool BIAS_RELU>
+__global__ __launch_bounds__(256) void maxpool3s2_nhwc_kernel(const float* __restrict__ x, int64_t x_ld, int x_off,
+                                                              int N, int H, int W, int C4,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int64_t out_ld, int out_off) {
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * OH * OW * C4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = e / C4;
+        const int c4 = (int)(e - p * C4);
+        const int ow = (int)(p % OW);
+        const int oh = (int)((p / OW) % OH);
+        const int64_t n = p / ((int64_t)OW * OH);
+        const int64_t base = (n * H + 2 * oh) * W + 2 * ow;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const float4 v = *reinterpret_cast<const float4*>(x + (base + (int64_t)dh * W + dw) * x_ld + x_off + 4 * c4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        if (BIAS_RELU) m = f4_bias_relu(m, *reinterpret_cast<const float4*>(bias + 4 * c4));
+        *reinterpret_cast<float4*>(out + p * out_ld + out_off + 4 * c4) = m;
+    }
+}
+
+inline int grid_for(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    if (b > 16384) b = 16384;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+inline bool aligned4(int64_t a, int b, int c) { return (a % 4 == 0) && (b % 4 == 0) && (c % 4 == 0); }
+
+}  // namespace
+
+extern "C" {
+
+int tise_bias_relu_nhwc(const float* x_dev, int64_t x_ld, int x_off, int64_t pixels, int C, const float* bias_dev,
+                        float* out_dev, int64_t out_ld, int out_off, void* stream) {
+    if (!x_dev || !bias_dev || !out_dev || pixels < 0 || C <= 0 || !aligned4(x_ld, x_off, C) ||
+        !aligned4(out_ld, out_off, C) || x_off + C > x_ld || out_off + C > out_ld)
+        return TISE_ERR_INVALID_ARG;
+    if (pixels == 0) return TISE_OK;
+    hipLaunchKernelGGL(bias_relu_nhwc_kernel, dim3(grid_for(pixels * (C / 4))), dim3(256), 0, (hipStream_t)stream, x_dev,
+                       x_ld, x_off, pixels, C / 4, bias_dev, out_dev, out_ld, out_off);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+int tise_avgpool3_bias_relu_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
+                                 const float* bias_dev, float* out_dev, int64_t out_ld, int out_off, void* stream) {
+    if (!x_dev || !bias_dev || !out_dev || n < 0 || h <= 0 || w <= 0 || C <= 0 || !aligned4(x_ld, x_off, C) ||
+        !aligned4(out_ld, out_off, C) || x_off + C > x_ld || out_off + C > out_ld)
+        return TISE_ERR_INVALID_ARG;
+    if (n == 0) return TISE_OK;
+    hipLaunchKernelGGL(avgpool3_bias_relu_nhwc_kernel, dim3(grid_for((int64_t)n * h * w * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, x_dev, x_ld, x_off, n, h, w, C / 4, bias_dev, out_dev, out_ld, out_off);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+int tise_maxpool3s2_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C, const float* bias_dev,
+                         float* out_dev, int64_t out_ld, int out_off, void* stream) {
+    if (!x_dev || !out_dev || n < 0 || h < 3 || w < 3 || C <= 0 || !aligned4(x_ld, x_off, C) ||
+        !aligned4(out_ld, out_off, C) || x_off + C > x_ld || out_off + C > out_ld)
+        return TISE_ERR_INVALID_ARG;
+    if (n == 0) return TISE_OK;
+    const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
+    const int g = grid_for((int64_t)n * oh * ow * (C / 4));
+    if (bias_dev)
+        hipLaunchKernelGGL(maxpool3s2_nhwc_kernel<true>, dim3(g), dim3(256), 0, (hipStream_t)stream, x_dev, x_ld, x_off, n,
+                           h, w, C / 4, bias_dev, out_dev, out_ld, out_off);
+    else
+        hipLaunchKernelGGL(maxpool3s2_nhwc_kernel<false>, dim3(g), dim3(256), 0, (hipStream_t)stream, x_dev, x_ld, x_off,
+                           n, h, w, C / 4, bias_dev, out_dev, out_ld, out_off);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+}  // extern "C"

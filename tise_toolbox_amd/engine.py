@@ -44,7 +44,7 @@ def require_gpu():
 class RealismEngine:
     def __init__(self, dims=2048, device_index=None, weights=None, num_classes=1000, seed=0,
                  channels_last=None, fold_bn=True, with_logits=False, model=None, normalize_input=True,
-                 lut=None):
+                 lut=None, fused=None):
         require_gpu()
         if device_index is None:
             device_index = torch.cuda.current_device()
@@ -70,6 +70,13 @@ class RealismEngine:
         if lut is None:
             lut = device.make_lut(normalize_input=getattr(self.model, "normalize_input", True))
         self.lut = lut
+        # MIOpen convs + hand-written HIP epilogues (trunk.py); TISE_FUSED_TRUNK=0 runs the plain module graph
+        self.fused = None
+        if fused is None:
+            fused = os.environ.get("TISE_FUSED_TRUNK", "1") != "0"
+        if fused and channels_last and isinstance(self.model, InceptionV3):
+            from .trunk import FusedTrunk
+            self.fused = FusedTrunk(self.model, self.device)
         self.stats = None
         self.is_acc = None
 
@@ -84,12 +91,19 @@ class RealismEngine:
     def features_from_float(self, batch):
         """(B,3,H,W) fp32 in [0,1] (the reference's DataLoader output) -> pool3 (B,dims) fp32."""
         x = batch.to(self.device, non_blocking=True).float()
+        if hasattr(self.model, "preprocess"):
+            x = self.model.preprocess(x)
         if self.channels_last:
             x = x.contiguous(memory_format=torch.channels_last)
-        return self._trunk(x, prenormalized=False)
+        return self._trunk(x, prenormalized=True)
 
     def _trunk(self, x, prenormalized):
-        pred = self.model(x, prenormalized=prenormalized)[0]
+        if self.fused is not None and prenormalized:
+            pred = self.fused(x)
+        elif hasattr(self.model, "preprocess"):
+            pred = self.model(x, prenormalized=prenormalized)[0]
+        else:
+            pred = self.model(x)[0]
         if pred.shape[2] != 1 or pred.shape[3] != 1:                 # fid_score.py:110-111
             pred = F.adaptive_avg_pool2d(pred, output_size=(1, 1))
         feats = pred.reshape(pred.shape[0], -1)

@@ -332,16 +332,7 @@ class InceptionV3(nn.Module):
         """inception.py:100-134.  ``prenormalized=True`` is the fused device path: the
         input is already 299x299 with the :120-124 affine applied by the resize kernel."""
         outp = []
-        x = inp
-        if not prenormalized:
-            if self.resize_input and tuple(x.shape[-2:]) != (299, 299):
-                # :117-118; for 299x299 input align_corners bilinear is the identity map
-                x = F.interpolate(x, size=(299, 299), mode="bilinear", align_corners=True)
-            if self.normalize_input:                                        # :120-124
-                x = x.clone()
-                x[:, 0] = x[:, 0] * (0.229 / 0.5) + (0.485 - 0.5) / 0.5
-                x[:, 1] = x[:, 1] * (0.224 / 0.5) + (0.456 - 0.5) / 0.5
-                x[:, 2] = x[:, 2] * (0.225 / 0.5) + (0.406 - 0.5) / 0.5
+        x = inp if prenormalized else self.preprocess(inp)
         for idx, block in enumerate(self.blocks):                           # :126-132
             x = block(x)
             if idx in self.output_blocks:
@@ -349,6 +340,18 @@ class InceptionV3(nn.Module):
             if idx == self.last_needed_block:
                 break
         return outp
+
+    def preprocess(self, x):
+        """inception.py:117-124: optional align_corners bilinear resize to 299x299, then the input affine."""
+        if self.resize_input and tuple(x.shape[-2:]) != (299, 299):
+            # :117-118; for 299x299 input align_corners bilinear is the identity map
+            x = F.interpolate(x, size=(299, 299), mode="bilinear", align_corners=True)
+        if self.normalize_input:                                            # :120-124
+            x = x.clone()
+            x[:, 0] = x[:, 0] * (0.229 / 0.5) + (0.485 - 0.5) / 0.5
+            x[:, 1] = x[:, 1] * (0.224 / 0.5) + (0.456 - 0.5) / 0.5
+            x[:, 2] = x[:, 2] * (0.225 / 0.5) + (0.406 - 0.5) / 0.5
+        return x
 
     def logits(self, pool3):
         """fc head on pool3 features (B,2048[,1,1]) -> (B, num_classes)."""

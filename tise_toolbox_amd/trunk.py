@@ -1,0 +1,237 @@
+"""Fused InceptionV3 trunk executor: MIOpen convolutions + hand-written HIP epilogues.
+
+Same function as ``InceptionV3.forward`` (mirror of ``image_realism/FID/inception.py:100-134``) for
+inputs that are already 299x299 and affine-normalised by the resize kernel, restructured for MI355X
+after the first rocprof pass (``profiles/r01a_*``: 35 % of a step was not convolution):
+
+* eval-mode BatchNorm folded into the weights; the bias + ReLU of every conv is ONE in-place pass
+  (``tise_bias_relu_nhwc``) instead of PyTorch's separate bias-add and ReLU kernels;
+* the 1x1 convolutions that read the same block input (torchvision InceptionA/C/D/E: branch1x1,
+  the ``*_1`` reducers and the pool branch's 1x1) are one convolution with concatenated output
+  channels (94 -> 66 conv launches, larger GEMM N);
+* the pool branch is evaluated as 1x1 conv THEN 3x3 average (both linear, they commute, border
+  included) so the pool touches 32..192 channels instead of 192..2048, fused with bias + ReLU
+  (``tise_avgpool3_bias_relu_nhwc``);
+* every branch's last epilogue writes straight into its channel slice of the block output -- no
+  ``torch.cat``;
+* the two stem max-pools absorb the preceding conv's bias + ReLU (``tise_maxpool3s2_nhwc``).
+
+Numerics: fp32 throughout; relative to the reference graph order only fp32 summation order changes
+(pool/conv commutation, fused-1x1 kernel choice).  ``tests/test_gpu_pipeline.py`` checks it against the
+unfused module and against the CPU oracle.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .inception import BasicConv2d, InceptionV3
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+class _Conv:
+    """Folded conv parameters on the device: weight (Cout,Cin,kh,kw) channels-last, bias (Cout,)."""
+
+    __slots__ = ("w", "b", "stride", "padding", "cout")
+
+    def __init__(self, mods, device):
+        ws, bs = [], []
+        for m in mods:
+            bn = m.bn
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            ws.append(m.conv.weight * scale.view(-1, 1, 1, 1))
+            bs.append(bn.bias - bn.running_mean * scale)
+        m0 = mods[0].conv
+        for m in mods[1:]:
+            assert m.conv.kernel_size == m0.kernel_size and m.conv.stride == m0.stride and m.conv.padding == m0.padding
+        self.w = torch.cat(ws, 0).to(device).contiguous(memory_format=torch.channels_last)
+        self.b = torch.cat(bs, 0).to(device).contiguous()
+        self.stride, self.padding = m0.stride, m0.padding
+        self.cout = self.w.shape[0]
+
+
+class FusedTrunk:
+    """Callable: (N,299,299,3)-storage channels-last input -> pool3 features (N, 2048) fp32."""
+
+    def __init__(self, model, device):
+        assert isinstance(model, InceptionV3)
+        self.device = torch.device(device)
+        with torch.no_grad():
+            mods = dict(model.named_modules())
+
+            def conv(*names):
+                ms = [mods[n] for n in names]
+                assert all(isinstance(m, BasicConv2d) for m in ms)
+                return _Conv(ms, self.device)
+
+            b0, b1, b2, b3 = "blocks.0.", "blocks.1.", "blocks.2.", "blocks.3."
+            self.last_block = model.last_needed_block
+            self.c1a, self.c2a, self.c2b = conv(b0 + "0"), conv(b0 + "1"), conv(b0 + "2")
+            if self.last_block >= 1:
+                self.c3b, self.c4a = conv(b1 + "0"), conv(b1 + "1")
+            self.blocks = []
+            if self.last_block >= 2:
+                for i, kind in enumerate("AAABCCCC"):
+                    self.blocks.append((kind, self._block_params(kind, b2 + str(i) + ".", conv)))
+            if self.last_block >= 3:
+                for i, kind in enumerate("DEE"):
+                    self.blocks.append((kind, self._block_params(kind, b3 + str(i) + ".", conv)))
+
+    @staticmethod
+    def _block_params(kind, p, conv):
+        if kind == "A":
+            return dict(f=conv(p + "branch1x1", p + "branch5x5_1", p + "branch3x3dbl_1", p + "branch_pool"),
+                        c5=conv(p + "branch5x5_2"), d2=conv(p + "branch3x3dbl_2"), d3=conv(p + "branch3x3dbl_3"))
+        if kind == "B":
+            return dict(c3=conv(p + "branch3x3"), d1=conv(p + "branch3x3dbl_1"), d2=conv(p + "branch3x3dbl_2"),
+                        d3=conv(p + "branch3x3dbl_3"))
+        if kind == "C":
+            return dict(f=conv(p + "branch1x1", p + "branch7x7_1", p + "branch7x7dbl_1", p + "branch_pool"),
+                        s2=conv(p + "branch7x7_2"), s3=conv(p + "branch7x7_3"), d2=conv(p + "branch7x7dbl_2"),
+                        d3=conv(p + "branch7x7dbl_3"), d4=conv(p + "branch7x7dbl_4"), d5=conv(p + "branch7x7dbl_5"))
+        if kind == "D":
+            return dict(f=conv(p + "branch3x3_1", p + "branch7x7x3_1"), c32=conv(p + "branch3x3_2"),
+                        s2=conv(p + "branch7x7x3_2"), s3=conv(p + "branch7x7x3_3"), s4=conv(p + "branch7x7x3_4"))
+        if kind == "E":
+            return dict(f=conv(p + "branch1x1", p + "branch3x3_1", p + "branch3x3dbl_1", p + "branch_pool"),
+                        a2=conv(p + "branch3x3_2a"), b2=conv(p + "branch3x3_2b"), d2=conv(p + "branch3x3dbl_2"),
+                        a3=conv(p + "branch3x3dbl_3a"), b3=conv(p + "branch3x3dbl_3b"))
+        raise ValueError(kind)
+
+    # ---- primitive ops on NHWC tensors ---------------------------------------------------------------
+    @staticmethod
+    def _conv(x, c):
+        """x: (N,H,W,Cin) contiguous -> raw conv output (N,OH,OW,Cout) contiguous (no bias, no ReLU)."""
+        y = torch.conv2d(x.permute(0, 3, 1, 2), c.w, None, c.stride, c.padding).permute(0, 2, 3, 1)
+        return y if y.is_contiguous() else y.contiguous()
+
+    @staticmethod
+    def _bias_relu(raw, bias, x_off=0, C=None, out=None, out_off=0):
+        """max(raw[..., x_off:x_off+C] + bias, 0) -> out[..., out_off:out_off+C] (in place when out is None
+        and the slice is the whole tensor; a new packed tensor when out is None and it is a sub-slice)."""
+        n, h, w, ld = raw.shape
+        C = ld if C is None else C
+        if out is None:
+            out = raw if (x_off == 0 and C == ld) else torch.empty((n, h, w, C), dtype=raw.dtype, device=raw.device)
+        _lib.call("tise_bias_relu_nhwc", _p(raw), ld, x_off, n * h * w, C, _p(bias), _p(out), out.shape[3], out_off,
+                  _stream())
+        return out
+
+    @staticmethod
+    def _avgpool_bias_relu(raw, bias, x_off, C, out, out_off):
+        n, h, w, ld = raw.shape
+        _lib.call("tise_avgpool3_bias_relu_nhwc", _p(raw), ld, x_off, n, h, w, C, _p(bias), _p(out), out.shape[3],
+                  out_off, _stream())
+
+    @staticmethod
+    def _maxpool(x, bias=None, out=None, out_off=0):
+        n, h, w, C = x.shape
+        oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        if out is None:
+            out = torch.empty((n, oh, ow, C), dtype=x.dtype, device=x.device)
+        _lib.call("tise_maxpool3s2_nhwc", _p(x), C, 0, n, h, w, C, _p(bias) if bias is not None else None, _p(out),
+                  out.shape[3], out_off, _stream())
+        return out
+
+    # ---- blocks -------------------------------------------------------------------------------------
+    def _block_a(self, x, P):
+        n, h, w, _ = x.shape
+        f, c5, d2, d3 = P["f"], P["c5"], P["d2"], P["d3"]
+        pf = f.cout - 176
+        out = torch.empty((n, h, w, 224 + pf), dtype=x.dtype, device=x.device)
+        raw = self._conv(x, f)                                       # [1x1:64 | 5x5_1:48 | dbl_1:64 | pool:pf]
+        self._bias_relu(raw, f.b[0:64], 0, 64, out, 0)
+        t5 = self._bias_relu(raw, f.b[64:112], 64, 48)
+        t3 = self._bias_relu(raw, f.b[112:176], 112, 64)
+        self._avgpool_bias_relu(raw, f.b[176:], 176, pf, out, 224)
+        self._bias_relu(self._conv(t5, c5), c5.b, 0, 64, out, 64)
+        t3 = self._bias_relu(self._conv(t3, d2), d2.b)
+        self._bias_relu(self._conv(t3, d3), d3.b, 0, 96, out, 128)
+        return out
+
+    def _block_b(self, x, P):
+        n, h, w, cin = x.shape
+        oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        out = torch.empty((n, oh, ow, 384 + 96 + cin), dtype=x.dtype, device=x.device)
+        self._bias_relu(self._conv(x, P["c3"]), P["c3"].b, 0, 384, out, 0)
+        t = self._bias_relu(self._conv(x, P["d1"]), P["d1"].b)
+        t = self._bias_relu(self._conv(t, P["d2"]), P["d2"].b)
+        self._bias_relu(self._conv(t, P["d3"]), P["d3"].b, 0, 96, out, 384)
+        self._maxpool(x, None, out, 480)
+        return out
+
+    def _block_c(self, x, P):
+        n, h, w, _ = x.shape
+        f = P["f"]
+        c7 = (f.cout - 384) // 2
+        out = torch.empty((n, h, w, 768), dtype=x.dtype, device=x.device)
+        raw = self._conv(x, f)                                       # [1x1:192 | 7x7_1:c7 | dbl_1:c7 | pool:192]
+        self._bias_relu(raw, f.b[0:192], 0, 192, out, 0)
+        t7 = self._bias_relu(raw, f.b[192:192 + c7], 192, c7)
+        td = self._bias_relu(raw, f.b[192 + c7:192 + 2 * c7], 192 + c7, c7)
+        self._avgpool_bias_relu(raw, f.b[192 + 2 * c7:], 192 + 2 * c7, 192, out, 576)
+        t7 = self._bias_relu(self._conv(t7, P["s2"]), P["s2"].b)
+        self._bias_relu(self._conv(t7, P["s3"]), P["s3"].b, 0, 192, out, 192)
+        for k in ("d2", "d3", "d4"):
+            td = self._bias_relu(self._conv(td, P[k]), P[k].b)
+        self._bias_relu(self._conv(td, P["d5"]), P["d5"].b, 0, 192, out, 384)
+        return out
+
+    def _block_d(self, x, P):
+        n, h, w, cin = x.shape
+        oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        f = P["f"]
+        out = torch.empty((n, oh, ow, 320 + 192 + cin), dtype=x.dtype, device=x.device)
+        raw = self._conv(x, f)                                       # [3x3_1:192 | 7x7x3_1:192]
+        t3 = self._bias_relu(raw, f.b[0:192], 0, 192)
+        t7 = self._bias_relu(raw, f.b[192:384], 192, 192)
+        self._bias_relu(self._conv(t3, P["c32"]), P["c32"].b, 0, 320, out, 0)
+        for k in ("s2", "s3"):
+            t7 = self._bias_relu(self._conv(t7, P[k]), P[k].b)
+        self._bias_relu(self._conv(t7, P["s4"]), P["s4"].b, 0, 192, out, 320)
+        self._maxpool(x, None, out, 512)
+        return out
+
+    def _block_e(self, x, P):
+        n, h, w, _ = x.shape
+        f = P["f"]
+        out = torch.empty((n, h, w, 2048), dtype=x.dtype, device=x.device)
+        raw = self._conv(x, f)                                       # [1x1:320 | 3x3_1:384 | dbl_1:448 | pool:192]
+        self._bias_relu(raw, f.b[0:320], 0, 320, out, 0)
+        t3 = self._bias_relu(raw, f.b[320:704], 320, 384)
+        td = self._bias_relu(raw, f.b[704:1152], 704, 448)
+        self._avgpool_bias_relu(raw, f.b[1152:1344], 1152, 192, out, 1856)
+        self._bias_relu(self._conv(t3, P["a2"]), P["a2"].b, 0, 384, out, 320)
+        self._bias_relu(self._conv(t3, P["b2"]), P["b2"].b, 0, 384, out, 704)
+        td = self._bias_relu(self._conv(td, P["d2"]), P["d2"].b)
+        self._bias_relu(self._conv(td, P["a3"]), P["a3"].b, 0, 384, out, 1088)
+        self._bias_relu(self._conv(td, P["b3"]), P["b3"].b, 0, 384, out, 1472)
+        return out
+
+    @torch.no_grad()
+    def __call__(self, x_nchw_channels_last):
+        """Input: (N,3,299,299) tensor in channels_last memory format (what the resize kernel emits).
+        Output: the feature map of the wrapper's last needed block as an NCHW *view* of NHWC storage
+        (block 3: (N,2048,1,1) after the global average)."""
+        x = x_nchw_channels_last.permute(0, 2, 3, 1)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        a = self._bias_relu(self._conv(x, self.c1a), self.c1a.b)
+        a = self._bias_relu(self._conv(a, self.c2a), self.c2a.b)
+        a = self._maxpool(self._conv(a, self.c2b), self.c2b.b)                 # conv bias + ReLU + max-pool, one pass
+        if self.last_block >= 1:
+            a = self._bias_relu(self._conv(a, self.c3b), self.c3b.b)
+            a = self._maxpool(self._conv(a, self.c4a), self.c4a.b)
+        fn = {"A": self._block_a, "B": self._block_b, "C": self._block_c, "D": self._block_d, "E": self._block_e}
+        for kind, P in self.blocks:
+            a = fn[kind](a, P)
+        if self.last_block >= 3:
+            a = a.mean(dim=(1, 2), keepdim=True)                               # AdaptiveAvgPool2d((1,1))
+        return a.permute(0, 3, 1, 2)
