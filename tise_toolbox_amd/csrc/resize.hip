@@ -93,7 +93,7 @@ int get_plan(int h, int w, int oh, int ow, DevPlan* out) {
     p.h = h; p.w = w; p.oh = oh; p.ow = ow; p.ksx = tx.ksize; p.ksy = ty.ksize;
     // pick the row tile so staged source rows + horizontal-pass rows fit comfortably in LDS
     const size_t lds_budget = 144 * 1024;
-    int rt = 8;
+    int rt = 16;
     int span = 0;
     for (;; rt >>= 1) {
         span = 0;
@@ -162,6 +162,12 @@ __device__ __forceinline__ uint8_t clip8(int v) {
     return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+// SMALLK: every horizontal window has <= 3 taps (any up-scale): the thread keeps its taps in registers.
+// Thread t owns the row elements e = t, t+256, ... (e = ox*3 + c) for EVERY row of the tile, so the
+// per-element table look-ups (window start, taps, table row) are done once per thread, not per pixel,
+// and the inner loops contain no integer division.
+#define RS_MAXE 8     // elements per thread per row kept in registers: supports ow*3 <= 2048
+template <bool SMALLK>
 __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
     const uint8_t* __restrict__ src, int h, int w, float* __restrict__ dst, int oh, int ow, int nhwc,
     const int* __restrict__ plan, int ksx, int ksy, int off_kx, int off_by, int off_ky, int off_t0, int rt, int span,
@@ -182,18 +188,17 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
     const int oy0 = tile * rt;
     const int oy1 = min(oy0 + rt, oh);
     const int ys0 = plan[off_t0 + tile];
-    // last source row needed by this tile
-    int ys1 = 0;
+    int ys1 = 0;                                                         // last source row needed by this tile
     for (int y = oy0; y < oy1; ++y) ys1 = max(ys1, by[2 * y] + by[2 * y + 1]);
     const int nrows = ys1 - ys0;
     const int tid = threadIdx.x;
+    const int rowlen = ow * 3;
 
     for (int i = tid; i < 3 * 256; i += 256) lut_s[i] = lut[i];
 
     // stage source rows [ys0, ys1): rows are contiguous in memory (w*3 bytes each)
     const uint8_t* sbase = src + ((size_t)img * h + ys0) * (size_t)w * 3;
     const int row_bytes = w * 3;
-    const size_t tot = (size_t)nrows * row_bytes;
     if ((((uintptr_t)sbase) & 15) == 0 && (row_bytes & 15) == 0) {
         const int vec_per_row = row_bytes >> 4;
         for (int i = tid; i < nrows * vec_per_row; i += 256) {
@@ -202,65 +207,105 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
                 *reinterpret_cast<const uint4*>(sbase + (size_t)r * row_bytes + c * 16);
         }
     } else {
+        const size_t tot = (size_t)nrows * row_bytes;
         for (size_t i = tid; i < tot; i += 256) {
             const int r = (int)(i / row_bytes), c = (int)(i - (size_t)r * row_bytes);
             srow[(size_t)r * src_pitch + c] = sbase[i];
         }
     }
-    __syncthreads();
 
-    // horizontal pass: trow[r][ox*3+c] for every staged row (skipped, i.e. a copy, when w == ow: Pillow
-    // only resamples an axis whose size changes)
-    const int hcount = nrows * ow * 3;
-    if (w == ow) {
-        for (int i = tid; i < hcount; i += 256) {
-            const int r = i / (ow * 3), e = i - r * (ow * 3);
-            trow[(size_t)r * tmp_pitch + e] = srow[(size_t)r * src_pitch + e];
-        }
-    } else {
-        for (int i = tid; i < hcount; i += 256) {
-            const int r = i / (ow * 3), e = i - r * (ow * 3);
-            const int ox = e / 3, c = e - ox * 3;
-            const int xmin = bx[2 * ox], cnt = bx[2 * ox + 1];
-            const int* k = kx + ox * ksx;
-            const unsigned char* sp = srow + (size_t)r * src_pitch + xmin * 3 + c;
-            int ss = 1 << (PRECISION_BITS - 1);
-            for (int x = 0; x < cnt; ++x) ss += (int)sp[x * 3] * k[x];
-            trow[(size_t)r * tmp_pitch + e] = clip8(ss);
+    // per-thread element descriptors
+    int e_off[RS_MAXE];          // byte offset of the first tap inside a staged source row
+    int e_k[RS_MAXE][3];         // taps (SMALLK)
+    int e_cnt[RS_MAXE];
+    int e_lut[RS_MAXE];          // c * 256
+    int e_dst[RS_MAXE];          // offset of (ox, c) inside an output row (nhwc) / inside a plane row (nchw: ox)
+    int ne = 0;
+#pragma unroll
+    for (int j = 0; j < RS_MAXE; ++j) {
+        const int e = tid + 256 * j;
+        e_off[j] = 0; e_cnt[j] = 0; e_lut[j] = 0; e_dst[j] = 0;
+        e_k[j][0] = e_k[j][1] = e_k[j][2] = 0;
+        if (e < rowlen) {
+            ne = j + 1;
+            const int ox = e / 3, c = e - 3 * ox;
+            const int xmin = (w == ow) ? ox : bx[2 * ox];
+            e_off[j] = xmin * 3 + c;
+            e_cnt[j] = (w == ow) ? 1 : bx[2 * ox + 1];
+            e_lut[j] = c * 256;
+            e_dst[j] = nhwc ? e : ox;
+            if (SMALLK && w != ow) {
+                const int* k = kx + ox * ksx;
+                e_k[j][0] = k[0];
+                e_k[j][1] = e_cnt[j] > 1 ? k[1] : 0;
+                e_k[j][2] = e_cnt[j] > 2 ? k[2] : 0;
+            }
         }
     }
     __syncthreads();
 
-    // vertical pass + table + store
-    const int orows = oy1 - oy0;
-    const int ocount = orows * ow * 3;
-    for (int i = tid; i < ocount; i += 256) {
-        int oy, ox, c;
-        if (nhwc) {                     // i = (oy, ox, c): interleaved output is contiguous in i
-            oy = i / (ow * 3);
-            const int e = i - oy * (ow * 3);
-            ox = e / 3; c = e - ox * 3;
-        } else {                        // i = (c, oy, ox): planar rows contiguous in ox
-            c = i / (orows * ow);
-            const int e = i - c * (orows * ow);
-            oy = e / ow; ox = e - oy * ow;
+    // horizontal pass LDS -> LDS (uint8 intermediate, as Pillow).  When w == ow Pillow skips this pass.
+    for (int r = 0; r < nrows; ++r) {
+        const unsigned char* sr = srow + (size_t)r * src_pitch;
+        unsigned char* tr = trow + (size_t)r * tmp_pitch;
+#pragma unroll
+        for (int j = 0; j < RS_MAXE; ++j) {
+            if (j >= ne) break;
+            const int e = tid + 256 * j;
+            if (e >= rowlen) break;
+            const unsigned char* sp = sr + e_off[j];
+            if (w == ow) {
+                tr[e] = sp[0];
+            } else if (SMALLK) {
+                // taps beyond cnt carry a zero coefficient; clamp their address to stay inside the staged row
+                const int c1 = e_cnt[j] > 1 ? 3 : 0, c2 = e_cnt[j] > 2 ? 6 : 0;
+                const int ss = (1 << (PRECISION_BITS - 1)) + (int)sp[0] * e_k[j][0] + (int)sp[c1] * e_k[j][1] +
+                               (int)sp[c2] * e_k[j][2];
+                tr[e] = clip8(ss);
+            } else {
+                const int ox = e / 3;
+                const int* k = kx + ox * ksx;
+                int ss = 1 << (PRECISION_BITS - 1);
+                for (int x = 0; x < e_cnt[j]; ++x) ss += (int)sp[x * 3] * k[x];
+                tr[e] = clip8(ss);
+            }
         }
-        const int y = oy0 + oy;
-        uint8_t v;
-        if (h == oh) {
-            v = trow[(size_t)(y - ys0) * tmp_pitch + ox * 3 + c];
-        } else {
-            const int ymin = by[2 * y], cnt = by[2 * y + 1];
-            const int* k = ky + y * ksy;
-            const unsigned char* tp = trow + (size_t)(ymin - ys0) * tmp_pitch + ox * 3 + c;
-            int ss = 1 << (PRECISION_BITS - 1);
-            for (int yy = 0; yy < cnt; ++yy) ss += (int)tp[(size_t)yy * tmp_pitch] * k[yy];
-            v = clip8(ss);
+    }
+    __syncthreads();
+
+    // vertical pass + table + store, one output row at a time (row parameters are wave-uniform)
+    for (int y = oy0; y < oy1; ++y) {
+        const int ymin = (h == oh) ? y : by[2 * y];
+        const int cnt = (h == oh) ? 1 : by[2 * y + 1];
+        const int* k = ky + y * ksy;
+        const unsigned char* tbase = trow + (size_t)(ymin - ys0) * tmp_pitch;
+        int k0 = 0, k1 = 0, k2 = 0;
+        if (h != oh && cnt <= 3) { k0 = k[0]; k1 = cnt > 1 ? k[1] : 0; k2 = cnt > 2 ? k[2] : 0; }
+        const int p1 = cnt > 1 ? tmp_pitch : 0, p2 = cnt > 2 ? 2 * tmp_pitch : 0;
+        float* drow_nhwc = dst + ((size_t)img * oh + y) * (size_t)rowlen;
+        uint8_t* urow = u8_out ? u8_out + ((size_t)img * oh + y) * (size_t)rowlen : nullptr;
+#pragma unroll
+        for (int j = 0; j < RS_MAXE; ++j) {
+            if (j >= ne) break;
+            const int e = tid + 256 * j;
+            if (e >= rowlen) break;
+            const unsigned char* tp = tbase + e;
+            uint8_t v;
+            if (h == oh) {
+                v = tp[0];
+            } else if (cnt <= 3) {
+                const int ss = (1 << (PRECISION_BITS - 1)) + (int)tp[0] * k0 + (int)tp[p1] * k1 + (int)tp[p2] * k2;
+                v = clip8(ss);
+            } else {
+                int ss = 1 << (PRECISION_BITS - 1);
+                for (int yy = 0; yy < cnt; ++yy) ss += (int)tp[(size_t)yy * tmp_pitch] * k[yy];
+                v = clip8(ss);
+            }
+            const float f = lut_s[e_lut[j] + v];
+            if (nhwc) drow_nhwc[e] = f;
+            else dst[(((size_t)img * 3 + (e_lut[j] >> 8)) * oh + y) * ow + e_dst[j]] = f;
+            if (urow) urow[e] = v;
         }
-        const float f = lut_s[c * 256 + v];
-        if (nhwc) dst[(((size_t)img * oh + y) * ow + ox) * 3 + c] = f;
-        else dst[(((size_t)img * 3 + c) * oh + y) * ow + ox] = f;
-        if (u8_out) u8_out[(((size_t)img * oh + y) * ow + ox) * 3 + c] = v;
     }
 }
 
@@ -280,12 +325,22 @@ extern "C" int tise_resize_bilinear_u8(const uint8_t* src_dev, int n, int h, int
     rc = get_lut(lut, &lut_dev);
     if (rc != TISE_OK) return rc;
     const size_t lds = 3 * 256 * 4 + (size_t)p.span * (((w * 3 + 15) & ~15) + ((ow * 3 + 3) & ~3));
-    if (lds > 48 * 1024)
-        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_bilinear_u8_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(resize_bilinear_u8_kernel, dim3(p.ntiles, n), dim3(256), lds, st, src_dev, h, w, dst_dev, oh, ow,
-                       nhwc, p.dev, p.ksx, p.ksy, p.off_kx, p.off_by, p.off_ky, p.off_t0, p.rt, p.span, lut_dev,
-                       u8_out_dev);
+    if (ow * 3 > 256 * RS_MAXE) return TISE_ERR_UNSUPPORTED;
+    if (p.ksx <= 3) {
+        if (lds > 48 * 1024)
+            TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_bilinear_u8_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(resize_bilinear_u8_kernel<true>, dim3(p.ntiles, n), dim3(256), lds, st, src_dev, h, w, dst_dev,
+                           oh, ow, nhwc, p.dev, p.ksx, p.ksy, p.off_kx, p.off_by, p.off_ky, p.off_t0, p.rt, p.span,
+                           lut_dev, u8_out_dev);
+    } else {
+        if (lds > 48 * 1024)
+            TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(resize_bilinear_u8_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(resize_bilinear_u8_kernel<false>, dim3(p.ntiles, n), dim3(256), lds, st, src_dev, h, w, dst_dev,
+                           oh, ow, nhwc, p.dev, p.ksx, p.ksy, p.off_kx, p.off_by, p.off_ky, p.off_t0, p.rt, p.span,
+                           lut_dev, u8_out_dev);
+    }
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }

@@ -27,7 +27,7 @@ def main():
              "| kernel | calls | total ms | avg us | min us | max us |", "|---|---:|---:|---:|---:|---:|"]
     for r in rows:
         if any(k in r["Name"] for k in MINE):
-            name = r["Name"].split("(")[0].replace("(anonymous namespace)::", "")
+            name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0]
             lines.append(f"| {name} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | "
                          f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} |")
     tr = []
@@ -48,7 +48,7 @@ def main():
             elif n.startswith("igemm"):
                 key = "MIOpen: igemm_fwd_gtcx35_nhwc_fp32 asm conv"
             else:
-                key = n.split("(")[0].replace("(anonymous namespace)::", "")[:80]
+                key = n.replace("(anonymous namespace)::", "").split("(")[0][:80]
             agg[key] += (e - s) / 1e6
             cnt[key] += 1
         lines += ["", f"## steady state: last {K} steps of the timed loop", "",
