@@ -210,7 +210,7 @@ def main():
         syrk_flop = 2.0 * B * 64 * 64 * (tiles * (tiles + 1) // 2)         # upper 64x64 tiles only, per launch
         resize_bytes = B * (256 * 256 * 3 + 299 * 299 * 3 * 4)
         kern = {
-            "syrk_f32_upper_kernel": {"bound": "mfma", "achieved": syrk_flop / (syrk_ms * 1e-3) / 1e12,
+            "syrk_f32_upper_bk64_kernel": {"bound": "mfma", "achieved": syrk_flop / (syrk_ms * 1e-3) / 1e12,
                                       "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "avg_ms": syrk_ms,
                                       "algorithmic_flop_per_launch": syrk_flop},
             "resize_bilinear_u8_kernel": {"bound": "hbm", "achieved": resize_bytes / (resize_ms * 1e-3) / 1e9,

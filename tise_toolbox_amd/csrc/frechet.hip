@@ -38,8 +38,8 @@
 #include "gemm_tile.h"
 
 #define PCHOL_NP 8          // k-chunks of the left-looking matvec
-#define SY_RC 64            // rows per row-chunk of the fused sytrd update/matvec
-#define SY_CC 256           // columns per workgroup
+#define SY_RC 256           // rows per row-chunk of the fused sytrd update/matvec (4 phases x 64 rows)
+#define SY_CC 64            // columns per workgroup
 
 struct FrState {
     int piv;        // next pivot (pchol)
@@ -320,45 +320,55 @@ __global__ __launch_bounds__(1024) void sytrd_step_kernel(const double* __restri
     }
 }
 
-// Fused trailing update + next matvec.  Thread = one column c; a workgroup covers SY_RC rows x SY_CC cols.
+// Fused trailing update + next matvec.  256 threads = 64 columns x 4 row phases; a workgroup covers a
+// SY_RC x SY_CC tile with a FIXED tile -> blockIdx map, so a tile is revisited by the same XCD every step and
+// stays in that XCD's L2 (the whole matrix is 33.5 MB against 32 MB of aggregate L2).
 //   rows/cols >= k+1:  A[j][c] -= vprev[j] w[c] + w[j] vprev[c]      (reflector k-1; skipped for k == 0)
 //   partial[rc][c] = sum_{j in chunk rc, j >= k+1} A[j][c] * vcur[j]  (matvec for reflector k)
-__global__ __launch_bounds__(SY_CC) void sytrd_update_matvec_kernel(double* __restrict__ A, int n, int k,
-                                                                    const double* __restrict__ vprev,
-                                                                    const double* __restrict__ w,
-                                                                    const double* __restrict__ vcur,
-                                                                    double* __restrict__ partial) {
+// Lanes run along a row (coalesced 512-B segments); by symmetry the column sums this produces are the
+// matrix-vector product, so no cross-lane reduction is needed.
+__global__ __launch_bounds__(256) void sytrd_update_matvec_kernel(double* __restrict__ A, int n, int k,
+                                                                  const double* __restrict__ vprev,
+                                                                  const double* __restrict__ w,
+                                                                  const double* __restrict__ vcur,
+                                                                  double* __restrict__ partial) {
     const int rc = blockIdx.y;
-    const int j0 = max(rc * SY_RC, k + 1);
-    const int j1 = min(rc * SY_RC + SY_RC, n);
+    const int r0 = rc * SY_RC;
     const int cbase = blockIdx.x * SY_CC;
-    if (j1 <= j0 || cbase + SY_CC <= k + 1) return;   // dead tile
+    if (min(r0 + SY_RC, n) <= k + 1 || cbase + SY_CC <= k + 1) return;   // dead tile
     __shared__ double s_vp[SY_RC], s_w[SY_RC], s_vc[SY_RC];
-    if (threadIdx.x < SY_RC) {
-        const int j = rc * SY_RC + threadIdx.x;
-        const bool ok = j < n;
+    __shared__ double s_part[4][SY_CC];
+    {
+        const int j = r0 + threadIdx.x;
+        const bool ok = j < n && j >= k + 1;
         s_vp[threadIdx.x] = (ok && k > 0) ? vprev[j] : 0.0;
         s_w[threadIdx.x] = (ok && k > 0) ? w[j] : 0.0;
         s_vc[threadIdx.x] = ok ? vcur[j] : 0.0;
     }
     __syncthreads();
-    const int c = cbase + threadIdx.x;
-    if (c >= n || c < k + 1) return;
-    const double vpc = k > 0 ? vprev[c] : 0.0;
-    const double wc = k > 0 ? w[c] : 0.0;
+    const int lc = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = cbase + lc;
+    const bool live = c < n && c >= k + 1;
+    const int j0 = max(r0 + ph * 64, k + 1);
+    const int j1 = min(r0 + ph * 64 + 64, n);
     double acc = 0.0;
-    if (k > 0) {
-        for (int j = j0; j < j1; ++j) {
-            const int jj = j - rc * SY_RC;
-            double a = A[(int64_t)j * n + c];
-            a -= __dadd_rn(__dmul_rn(s_vp[jj], wc), __dmul_rn(s_w[jj], vpc));
-            A[(int64_t)j * n + c] = a;
-            acc += a * s_vc[jj];
+    if (live) {
+        if (k > 0) {
+            const double vpc = vprev[c], wc = w[c];
+            for (int j = j0; j < j1; ++j) {
+                const int jj = j - r0;
+                double a = A[(int64_t)j * n + c];
+                a -= __dadd_rn(__dmul_rn(s_vp[jj], wc), __dmul_rn(s_w[jj], vpc));
+                A[(int64_t)j * n + c] = a;
+                acc += a * s_vc[jj];
+            }
+        } else {
+            for (int j = j0; j < j1; ++j) acc += A[(int64_t)j * n + c] * s_vc[j - r0];
         }
-    } else {
-        for (int j = j0; j < j1; ++j) acc += A[(int64_t)j * n + c] * s_vc[j - rc * SY_RC];
     }
-    partial[(int64_t)rc * n + c] = acc;
+    s_part[ph][lc] = acc;
+    __syncthreads();
+    if (ph == 0 && live) partial[(int64_t)rc * n + c] = ((s_part[0][lc] + s_part[1][lc]) + s_part[2][lc]) + s_part[3][lc];
 }
 
 __global__ void sytrd_last_kernel(const double* __restrict__ A, int n, double* __restrict__ td) {
@@ -409,23 +419,40 @@ __device__ __forceinline__ int sturm_count(const double* __restrict__ td, const 
     return cnt;
 }
 
-__global__ __launch_bounds__(64) void bisect_kernel(const double* __restrict__ td, const double* __restrict__ te, int n,
-                                                    const FrState* __restrict__ st, double* __restrict__ eig) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per eigenvalue, 64-way multisection: every lane evaluates the Sturm count at its own shift
+// inside the current bracket, a ballot picks the sub-interval that contains the m-th eigenvalue.  6 bits per
+// pass instead of 1 => ~9 passes over the tridiagonal recurrence instead of ~55, and n waves instead of n
+// threads keep every CU busy.  td/te are read at wave-uniform addresses (scalar loads).
+__global__ __launch_bounds__(256) void bisect_kernel(const double* __restrict__ td, const double* __restrict__ te, int n,
+                                                     const FrState* __restrict__ st, double* __restrict__ eig) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= n) return;
     double lo = st->glo, hi = st->ghi;
     const double pivmin = st->pivmin;
     // absolute accuracy eps * ||T|| is all the trace of the square root needs (and all that the
-    // tridiagonalisation preserved): ~55 halvings of the Gershgorin interval, no more.
+    // tridiagonalisation preserved)
     const double tol = 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin;
-    for (int it = 0; it < 200; ++it) {
-        const double mid = 0.5 * (lo + hi);
-        if (!(mid > lo) || !(mid < hi)) break;
-        if (hi - lo <= tol) break;
-        const int cnt = sturm_count(td, te, n, mid, pivmin);
-        if (cnt >= m + 1) hi = mid; else lo = mid;
+    for (int it = 0; it < 40; ++it) {
+        const double width = hi - lo;
+        if (!(width > tol)) break;
+        const double x = lo + width * ((double)(lane + 1) * (1.0 / 65.0));
+        const int cnt = sturm_count(td, te, n, x, pivmin);
+        const unsigned long long mask = __ballot(cnt >= m + 1);     // monotone in the lane index
+        double nlo, nhi;
+        if (mask == 0ull) {                      // eigenvalue above every probe
+            nlo = __shfl(x, 63, 64);
+            nhi = hi;
+        } else {
+            const int first = __ffsll((long long)mask) - 1;
+            nhi = __shfl(x, first, 64);
+            nlo = first > 0 ? __shfl(x, first - 1, 64) : lo;
+        }
+        if (!(nhi - nlo < width)) break;         // no progress at the resolution of the doubles
+        lo = nlo;
+        hi = nhi;
     }
-    eig[m] = 0.5 * (lo + hi);
+    if (lane == 0) eig[m] = 0.5 * (lo + hi);
 }
 
 // ------------------------------------------------------------------ final combination
@@ -499,20 +526,20 @@ int run_eigvalsh_inplace(tise_frechet* h, int n, hipStream_t st) {
         TISE_HIP_CHECK(hipMemcpyAsync(h->eig, A, sizeof(double), hipMemcpyDeviceToDevice, st));
         return TISE_OK;
     }
-    const dim3 ugrid(ceil_div(n, SY_CC), ceil_div(n, SY_RC));
+    const dim3 ugrid(ceil_div(n, SY_CC), ceil_div(n, SY_RC));   // 32 x 8 = 256 workgroups at n = 2048
     double* vprev = h->va;
     double* vcur = h->vb;
     for (int k = 0; k <= n - 2; ++k) {
         hipLaunchKernelGGL(sytrd_step_kernel, dim3(1), dim3(1024), 0, st, A, n, k, h->partial, vprev, h->w, vcur, h->td,
                            h->te, h->st);
-        hipLaunchKernelGGL(sytrd_update_matvec_kernel, ugrid, dim3(SY_CC), 0, st, A, n, k, vprev, h->w, vcur, h->partial);
+        hipLaunchKernelGGL(sytrd_update_matvec_kernel, ugrid, dim3(256), 0, st, A, n, k, vprev, h->w, vcur, h->partial);
         double* t = vprev; vprev = vcur; vcur = t;
     }
     TISE_LAUNCH_CHECK();
     hipLaunchKernelGGL(sytrd_last_kernel, dim3(1), dim3(64), 0, st, A, n, h->td);
     if (h->profiling) TISE_HIP_CHECK(hipEventRecord(h->ev[3], st));
     hipLaunchKernelGGL(gershgorin_kernel, dim3(1), dim3(1024), 0, st, h->td, h->te, n, h->st);
-    hipLaunchKernelGGL(bisect_kernel, dim3(ceil_div(n, 64)), dim3(64), 0, st, h->td, h->te, n, h->st, h->eig);
+    hipLaunchKernelGGL(bisect_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, st, h->td, h->te, n, h->st, h->eig);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
