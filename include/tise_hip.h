@@ -167,6 +167,39 @@ int tise_maxpool3s2_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int
                          const float* bias_dev, float* out_dev, int64_t out_ld, int out_off, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * (a5, convolution) Implicit-GEMM convolution on fp16 MFMA with 3-term split-precision operands.
+ * Replaces the Conv2d + BatchNorm(eval) + ReLU of torchvision's BasicConv2d for NHWC tensors held as
+ * two fp16 planes (v ~= hi + lo * 2^-11): D = max(scale * conv(x, w) + bias, 0), re-split and written
+ * into up to four destination channel slices (mode 0), or raw fp32 scale*conv (mode 1, pool branch).
+ * `args` points to a host-side tise_conv_args (copied into the launch).  tn in {2,3,4,5}: the output
+ * tile is 128 pixels x 32*tn channels; weights must be padded to a multiple of 32*tn rows and of 32 in K.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int c0, c1;             /* output-channel range [c0, c1) of this segment                           */
+    void* dst;              /* mode 0: fp16 hi plane (lo plane at dst + plane elements); mode 1: float* */
+    long long ld;           /* destination elements per pixel                                          */
+    long long plane;        /* elements between the hi and lo planes (mode 0)                          */
+    int off;                /* first destination channel                                               */
+    int mode;
+} tise_conv_seg;
+
+typedef struct {
+    const void* x;          /* fp16 [2][N][H][W][Cin]                                                  */
+    long long x_plane;
+    const void* w;          /* fp16 [2][Cout_pad][Kpad], K = (kh, kw, cin) with cin fastest            */
+    long long w_plane;
+    const float* scale;     /* [Cout_pad] un-scaling of the (power-of-two pre-scaled) weights          */
+    const float* bias;      /* [Cout_pad]                                                              */
+    int N, H, W, Cin, KH, KW, SH, SW, PH, PW, OH, OW;
+    int Cout, K, Kpad;
+    long long M;            /* N*OH*OW                                                                 */
+    int nseg;
+    tise_conv_seg seg[4];
+} tise_conv_args;
+
+int tise_conv_split_f16(const tise_conv_args* args, int tn, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * fp64 GEMM building block (MFMA v_mfma_f64_16x16x4_f64), exported for tests/bench only:
  * C[m][n] (ldc) = sum_k A(m,k) * B(k,n) with A(m,k) = a[m*sam + k*sak], B(k,n) = b[k*sbk + n*sbn].
  * ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,117 @@
+"""Host side of the split-precision fp16-MFMA convolution (csrc/conv_split.hip).
+
+A value v is carried as two fp16 numbers, v ~= hi + lo * 2**-11.  ``split`` / ``merge`` convert between
+fp32 tensors and (2, ...) fp16 plane pairs; ``SplitConv`` packs BatchNorm-folded conv weights once
+(power-of-two per-channel scaling so the fp16 halves stay normal, K = (kh, kw, cin) with cin fastest,
+zero padding to the kernel's tile multiples) and launches ``tise_conv_split_f16``.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+LO_SCALE = 2048.0   # 2**11
+
+
+class ConvSeg(ctypes.Structure):
+    _fields_ = [("c0", ctypes.c_int), ("c1", ctypes.c_int), ("dst", ctypes.c_void_p), ("ld", ctypes.c_longlong),
+                ("plane", ctypes.c_longlong), ("off", ctypes.c_int), ("mode", ctypes.c_int)]
+
+
+class ConvArgs(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("x_plane", ctypes.c_longlong), ("w", ctypes.c_void_p),
+                ("w_plane", ctypes.c_longlong), ("scale", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cin", ctypes.c_int),
+                ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("SH", ctypes.c_int), ("SW", ctypes.c_int),
+                ("PH", ctypes.c_int), ("PW", ctypes.c_int), ("OH", ctypes.c_int), ("OW", ctypes.c_int),
+                ("Cout", ctypes.c_int), ("K", ctypes.c_int), ("Kpad", ctypes.c_int), ("M", ctypes.c_longlong),
+                ("nseg", ctypes.c_int), ("seg", ConvSeg * 4)]
+
+
+def split(x):
+    """fp32 tensor -> (2, *x.shape) fp16: plane 0 = hi, plane 1 = (x - hi) * 2**11."""
+    hi = x.half()
+    lo = ((x - hi.float()) * LO_SCALE).half()
+    return torch.stack([hi, lo], 0)
+
+
+def merge(planes):
+    return planes[0].float() + planes[1].float() * (1.0 / LO_SCALE)
+
+
+def pick_tn(cout):
+    """Tile width 32*tn (tn in 2..5) that wastes the fewest padded output channels; ties -> wider."""
+    best = None
+    for tn in (5, 4, 3, 2):
+        bn = 32 * tn
+        padded = -(-cout // bn) * bn
+        key = (padded, -tn)
+        if best is None or key < best[0]:
+            best = (key, tn)
+    return best[1]
+
+
+class SplitConv:
+    """One (possibly channel-concatenated) convolution with folded scale/bias, packed for the kernel."""
+
+    def __init__(self, weight, bias, stride, padding, device, tn=None):
+        """weight: (Cout, Cin, KH, KW) fp32 (BatchNorm already folded), bias: (Cout,) fp32."""
+        cout, cin, kh, kw = weight.shape
+        assert cin % 16 == 0 and cin >= 32, "conv_split needs Cin % 16 == 0 and Cin >= 32"
+        self.cout, self.cin, self.kh, self.kw = cout, cin, kh, kw
+        self.stride = tuple(stride)
+        self.padding = tuple(padding)
+        self.tn = tn or pick_tn(cout)
+        bn = 32 * self.tn
+        self.cout_pad = -(-cout // bn) * bn
+        self.k = kh * kw * cin
+        self.kpad = -(-self.k // 32) * 32
+        w = weight.detach().float().cpu()
+        amax = w.abs().reshape(cout, -1).amax(1).clamp_min(1e-30)
+        pre = torch.exp2(-torch.floor(torch.log2(amax)))            # exact powers of two: max |w * pre| in [1, 2)
+        wk = (w * pre.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(cout, self.k)
+        wp = torch.zeros((self.cout_pad, self.kpad), dtype=torch.float32)
+        wp[:cout, :self.k] = wk
+        self.w = split(wp).to(device).contiguous()                  # (2, Cout_pad, Kpad) fp16
+        sc = torch.zeros(self.cout_pad, dtype=torch.float32)
+        sc[:cout] = 1.0 / pre
+        bs = torch.zeros(self.cout_pad, dtype=torch.float32)
+        bs[:cout] = bias.detach().float().cpu()
+        self.scale = sc.to(device)
+        self.bias = bs.to(device)
+
+    def out_hw(self, h, w):
+        oh = (h + 2 * self.padding[0] - self.kh) // self.stride[0] + 1
+        ow = (w + 2 * self.padding[1] - self.kw) // self.stride[1] + 1
+        return oh, ow
+
+    def __call__(self, x, segs):
+        """x: (2, N, H, W, Cin) fp16 planes.  segs: list of (c0, c1, dst_tensor, dst_off, mode):
+        mode 0 -> dst is a (2, N, OH, OW, C) fp16 plane pair, mode 1 -> dst is a (N, OH, OW, C) fp32 tensor."""
+        assert x.dtype == torch.float16 and x.dim() == 5 and x.shape[4] == self.cin and x.is_contiguous()
+        _, n, h, w, _ = x.shape
+        oh, ow = self.out_hw(h, w)
+        a = ConvArgs()
+        a.x = x.data_ptr(); a.x_plane = x.stride(0)
+        a.w = self.w.data_ptr(); a.w_plane = self.w.stride(0)
+        a.scale = self.scale.data_ptr(); a.bias = self.bias.data_ptr()
+        a.N, a.H, a.W, a.Cin = n, h, w, self.cin
+        a.KH, a.KW, a.SH, a.SW, a.PH, a.PW = self.kh, self.kw, self.stride[0], self.stride[1], self.padding[0], self.padding[1]
+        a.OH, a.OW = oh, ow
+        a.Cout, a.K, a.Kpad = self.cout, self.k, self.kpad
+        a.M = n * oh * ow
+        a.nseg = len(segs)
+        for i, (c0, c1, dst, off, mode) in enumerate(segs):
+            s = a.seg[i]
+            s.c0, s.c1, s.off, s.mode = c0, c1, off, mode
+            s.dst = dst.data_ptr()
+            if mode == 0:
+                assert dst.dtype == torch.float16 and dst.shape[1:4] == (n, oh, ow) and dst.is_contiguous()
+                s.ld, s.plane = dst.shape[4], dst.stride(0)
+            else:
+                assert dst.dtype == torch.float32 and dst.shape[:3] == (n, oh, ow) and dst.is_contiguous()
+                s.ld, s.plane = dst.shape[3], 0
+        _lib.call("tise_conv_split_f16", ctypes.byref(a), self.tn,
+                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return oh, ow
