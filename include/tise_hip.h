@@ -166,6 +166,18 @@ int tise_avgpool3_bias_relu_nhwc(const float* x_dev, int64_t x_ld, int x_off, in
 int tise_maxpool3s2_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
                          const float* bias_dev, float* out_dev, int64_t out_ld, int out_off, void* stream);
 
+/* Split-fp16 variants of the epilogues (activations as two fp16 planes, v ~= hi + lo * 2^-11, the
+ * format tise_conv_split_f16 consumes and produces): out_dev is the hi plane, the lo plane follows
+ * out_plane elements later; x of the max pool is such a plane pair too. */
+int tise_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_off, int64_t pixels, int C,
+                              const float* bias_dev, void* out_dev, int64_t out_ld, int out_off,
+                              int64_t out_plane, void* stream);
+int tise_avgpool3_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
+                                       const float* bias_dev, void* out_dev, int64_t out_ld, int out_off,
+                                       int64_t out_plane, void* stream);
+int tise_maxpool3s2_split_nhwc(const void* x_dev, int64_t x_ld, int x_off, int64_t x_plane, int n, int h, int w,
+                               int C, void* out_dev, int64_t out_ld, int out_off, int64_t out_plane, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * (a5, convolution) Implicit-GEMM convolution on fp16 MFMA with 3-term split-precision operands.
  * Replaces the Conv2d + BatchNorm(eval) + ReLU of torchvision's BasicConv2d for NHWC tensors held as

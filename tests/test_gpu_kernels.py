@@ -345,3 +345,66 @@ def test_fused_trunk_matches_module_graph(dev, dims):
     assert got.shape == want.shape
     err = (got - want).abs().max().item()
     assert err <= 2e-4 * want.abs().max().item(), err
+
+
+# ------------------------------------------------------------------------------------------- split-precision conv
+@pytest.mark.parametrize("shape", [(17, 17, 160, 160, 1, 7, 1, (0, 3)), (35, 35, 48, 64, 5, 5, 1, (2, 2)),
+                                   (35, 35, 288, 384, 3, 3, 2, (0, 0)), (9, 9, 80, 192, 3, 3, 1, (0, 0)),
+                                   (8, 8, 320, 1344, 1, 1, 1, (0, 0)), (11, 7, 32, 48, 3, 3, 1, (1, 1))])
+def test_conv_split_matches_fp64_conv(dev, shape):
+    """3-term split fp16 MFMA conv vs an fp64 convolution: fp32-class accuracy (|err| <= 4e-6 of the
+    output scale), including M/N/K tails, padding, stride, channel counts with Cin % 32 == 16."""
+    from tise_toolbox_amd.conv_split import SplitConv, merge, split
+    H, W, Cin, Cout, kh, kw, st, pad = shape
+    g = torch.Generator(device="cpu").manual_seed(Cin + Cout)
+    n = 5
+    x = (torch.rand((n, H, W, Cin), generator=g) * 3.0).to(dev)
+    w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+    conv = SplitConv(w, b, (st, st), pad, dev)
+    oh, ow = conv.out_hw(H, W)
+    out = torch.zeros((2, n, oh, ow, Cout + 32), dtype=torch.float16, device=dev)
+    raw = torch.zeros((n, oh, ow, 16), dtype=torch.float32, device=dev)
+    # three destinations: a shifted slice of a wider tensor, a raw fp32 slice, the rest
+    conv(split(x), [(0, 16, out, 16, 0), (16, 32, raw, 0, 1), (32, Cout, out, 64, 0)])
+    ref_lin = torch.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, st, pad).permute(0, 2, 3, 1)
+    ref = torch.relu(ref_lin + b.double())
+    scale = ref.abs().max().item()
+    got = merge(out)
+    assert (got[..., 16:32].double() - ref[..., 0:16]).abs().max().item() <= 4e-6 * scale
+    assert (got[..., 64:].double() - ref[..., 32:]).abs().max().item() <= 4e-6 * scale
+    assert (raw.double() - ref_lin[..., 16:32]).abs().max().item() <= 4e-6 * scale
+    assert got[..., :16].abs().max().item() == 0 and got[..., 32:64].abs().max().item() == 0     # untouched
+
+
+def test_split_pool_ops(dev):
+    import torch.nn.functional as F
+    from tise_toolbox_amd.conv_split import merge, split
+    from tise_toolbox_amd.trunk import SplitTrunk
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = (torch.rand((2, 13, 9, 48), generator=g) * 5).to(dev)
+    xs = split(x)
+    assert (merge(xs) - x).abs().max().item() <= 2 ** -21 * 5            # 22-bit representation
+    got = SplitTrunk._maxpool_split(xs)
+    want = F.max_pool2d(merge(xs).permute(0, 3, 1, 2), 3, 2).permute(0, 2, 3, 1)
+    assert torch.equal(merge(got), want.contiguous())
+    raw = torch.randn((2, 9, 11, 32), generator=g).to(dev)
+    bias = torch.randn(32, generator=g).to(dev)
+    out = torch.zeros((2, 2, 9, 11, 64), dtype=torch.float16, device=dev)
+    SplitTrunk._avgpool_split(raw, bias, out, 16)
+    want = torch.relu(F.avg_pool2d(raw.permute(0, 3, 1, 2), 3, 1, 1) + bias.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    assert (merge(out)[..., 16:48] - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+
+
+def test_split_trunk_matches_module_graph(dev):
+    from tise_toolbox_amd.inception import InceptionV3
+    from tise_toolbox_amd.trunk import SplitTrunk
+    torch.backends.cudnn.benchmark = False
+    m = InceptionV3([3], seed=0).to(dev).eval()
+    x = torch.rand((6, 3, 299, 299), device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        want = m(x, prenormalized=True)[0]
+        got = SplitTrunk(m, dev)(x)
+    assert got.shape == want.shape
+    err = (got - want).abs().max().item()
+    assert err <= 2e-4 * want.abs().max().item(), err

@@ -62,6 +62,12 @@ SIGNATURES = {
                                               c_int64, c_int, c_void_p]),
     "tise_maxpool3s2_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64,
                                       c_int, c_void_p]),
+    "tise_bias_relu_split_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int,
+                                           c_int64, c_void_p]),
+    "tise_avgpool3_bias_relu_split_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                                    c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "tise_maxpool3s2_split_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p,
+                                            c_int64, c_int, c_int64, c_void_p]),
     "tise_conv_split_f16": (c_int, [c_void_p, c_int, c_void_p]),
     "tise_gemm_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                c_int, c_int, c_int, c_void_p]),

@@ -40,15 +40,20 @@ def merge(planes):
     return planes[0].float() + planes[1].float() * (1.0 / LO_SCALE)
 
 
+# relative efficiency of the kernel by tile width (tools/conv_split_probe.py): narrow tiles re-read the
+# pixel operand more often per MFMA
+_TN_EFF = {2: 0.78, 3: 0.90, 4: 1.0, 5: 1.0}
+
+
 def pick_tn(cout):
-    """Tile width 32*tn (tn in 2..5) that wastes the fewest padded output channels; ties -> wider."""
+    """Tile width 32*tn (tn in 2..5): least padded work weighted by the measured tile efficiency."""
     best = None
     for tn in (5, 4, 3, 2):
         bn = 32 * tn
         padded = -(-cout // bn) * bn
-        key = (padded, -tn)
-        if best is None or key < best[0]:
-            best = (key, tn)
+        cost = padded / _TN_EFF[tn]
+        if best is None or cost < best[0]:
+            best = (cost, tn)
     return best[1]
 
 

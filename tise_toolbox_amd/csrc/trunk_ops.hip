@@ -101,6 +101,106 @@ __global__ __launch_bounds__(256) void maxpool3s2_nhwc_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-fp16 variants (activations held as two fp16 planes, v ~= hi + lo * 2^-11; conv_split.hip).
+typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_store4(float4 v, _Float16* hi_p, _Float16* lo_p) {
+    half4v h, l;
+    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+    l[0] = (_Float16)((v.x - (float)h[0]) * 2048.f); l[1] = (_Float16)((v.y - (float)h[1]) * 2048.f);
+    l[2] = (_Float16)((v.z - (float)h[2]) * 2048.f); l[3] = (_Float16)((v.w - (float)h[3]) * 2048.f);
+    *reinterpret_cast<half4v*>(hi_p) = h;
+    *reinterpret_cast<half4v*>(lo_p) = l;
+}
+
+// fp32 raw conv output (slice) -> max(x + b, 0) -> split planes (stem, after the MIOpen Cin=3 conv)
+__global__ __launch_bounds__(256) void bias_relu_split_kernel(const float* __restrict__ x, int64_t x_ld, int x_off,
+                                                              int64_t pixels, int C4, const float* __restrict__ bias,
+                                                              _Float16* __restrict__ out, int64_t out_ld, int out_off,
+                                                              int64_t out_plane) {
+    const int64_t total = pixels * C4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = e / C4;
+        const int c4 = (int)(e - p * C4);
+        const float4 v = f4_bias_relu(*reinterpret_cast<const float4*>(x + p * x_ld + x_off + 4 * c4),
+                                      *reinterpret_cast<const float4*>(bias + 4 * c4));
+        _Float16* d = out + p * out_ld + out_off + 4 * c4;
+        split_store4(v, d, d + out_plane);
+    }
+}
+
+// fp32 raw 1x1-conv output (slice) -> 3x3/s1/p1 average (count_include_pad) + bias, ReLU -> split planes
+__global__ __launch_bounds__(256) void avgpool3_bias_relu_split_kernel(const float* __restrict__ x, int64_t x_ld,
+                                                                       int x_off, int N, int H, int W, int C4,
+                                                                       const float* __restrict__ bias,
+                                                                       _Float16* __restrict__ out, int64_t out_ld,
+                                                                       int out_off, int64_t out_plane) {
+    const int64_t total = (int64_t)N * H * W * C4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = e / C4;
+        const int c4 = (int)(e - p * C4);
+        const int w = (int)(p % W);
+        const int h = (int)((p / W) % H);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int dh = -1; dh <= 1; ++dh) {
+            const int hh = h + dh;
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int dw = -1; dw <= 1; ++dw) {
+                const int ww = w + dw;
+                if (ww < 0 || ww >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + (p + (int64_t)dh * W + dw) * x_ld + x_off + 4 * c4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        }
+        s.x /= 9.f; s.y /= 9.f; s.z /= 9.f; s.w /= 9.f;
+        const float4 v = f4_bias_relu(s, *reinterpret_cast<const float4*>(bias + 4 * c4));
+        _Float16* d = out + p * out_ld + out_off + 4 * c4;
+        split_store4(v, d, d + out_plane);
+    }
+}
+
+// split planes -> 3x3 / stride 2 max pool -> split planes (8 channels = 16 B per thread).  The value
+// hi + lo*2^-11 is exact in fp32, so the maximum is taken on it and its (hi, lo) pair is passed through.
+__global__ __launch_bounds__(256) void maxpool3s2_split_kernel(const _Float16* __restrict__ x, int64_t x_ld, int x_off,
+                                                               int64_t x_plane, int N, int H, int W, int C8,
+                                                               _Float16* __restrict__ out, int64_t out_ld, int out_off,
+                                                               int64_t out_plane) {
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * OH * OW * C8;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = e / C8;
+        const int c8 = (int)(e - p * C8);
+        const int ow = (int)(p % OW);
+        const int oh = (int)((p / OW) % OH);
+        const int64_t n = p / ((int64_t)OW * OH);
+        const int64_t base = (n * H + 2 * oh) * W + 2 * ow;
+        half8v bh, bl;
+        float bv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bv[i] = -INFINITY;
+#pragma unroll
+        for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 3; ++dw) {
+                const _Float16* q = x + (base + (int64_t)dh * W + dw) * x_ld + x_off + 8 * c8;
+                const half8v vh = *reinterpret_cast<const half8v*>(q);
+                const half8v vl = *reinterpret_cast<const half8v*>(q + x_plane);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float v = (float)vh[i] + (float)vl[i] * (1.f / 2048.f);
+                    if (v > bv[i]) { bv[i] = v; bh[i] = vh[i]; bl[i] = vl[i]; }
+                }
+            }
+        _Float16* d = out + p * out_ld + out_off + 8 * c8;
+        *reinterpret_cast<half8v*>(d) = bh;
+        *reinterpret_cast<half8v*>(d + out_plane) = bl;
+    }
+}
+
 inline int grid_for(int64_t total) {
     int64_t b = (total + 255) / 256;
     if (b > 16384) b = 16384;
@@ -152,6 +252,47 @@ int tise_maxpool3s2_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int
     else
         hipLaunchKernelGGL(maxpool3s2_nhwc_kernel<false>, dim3(g), dim3(256), 0, (hipStream_t)stream, x_dev, x_ld, x_off,
                            n, h, w, C / 4, bias_dev, out_dev, out_ld, out_off);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+int tise_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_off, int64_t pixels, int C, const float* bias_dev,
+                              void* out_dev, int64_t out_ld, int out_off, int64_t out_plane, void* stream) {
+    if (!x_dev || !bias_dev || !out_dev || pixels < 0 || C <= 0 || !aligned4(x_ld, x_off, C) ||
+        !aligned4(out_ld, out_off, C) || x_off + C > x_ld || out_off + C > out_ld)
+        return TISE_ERR_INVALID_ARG;
+    if (pixels == 0) return TISE_OK;
+    hipLaunchKernelGGL(bias_relu_split_kernel, dim3(grid_for(pixels * (C / 4))), dim3(256), 0, (hipStream_t)stream, x_dev,
+                       x_ld, x_off, pixels, C / 4, bias_dev, reinterpret_cast<_Float16*>(out_dev), out_ld, out_off,
+                       out_plane);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+int tise_avgpool3_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
+                                       const float* bias_dev, void* out_dev, int64_t out_ld, int out_off,
+                                       int64_t out_plane, void* stream) {
+    if (!x_dev || !bias_dev || !out_dev || n < 0 || h <= 0 || w <= 0 || C <= 0 || !aligned4(x_ld, x_off, C) ||
+        !aligned4(out_ld, out_off, C) || x_off + C > x_ld || out_off + C > out_ld)
+        return TISE_ERR_INVALID_ARG;
+    if (n == 0) return TISE_OK;
+    hipLaunchKernelGGL(avgpool3_bias_relu_split_kernel, dim3(grid_for((int64_t)n * h * w * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, x_dev, x_ld, x_off, n, h, w, C / 4, bias_dev,
+                       reinterpret_cast<_Float16*>(out_dev), out_ld, out_off, out_plane);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+int tise_maxpool3s2_split_nhwc(const void* x_dev, int64_t x_ld, int x_off, int64_t x_plane, int n, int h, int w, int C,
+                               void* out_dev, int64_t out_ld, int out_off, int64_t out_plane, void* stream) {
+    if (!x_dev || !out_dev || n < 0 || h < 3 || w < 3 || C <= 0 || C % 8 || x_ld % 8 || x_off % 8 || out_ld % 8 ||
+        out_off % 8 || x_off + C > x_ld || out_off + C > out_ld)
+        return TISE_ERR_INVALID_ARG;
+    if (n == 0) return TISE_OK;
+    const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_split_kernel, dim3(grid_for((int64_t)n * oh * ow * (C / 8))), dim3(256), 0,
+                       (hipStream_t)stream, reinterpret_cast<const _Float16*>(x_dev), x_ld, x_off, x_plane, n, h, w, C / 8,
+                       reinterpret_cast<_Float16*>(out_dev), out_ld, out_off, out_plane);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }

@@ -235,3 +235,149 @@ class FusedTrunk:
         if self.last_block >= 3:
             a = a.mean(dim=(1, 2), keepdim=True)                               # AdaptiveAvgPool2d((1,1))
         return a.permute(0, 3, 1, 2)
+
+
+class SplitTrunk(FusedTrunk):
+    """Same graph as ``FusedTrunk`` with every convolution after the Cin=3 stem layer on the hand-written
+    split-precision fp16-MFMA kernel (``csrc/conv_split.hip``): activations travel between layers as two
+    fp16 planes (v ~= hi + lo * 2**-11, 22 mantissa bits), each conv's epilogue applies the folded
+    BatchNorm scale/bias and ReLU and writes straight into the consumer's channel slice, the pool branch
+    gets raw fp32 from the fused 1x1 conv and ``tise_avgpool3_bias_relu_split_nhwc`` finishes it.
+    Measured per layer 1.5-2.3x MIOpen's fp32 kernels at a smaller error against an fp64 reference
+    (``tools/conv_split_probe.py``).  Requires the wrapper to go to pool3 (last block 3)."""
+
+    def __init__(self, model, device):
+        super().__init__(model, device)
+        from .conv_split import SplitConv
+        assert self.last_block == 3, "SplitTrunk implements the pool3 (dims=2048) path"
+
+        def sc(c):
+            return SplitConv(c.w, c.b, c.stride, c.padding, self.device)
+
+        self.s2a, self.s2b, self.s3b, self.s4a = sc(self.c2a), sc(self.c2b), sc(self.c3b), sc(self.c4a)
+        self.sblocks = [(kind, {k: sc(v) for k, v in P.items()}) for kind, P in self.blocks]
+
+    # ---- helpers on split tensors (2, N, H, W, C) fp16 ------------------------------------------------
+    @staticmethod
+    def _new(n, h, w, c, dev):
+        return torch.empty((2, n, h, w, c), dtype=torch.float16, device=dev)
+
+    def _sconv(self, conv, x, segs=None):
+        """Run a SplitConv; with segs None the whole output goes to a fresh packed split tensor."""
+        _, n, h, w, _ = x.shape
+        oh, ow = conv.out_hw(h, w)
+        if segs is None:
+            out = self._new(n, oh, ow, conv.cout, x.device)
+            conv(x, [(0, conv.cout, out, 0, 0)])
+            return out
+        conv(x, segs)
+        return None
+
+    @staticmethod
+    def _maxpool_split(x, out=None, out_off=0):
+        _, n, h, w, c = x.shape
+        oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        if out is None:
+            out = torch.empty((2, n, oh, ow, c), dtype=torch.float16, device=x.device)
+        _lib.call("tise_maxpool3s2_split_nhwc", _p(x), c, 0, x.stride(0), n, h, w, c, _p(out), out.shape[4], out_off,
+                  out.stride(0), _stream())
+        return out
+
+    @staticmethod
+    def _avgpool_split(raw, bias, out, out_off):
+        n, h, w, c = raw.shape
+        _lib.call("tise_avgpool3_bias_relu_split_nhwc", _p(raw), c, 0, n, h, w, c, _p(bias), _p(out), out.shape[4],
+                  out_off, out.stride(0), _stream())
+
+    def _sblock_a(self, x, P):
+        _, n, h, w, _ = x.shape
+        f = P["f"]
+        pf = f.cout - 176
+        dev = x.device
+        out = self._new(n, h, w, 224 + pf, dev)
+        t5, t3 = self._new(n, h, w, 48, dev), self._new(n, h, w, 64, dev)
+        raw = torch.empty((n, h, w, pf), dtype=torch.float32, device=dev)
+        f(x, [(0, 64, out, 0, 0), (64, 112, t5, 0, 0), (112, 176, t3, 0, 0), (176, 176 + pf, raw, 0, 1)])
+        self._avgpool_split(raw, f.bias[176:176 + pf], out, 224)
+        P["c5"](t5, [(0, 64, out, 64, 0)])
+        t3 = self._sconv(P["d2"], t3)
+        P["d3"](t3, [(0, 96, out, 128, 0)])
+        return out
+
+    def _sblock_b(self, x, P):
+        _, n, h, w, cin = x.shape
+        oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        out = self._new(n, oh, ow, 384 + 96 + cin, x.device)
+        P["c3"](x, [(0, 384, out, 0, 0)])
+        t = self._sconv(P["d2"], self._sconv(P["d1"], x))
+        P["d3"](t, [(0, 96, out, 384, 0)])
+        self._maxpool_split(x, out, 480)
+        return out
+
+    def _sblock_c(self, x, P):
+        _, n, h, w, _ = x.shape
+        f = P["f"]
+        c7 = (f.cout - 384) // 2
+        dev = x.device
+        out = self._new(n, h, w, 768, dev)
+        t7, td = self._new(n, h, w, c7, dev), self._new(n, h, w, c7, dev)
+        raw = torch.empty((n, h, w, 192), dtype=torch.float32, device=dev)
+        f(x, [(0, 192, out, 0, 0), (192, 192 + c7, t7, 0, 0), (192 + c7, 192 + 2 * c7, td, 0, 0),
+              (192 + 2 * c7, 384 + 2 * c7, raw, 0, 1)])
+        self._avgpool_split(raw, f.bias[192 + 2 * c7:384 + 2 * c7], out, 576)
+        t7 = self._sconv(P["s2"], t7)
+        P["s3"](t7, [(0, 192, out, 192, 0)])
+        for k in ("d2", "d3", "d4"):
+            td = self._sconv(P[k], td)
+        P["d5"](td, [(0, 192, out, 384, 0)])
+        return out
+
+    def _sblock_d(self, x, P):
+        _, n, h, w, cin = x.shape
+        oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        dev = x.device
+        out = self._new(n, oh, ow, 320 + 192 + cin, dev)
+        t3, t7 = self._new(n, h, w, 192, dev), self._new(n, h, w, 192, dev)
+        P["f"](x, [(0, 192, t3, 0, 0), (192, 384, t7, 0, 0)])
+        P["c32"](t3, [(0, 320, out, 0, 0)])
+        for k in ("s2", "s3"):
+            t7 = self._sconv(P[k], t7)
+        P["s4"](t7, [(0, 192, out, 320, 0)])
+        self._maxpool_split(x, out, 512)
+        return out
+
+    def _sblock_e(self, x, P):
+        _, n, h, w, _ = x.shape
+        f = P["f"]
+        dev = x.device
+        out = self._new(n, h, w, 2048, dev)
+        t3, td = self._new(n, h, w, 384, dev), self._new(n, h, w, 448, dev)
+        raw = torch.empty((n, h, w, 192), dtype=torch.float32, device=dev)
+        f(x, [(0, 320, out, 0, 0), (320, 704, t3, 0, 0), (704, 1152, td, 0, 0), (1152, 1344, raw, 0, 1)])
+        self._avgpool_split(raw, f.bias[1152:1344], out, 1856)
+        P["a2"](t3, [(0, 384, out, 320, 0)])
+        P["b2"](t3, [(0, 384, out, 704, 0)])
+        td = self._sconv(P["d2"], td)
+        P["a3"](td, [(0, 384, out, 1088, 0)])
+        P["b3"](td, [(0, 384, out, 1472, 0)])
+        return out
+
+    @torch.no_grad()
+    def __call__(self, x_nchw_channels_last):
+        x = x_nchw_channels_last.permute(0, 2, 3, 1)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        raw = self._conv(x, self.c1a)                                   # Cin = 3: MIOpen fp32
+        n, h, w, c = raw.shape
+        a = self._new(n, h, w, c, raw.device)
+        _lib.call("tise_bias_relu_split_nhwc", _p(raw), c, 0, n * h * w, c, _p(self.c1a.b), _p(a), c, 0, a.stride(0),
+                  _stream())
+        a = self._sconv(self.s2a, a)
+        a = self._maxpool_split(self._sconv(self.s2b, a))
+        a = self._sconv(self.s3b, a)
+        a = self._maxpool_split(self._sconv(self.s4a, a))
+        fn = {"A": self._sblock_a, "B": self._sblock_b, "C": self._sblock_c, "D": self._sblock_d, "E": self._sblock_e}
+        for kind, P in self.sblocks:
+            a = fn[kind](a, P)
+        feat = (a[0].float() + a[1].float() * (1.0 / 2048.0)).mean(dim=(1, 2), keepdim=True)   # merge + global average
+        return feat.permute(0, 3, 1, 2)

@@ -52,14 +52,16 @@ if "trunk" in which:
 
 if "fused" in which:
     res = {}
-    for fused in (True, False):
-        eng = RealismEngine(dims=2048, seed=0, with_logits=True, channels_last=True, fused=fused)
+    for fused in ("split", "miopen", False):
+        if fused:
+            os.environ["TISE_CONV"] = fused
+        eng = RealismEngine(dims=2048, seed=0, with_logits=True, channels_last=True, fused=bool(fused))
         for bs in (500,):
             x = torch.rand((bs, 3, 299, 299), device=dev).contiguous(memory_format=torch.channels_last)
             with torch.no_grad():
                 ms = timeit(lambda: eng._trunk(x, True), iters=5, warm=3)
-            res[f"{'fused' if fused else 'module'}_b{bs}"] = {"ms": ms, "img_s": bs / ms * 1e3, "tflops": 11.42e9 * bs / ms / 1e9}
-            print("trunk fused", fused, bs, res[f"{'fused' if fused else 'module'}_b{bs}"], flush=True)
+            res[f"{fused or 'module'}_b{bs}"] = {"ms": ms, "img_s": bs / ms * 1e3, "tflops": 11.42e9 * bs / ms / 1e9}
+            print("trunk", fused, bs, res[f"{fused or 'module'}_b{bs}"], flush=True)
         del eng
         torch.cuda.empty_cache()
     out["fused"] = res
