@@ -185,6 +185,8 @@ int tise_maxpool3s2_split_nhwc(const void* x_dev, int64_t x_ld, int x_off, int64
  * into up to four destination channel slices (mode 0), or raw fp32 scale*conv (mode 1, pool branch).
  * `args` points to a host-side tise_conv_args (copied into the launch).  tn in {2,3,4,5}: the output
  * tile is 128 pixels x 32*tn channels; weights must be padded to a multiple of 32*tn rows and of 32 in K.
+ * tn | 16 selects the direct-to-LDS (global_load_lds) double-buffered variant of the same computation,
+ * tn | 32 the 8-wave, 256-pixel-tile, three-stage variant (bitwise identical results).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int c0, c1;             /* output-channel range [c0, c1) of this segment                           */

@@ -6,6 +6,7 @@ fp32 tensors and (2, ...) fp16 plane pairs; ``SplitConv`` packs BatchNorm-folded
 zero padding to the kernel's tile multiples) and launches ``tise_conv_split_f16``.
 """
 import ctypes
+import os
 
 import torch
 
@@ -68,6 +69,9 @@ class SplitConv:
         self.stride = tuple(stride)
         self.padding = tuple(padding)
         self.tn = tn or pick_tn(cout)
+        # kernel variant: "reg" register-staged (4 waves), "glds" direct-to-LDS 2-stage (4 waves),
+        # "glds3" direct-to-LDS 3-stage, 8 waves, 256-pixel tile
+        self.variant = os.environ.get("TISE_CONV_VARIANT", "glds")
         bn = 32 * self.tn
         self.cout_pad = -(-cout // bn) * bn
         self.k = kh * kw * cin
@@ -106,7 +110,7 @@ class SplitConv:
         a.OH, a.OW = oh, ow
         a.Cout, a.K, a.Kpad = self.cout, self.k, self.kpad
         a.M = n * oh * ow
-        a.nseg = len(segs)
+        a.nseg = len(segs) | getattr(self, "debug_flags", 0)
         for i, (c0, c1, dst, off, mode) in enumerate(segs):
             s = a.seg[i]
             s.c0, s.c1, s.off, s.mode = c0, c1, off, mode
@@ -117,6 +121,6 @@ class SplitConv:
             else:
                 assert dst.dtype == torch.float32 and dst.shape[:3] == (n, oh, ow) and dst.is_contiguous()
                 s.ld, s.plane = dst.shape[3], 0
-        _lib.call("tise_conv_split_f16", ctypes.byref(a), self.tn,
+        _lib.call("tise_conv_split_f16", ctypes.byref(a), self.tn | {"reg": 0, "glds": 16, "glds3": 32}[self.variant],
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         return oh, ow

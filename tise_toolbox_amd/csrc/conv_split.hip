@@ -38,6 +38,84 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // native ve
 typedef tise_conv_seg ConvSeg;
 typedef tise_conv_args ConvArgs;
 
+// Epilogue shared by both kernels (see the comment inside).  LDS_BYTES is the size of the caller's LDS array.
+template <int TN, int LDS_BYTES, int BM = CS_BM>
+__device__ __forceinline__ void conv_split_epilogue(const ConvArgs& p, float16_t (&acc_main)[TN], float16_t (&acc_corr)[TN],
+                                                    unsigned char* lds, long long m0, int n0) {
+    constexpr int BN = 32 * TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // D[row = pixel][col = cout]; a lane holds col = lane & 31 and rows (j&3) + 8*(j>>2) + 4*(lane>>5).
+    // Split outputs go through LDS (the operand buffers are free now) so that every pixel row of the tile
+    // leaves as 16-byte stores covering whole 64..320-byte channel runs; one pass per plane.  Raw fp32
+    // segments (pool branch) are stored directly from the accumulators.
+    constexpr int T_PITCH = BN * 2 + 16;                    // bytes per staged pixel row
+    static_assert(BM * T_PITCH <= LDS_BYTES, "staging tile must fit the operand LDS");
+    constexpr int NCH = BN / 8;                             // 16-byte chunks per row
+    const int nseg = p.nseg & 0xff;
+    _Float16 lo_keep[TN][16];
+#pragma unroll
+    for (int plane = 0; plane < 2; ++plane) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const int col = n0 + t * 32 + (lane & 31);
+            const bool col_ok = col < p.Cout;
+            // static-index segment look-up (dynamic indexing of the by-value argument struct would spill it)
+            void* s_dst = p.seg[0].dst;
+            long long s_ld = p.seg[0].ld;
+            int s_off = p.seg[0].off, s_mode = p.seg[0].mode, s_c0 = p.seg[0].c0;
+#pragma unroll
+            for (int s = 1; s < 4; ++s)
+                if (s < nseg && col >= p.seg[s].c0) {
+                    s_dst = p.seg[s].dst; s_ld = p.seg[s].ld; s_off = p.seg[s].off; s_mode = p.seg[s].mode; s_c0 = p.seg[s].c0;
+                }
+            const float sc = col_ok ? p.scale[col] : 0.f;
+            const float bs = col_ok ? p.bias[col] : 0.f;
+            unsigned char* trow = lds + (size_t)(wave * 32 + 4 * (lane >> 5)) * T_PITCH + (t * 32 + (lane & 31)) * 2;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int r = (j & 3) + 8 * (j >> 2);
+                if (plane == 0) {
+                    float v = (acc_main[t][j] + acc_corr[t][j] * (1.0f / 2048.0f)) * sc;
+                    if (s_mode == 0) {
+                        v = fmaxf(v + bs, 0.f);
+                        const _Float16 hi = (_Float16)v;
+                        lo_keep[t][j] = (_Float16)((v - (float)hi) * 2048.0f);
+                        *reinterpret_cast<_Float16*>(trow + r * T_PITCH) = hi;
+                    } else {
+                        lo_keep[t][j] = (_Float16)0.f;
+                        const long long pp = m0 + wave * 32 + r + 4 * (lane >> 5);
+                        if (col_ok && pp < p.M) reinterpret_cast<float*>(s_dst)[pp * s_ld + s_off + (col - s_c0)] = v;
+                    }
+                } else {
+                    *reinterpret_cast<_Float16*>(trow + r * T_PITCH) = lo_keep[t][j];
+                }
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < BM * NCH; idx += BM * 2) {
+            const int r = idx / NCH, c = idx - r * NCH;
+            const int col = n0 + c * 8;
+            const long long pp = m0 + r;
+            if (col >= p.Cout || pp >= p.M) continue;
+            void* s_dst = p.seg[0].dst;
+            long long s_ld = p.seg[0].ld, s_plane = p.seg[0].plane;
+            int s_off = p.seg[0].off, s_mode = p.seg[0].mode, s_c0 = p.seg[0].c0;
+#pragma unroll
+            for (int s = 1; s < 4; ++s)
+                if (s < nseg && col >= p.seg[s].c0) {
+                    s_dst = p.seg[s].dst; s_ld = p.seg[s].ld; s_plane = p.seg[s].plane;
+                    s_off = p.seg[s].off; s_mode = p.seg[s].mode; s_c0 = p.seg[s].c0;
+                }
+            if (s_mode != 0) continue;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(lds + (size_t)r * T_PITCH + c * 16);
+            _Float16* d = reinterpret_cast<_Float16*>(s_dst) + (plane ? s_plane : 0) + pp * s_ld + s_off + (col - s_c0);
+            *reinterpret_cast<u32x4_t*>(d) = v;
+        }
+        if (plane == 0) __syncthreads();
+    }
+}
+
 template <int TN>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs p) {
     constexpr int BN = 32 * TN;
@@ -137,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs p) {
             }
         }
         __syncthreads();
-        if (step + 1 < nsteps) CS_FETCH(step + 1)
+        if (step + 1 < nsteps && !(p.nseg & 0x100)) CS_FETCH(step + 1)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const unsigned char* ap = As + wave * 32 * CS_PITCH + frag_off + s * 32;
@@ -156,53 +234,297 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: D[row = pixel][col = cout]; lane holds col = lane & 31, rows (j&3) + 8*(j>>2) + 4*(lane>>5)
+    conv_split_epilogue<TN, 2 * CS_A_PLANE + 2 * B_PLANE>(p, acc_main, acc_corr, lds, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variant 2: operands go global -> LDS directly (global_load_lds_dwordx4, no staging registers), two LDS
+// stages, one barrier per K-step: the loads of step s+1 are issued right after the barrier of step s and
+// stay in flight under that step's MFMAs.  LDS rows are unpadded 64-byte runs (a DMA wave-instruction
+// writes 1 KiB = 16 rows linearly); bank conflicts of the ds_read_b128 fragment reads are removed by an
+// XOR swizzle of the 16-byte chunk index with (row >> 2) & 3, applied on the SOURCE address of the DMA and
+// on the read address (cdna guide rule 21).  Out-of-image taps and tails read a zero page instead.
+__device__ u32x4_t g_conv_zero_page[4];
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs p) {
+    constexpr int BN = 32 * TN;
+    constexpr int A_PLANE = CS_BM * 64, B_PLANE = BN * 64;
+    constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+    constexpr int T_BYTES = CS_BM * (BN * 2 + 16);
+    constexpr int LDS_BYTES = (2 * STAGE > T_BYTES) ? 2 * STAGE : T_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const long long nwg = (long long)gridDim.x;
+    long long bid = blockIdx.x;
+    {
+        const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long tile_m = bid / tiles_n;
+    const int tile_n = (int)(bid - tile_m * tiles_n);
+    const long long m0 = tile_m * CS_BM;
+    const int n0 = tile_n * BN;
+
+    // ---- loader role -------------------------------------------------------------------------------
+    // lane i of a DMA instruction fills row (i >> 2), physical chunk (i & 3) of a 16-row block; the logical
+    // chunk it must fetch is (i & 3) ^ ((row >> 2) & 3) = (i & 3) ^ ((i >> 4) & 3)
+    const int cl = (lane & 3) ^ ((lane >> 4) & 3);
+    const int unit = cl >> 1, sub8 = (cl & 1) * 8;
+    const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
+    const _Float16* wg = reinterpret_cast<const _Float16*>(p.w);
+    const _Float16* zp = reinterpret_cast<const _Float16*>(g_conv_zero_page);
+    int ih0[2], iw0[2];
+    long long ibase[2];
+    bool rok[2];
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-        const int col = n0 + t * 32 + (lane & 31);
-        if (col >= p.Cout) continue;
-        // segment look-up with static indices only (dynamic indexing of the by-value argument struct would
-        // spill it to scratch)
-        void* s_dst = p.seg[0].dst;
-        long long s_ld = p.seg[0].ld, s_plane = p.seg[0].plane;
-        int s_off = p.seg[0].off, s_mode = p.seg[0].mode, s_c0 = p.seg[0].c0;
+    for (int jj = 0; jj < 2; ++jj) {
+        const long long pix = m0 + (2 * wave + jj) * 16 + (lane >> 2);
+        rok[jj] = pix < p.M;
+        const long long pp = rok[jj] ? pix : 0;
+        const int ohw = p.OH * p.OW;
+        const int n = (int)(pp / ohw);
+        const int rem = (int)(pp - (long long)n * ohw);
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        ih0[jj] = oh * p.SH - p.PH;
+        iw0[jj] = ow * p.SW - p.PW;
+        ibase[jj] = (long long)n * p.H * p.W * p.Cin;
+    }
+    int a_c = unit * 16, a_kh = 0, a_kw = 0, a_k = unit * 16;
+    while (a_c >= p.Cin) { a_c -= p.Cin; if (++a_kw == p.KW) { a_kw = 0; ++a_kh; } }
+
+#define CG_ISSUE(STEP, STAGEBASE)                                                                         \
+    {                                                                                                     \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                 \
+            const int ih = ih0[jj] + a_kh, iw = iw0[jj] + a_kw;                                            \
+            const bool ok = rok[jj] && a_k < p.K && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;            \
+            const _Float16* sh = xg + ibase[jj] + ((long long)ih * p.W + iw) * p.Cin + a_c + sub8;         \
+            const _Float16* sl = sh + p.x_plane;                                                           \
+            sh = ok ? sh : zp; sl = ok ? sl : zp;                                                          \
+            unsigned char* d = (STAGEBASE) + (2 * wave + jj) * 1024;                                       \
+            __builtin_amdgcn_global_load_lds(sh, (lds_ptr_t)d, 16, 0, 0);                                  \
+            __builtin_amdgcn_global_load_lds(sl, (lds_ptr_t)(d + A_PLANE), 16, 0, 0);                      \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                   \
+            const int q = wave * TN + i;                      /* 4*TN instructions: 2 planes x 2*TN blocks */ \
+            const int plane = q >= 2 * TN ? 1 : 0;                                                         \
+            const int rb = q - plane * 2 * TN;                                                             \
+            const _Float16* sw = wg + (plane ? p.w_plane : 0) + (long long)(n0 + rb * 16 + (lane >> 2)) * p.Kpad + \
+                                 (STEP) * CS_BK + cl * 8;                                                  \
+            unsigned char* d = (STAGEBASE) + 2 * A_PLANE + plane * B_PLANE + rb * 1024;                    \
+            __builtin_amdgcn_global_load_lds(sw, (lds_ptr_t)d, 16, 0, 0);                                  \
+        }                                                                                                  \
+        a_k += CS_BK; a_c += CS_BK;                                                                        \
+        if (a_c >= p.Cin) { a_c -= p.Cin; if (++a_kw == p.KW) { a_kw = 0; ++a_kh; } }                      \
+        if (a_c >= p.Cin) { a_c -= p.Cin; if (++a_kw == p.KW) { a_kw = 0; ++a_kh; } }                      \
+    }
+
+    float16_t acc_main[TN], acc_corr[TN];
 #pragma unroll
-        for (int s = 1; s < 4; ++s)
-            if (s < p.nseg && col >= p.seg[s].c0) {
-                s_dst = p.seg[s].dst; s_ld = p.seg[s].ld; s_plane = p.seg[s].plane;
-                s_off = p.seg[s].off; s_mode = p.seg[s].mode; s_c0 = p.seg[s].c0;
-            }
-        const float sc = p.scale[col];
-        const float bs = p.bias[col];
-        const long long dcol = s_off + (col - s_c0);
+    for (int t = 0; t < TN; ++t)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const long long pp = m0 + wave * 32 + (j & 3) + 8 * (j >> 2) + 4 * (lane >> 5);
-            if (pp >= p.M) continue;
-            float v = (acc_main[t][j] + acc_corr[t][j] * (1.0f / 2048.0f)) * sc;
-            if (s_mode == 0) {
-                v = fmaxf(v + bs, 0.f);
-                const _Float16 hi = (_Float16)v;
-                const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
-                _Float16* d = reinterpret_cast<_Float16*>(s_dst) + pp * s_ld + dcol;
-                d[0] = hi;
-                d[s_plane] = lo;
-            } else {
-                reinterpret_cast<float*>(s_dst)[pp * s_ld + dcol] = v;
+        for (int j = 0; j < 16; ++j) { acc_main[t][j] = 0.f; acc_corr[t][j] = 0.f; }
+
+    const int nsteps = p.Kpad / CS_BK;
+    // fragment read: row (lane & 31) of a 32-row block, logical chunk 2*s + (lane >> 5), swizzled
+    const int frow = (lane & 31) * 64;
+    const int fswz = ((lane & 31) >> 2) & 3;
+    CG_ISSUE(0, lds)
+    for (int step = 0; step < nsteps; ++step) {
+        unsigned char* cur = lds + (step & 1) * STAGE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my DMA pieces of this stage have landed
+        __syncthreads();                                       // everyone's have; everyone left the other stage
+        if (step + 1 < nsteps) CG_ISSUE(step + 1, lds + ((step + 1) & 1) * STAGE)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int choff = ((2 * s + (lane >> 5)) ^ fswz) * 16;
+            const unsigned char* ap = cur + wave * 32 * 64 + frow + choff;
+            const half8_t a_hi = *reinterpret_cast<const half8_t*>(ap);
+            const half8_t a_lo = *reinterpret_cast<const half8_t*>(ap + A_PLANE);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const unsigned char* bp = cur + 2 * A_PLANE + t * 32 * 64 + frow + choff;
+                const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);
+                const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);
+                acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc_main[t], 0, 0, 0);
+                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc_corr[t], 0, 0, 0);
+                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc_corr[t], 0, 0, 0);
             }
         }
     }
+    __syncthreads();                                           // all fragment reads done before LDS is reused
+    conv_split_epilogue<TN, LDS_BYTES>(p, acc_main, acc_corr, lds, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variant 3: 512 threads = 8 waves stacked along M (256 pixels x 32*TN couts per workgroup), THREE LDS
+// stages, DMA issued two K-steps ahead, one raw s_barrier per step with a counted s_waitcnt vmcnt(L) that
+// leaves the newest stage's L pieces in flight (the variant-2 structure has at most one stage of loads in
+// flight per workgroup and measured latency bound: ~48-64 KB in flight per CU against a ~1.5 us L2 round
+// trip).  Ordering (MI355X_MICROARCH "Read a staged buffer one phase AFTER the wait that retires it"):
+//   step s:  vmcnt(L) -> s_barrier -> issue DMA for step s+2 into stage (s+2)%3 -> MFMAs from stage s%3
+//   RAW: stage s%3 was issued in step s-2, retired by this wave's vmcnt before the barrier every reader passes.
+//   WAR: stage (s+2)%3 was last read in step s-1; a wave reaches the barrier of step s only after the
+//        ds_reads feeding its step s-1 MFMAs returned.
+template <int TN>
+__global__ __launch_bounds__(512) void conv_split_glds3_kernel(const ConvArgs p) {
+    constexpr int BM = 256;
+    constexpr int BN = 32 * TN;
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
+    constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+    constexpr int T_BYTES = BM * (BN * 2 + 16);
+    constexpr int LDS_BYTES = (3 * STAGE > T_BYTES) ? 3 * STAGE : T_BYTES;
+    constexpr int NB = (4 * TN + 7) / 8;                 // B DMA pieces per wave per stage
+    constexpr int L = 4 + NB;                            // DMA pieces per wave per stage
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const long long nwg = (long long)gridDim.x;
+    long long bid = blockIdx.x;
+    {
+        const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long tile_m = bid / tiles_n;
+    const int tile_n = (int)(bid - tile_m * tiles_n);
+    const long long m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    const int cl = (lane & 3) ^ ((lane >> 4) & 3);
+    const int unit = cl >> 1, sub8 = (cl & 1) * 8;
+    const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
+    const _Float16* wg = reinterpret_cast<const _Float16*>(p.w);
+    const _Float16* zp = reinterpret_cast<const _Float16*>(g_conv_zero_page);
+    int ih0[2], iw0[2];
+    long long ibase[2];
+    bool rok[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const long long pix = m0 + (2 * wave + jj) * 16 + (lane >> 2);
+        rok[jj] = pix < p.M;
+        const long long pp = rok[jj] ? pix : 0;
+        const int ohw = p.OH * p.OW;
+        const int n = (int)(pp / ohw);
+        const int rem = (int)(pp - (long long)n * ohw);
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        ih0[jj] = oh * p.SH - p.PH;
+        iw0[jj] = ow * p.SW - p.PW;
+        ibase[jj] = (long long)n * p.H * p.W * p.Cin;
+    }
+    int a_c = unit * 16, a_kh = 0, a_kw = 0, a_k = unit * 16;
+    while (a_c >= p.Cin) { a_c -= p.Cin; if (++a_kw == p.KW) { a_kw = 0; ++a_kh; } }
+
+#define CG3_ISSUE(STEP, STAGEBASE)                                                                        \
+    {                                                                                                     \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                 \
+            const int ih = ih0[jj] + a_kh, iw = iw0[jj] + a_kw;                                            \
+            const bool ok = rok[jj] && a_k < p.K && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;            \
+            const _Float16* sh = xg + ibase[jj] + ((long long)ih * p.W + iw) * p.Cin + a_c + sub8;         \
+            const _Float16* sl = sh + p.x_plane;                                                           \
+            sh = ok ? sh : zp; sl = ok ? sl : zp;                                                          \
+            unsigned char* d = (STAGEBASE) + (2 * wave + jj) * 1024;                                       \
+            __builtin_amdgcn_global_load_lds(sh, (lds_ptr_t)d, 16, 0, 0);                                  \
+            __builtin_amdgcn_global_load_lds(sl, (lds_ptr_t)(d + A_PLANE), 16, 0, 0);                      \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                   \
+            /* 4*TN pieces (2 planes x 2*TN row blocks) over 8 waves; a surplus slot repeats a piece      \
+               (same bytes to the same place) so that every wave issues exactly NB: the vmcnt count is    \
+               then wave independent */                                                                    \
+            const int q = (wave + 8 * i) % (4 * TN);                                                       \
+            const int plane = q >= 2 * TN ? 1 : 0;                                                         \
+            const int rb = q - plane * 2 * TN;                                                             \
+            const _Float16* sw = wg + (plane ? p.w_plane : 0) + (long long)(n0 + rb * 16 + (lane >> 2)) * p.Kpad + \
+                                 (STEP) * CS_BK + cl * 8;                                                  \
+            unsigned char* d = (STAGEBASE) + 2 * A_PLANE + plane * B_PLANE + rb * 1024;                    \
+            __builtin_amdgcn_global_load_lds(sw, (lds_ptr_t)d, 16, 0, 0);                                  \
+        }                                                                                                  \
+        a_k += CS_BK; a_c += CS_BK;                                                                        \
+        if (a_c >= p.Cin) { a_c -= p.Cin; if (++a_kw == p.KW) { a_kw = 0; ++a_kh; } }                      \
+        if (a_c >= p.Cin) { a_c -= p.Cin; if (++a_kw == p.KW) { a_kw = 0; ++a_kh; } }                      \
+    }
+
+    float16_t acc_main[TN], acc_corr[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc_main[t][j] = 0.f; acc_corr[t][j] = 0.f; }
+
+    const int nsteps = p.Kpad / CS_BK;
+    const int frow = (lane & 31) * 64;
+    const int fswz = ((lane & 31) >> 2) & 3;
+    CG3_ISSUE(0, lds)
+    if (nsteps > 1) CG3_ISSUE(1, lds + STAGE)
+    int cur_stage = 0, nxt_stage = 2;                    // stage of step s, stage that step s+2 goes to
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (step + 2 < nsteps) CG3_ISSUE(step + 2, lds + nxt_stage * STAGE)
+        const unsigned char* cur = lds + cur_stage * STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int choff = ((2 * s + (lane >> 5)) ^ fswz) * 16;
+            const unsigned char* ap = cur + wave * 32 * 64 + frow + choff;
+            const half8_t a_hi = *reinterpret_cast<const half8_t*>(ap);
+            const half8_t a_lo = *reinterpret_cast<const half8_t*>(ap + A_PLANE);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const unsigned char* bp = cur + 2 * A_PLANE + t * 32 * 64 + frow + choff;
+                const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);
+                const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);
+                acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc_main[t], 0, 0, 0);
+                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc_corr[t], 0, 0, 0);
+                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc_corr[t], 0, 0, 0);
+            }
+        }
+        cur_stage = cur_stage == 2 ? 0 : cur_stage + 1;
+        nxt_stage = nxt_stage == 2 ? 0 : nxt_stage + 1;
+    }
+    __syncthreads();                                           // all fragment reads done before LDS is reused
+    conv_split_epilogue<TN, LDS_BYTES, BM>(p, acc_main, acc_corr, lds, m0, n0);
 }
 
 extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
-    if (!args || !args->x || !args->w || !args->scale || !args->bias || args->nseg < 1 || args->nseg > 4 ||
+    if (!args || !args->x || !args->w || !args->scale || !args->bias || (args->nseg & 0xff) < 1 || (args->nseg & 0xff) > 4 ||
         args->Cin % 16 != 0 || args->Cin < 32 || args->Kpad % CS_BK != 0 || args->M <= 0)
         return TISE_ERR_INVALID_ARG;
+    const bool glds = (tn & 16) != 0, glds3 = (tn & 32) != 0;
+    tn &= 15;
     const int bn = 32 * tn;
-    const long long tiles = ((args->M + CS_BM - 1) / CS_BM) * ((args->Cout + bn - 1) / bn);
+    const int bm = glds3 ? 256 : CS_BM;
+    const long long tiles = ((args->M + bm - 1) / bm) * ((args->Cout + bn - 1) / bn);
     if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)tiles), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (glds3) {
+        const dim3 block512(512);
+        switch (tn) {
+            case 2: hipLaunchKernelGGL(conv_split_glds3_kernel<2>, grid, block512, 0, st, *args); break;
+            case 3: hipLaunchKernelGGL(conv_split_glds3_kernel<3>, grid, block512, 0, st, *args); break;
+            case 4: hipLaunchKernelGGL(conv_split_glds3_kernel<4>, grid, block512, 0, st, *args); break;
+            case 5: hipLaunchKernelGGL(conv_split_glds3_kernel<5>, grid, block512, 0, st, *args); break;
+            default: return TISE_ERR_INVALID_ARG;
+        }
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
+    if (glds) {
+        switch (tn) {
+            case 2: hipLaunchKernelGGL(conv_split_glds_kernel<2>, grid, block, 0, st, *args); break;
+            case 3: hipLaunchKernelGGL(conv_split_glds_kernel<3>, grid, block, 0, st, *args); break;
+            case 4: hipLaunchKernelGGL(conv_split_glds_kernel<4>, grid, block, 0, st, *args); break;
+            case 5: hipLaunchKernelGGL(conv_split_glds_kernel<5>, grid, block, 0, st, *args); break;
+            default: return TISE_ERR_INVALID_ARG;
+        }
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
     switch (tn) {
         case 2: hipLaunchKernelGGL(conv_split_kernel<2>, grid, block, 0, st, *args); break;
         case 3: hipLaunchKernelGGL(conv_split_kernel<3>, grid, block, 0, st, *args); break;

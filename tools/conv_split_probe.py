@@ -20,12 +20,13 @@ shapes = [  # (H, W, Cin, Cout, kh, kw, stride, pad)
     (8, 8, 448, 384, 3, 3, 1, (1, 1)), (35, 35, 192, 208, 1, 1, 1, (0, 0)), (8, 8, 384, 384, 1, 3, 1, (0, 1)),
 ]
 g = torch.Generator(device="cpu").manual_seed(0)
-tot_m = tot_s = 0.0
+tot_m = tot_s = tot_g = tot_g3 = 0.0
 for (H, W, Cin, Cout, kh, kw, st, pad) in shapes:
     x = torch.rand((B, H, W, Cin), generator=g).to(dev) * 2.0                       # non-negative like post-ReLU
     w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
     b = (torch.randn(Cout, generator=g) * 0.1).to(dev)
     conv = SplitConv(w, b, (st, st), pad, dev)
+    conv.variant = "reg"
     xs = split(x)
     oh, ow = conv.out_hw(H, W)
     out = torch.empty((2, B, oh, ow, Cout), dtype=torch.float16, device=dev)
@@ -49,9 +50,20 @@ for (H, W, Cin, Cout, kh, kw, st, pad) in shapes:
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / it
     ms_s = t(lambda: conv(xs, [(0, Cout, out, 0, 0)]))
+    res = {}
+    for var in ("glds", "glds3"):
+        conv.variant = var
+        out2 = torch.zeros_like(out)
+        same = True
+        for rep in range(4):                       # repeated runs: a pipeline race shows up as a mismatch
+            out2.zero_()
+            conv(xs, [(0, Cout, out2, 0, 0)])
+            same = same and bool(torch.equal(out2, out))
+        res[var] = (t(lambda: conv(xs, [(0, Cout, out2, 0, 0)])), same)
+    conv.variant = "reg"
     ms_m = t(lambda: torch.conv2d(x.permute(0, 3, 1, 2), wcl, None, st, pad))
     flop = 2.0 * B * oh * ow * Cout * Cin * kh * kw
-    tot_m += ms_m; tot_s += ms_s
+    tot_m += ms_m; tot_s += ms_s; tot_g += res['glds'][0]; tot_g3 += res['glds3'][0]
     print(f"{H}x{W}x{Cin}->{Cout} k{kh}x{kw} s{st} tn{conv.tn}: split {ms_s:7.3f} ms ({flop/ms_s/1e9:6.1f} TF-eq, {3*flop/ms_s/1e9:6.0f} TF fp16)  "
-          f"miopen {ms_m:7.3f} ms ({flop/ms_m/1e9:6.1f} TF)  speedup {ms_m/ms_s:4.2f}x  err split {e_split/scale:.2e} miopen {e_mi/scale:.2e}", flush=True)
-print(f"total: split {tot_s:.2f} ms, miopen {tot_m:.2f} ms, speedup {tot_m/tot_s:.2f}x")
+          f"miopen {ms_m:7.3f} ms ({flop/ms_m/1e9:6.1f} TF)  speedup {ms_m/ms_s:4.2f}x  glds {res['glds'][0]:6.3f} ms ({3*flop/res['glds'][0]/1e9:4.0f} TF16 same={res['glds'][1]})  glds3 {res['glds3'][0]:6.3f} ms ({3*flop/res['glds3'][0]/1e9:4.0f} TF16 same={res['glds3'][1]})  err split {e_split/scale:.2e} miopen {e_mi/scale:.2e}", flush=True)
+print(f"total: reg {tot_s:.2f} ms, glds {tot_g:.2f} ms, glds3 {tot_g3:.2f} ms, miopen {tot_m:.2f} ms")
