@@ -71,7 +71,7 @@ class SplitConv:
         self.tn = tn or pick_tn(cout)
         # kernel variant: "reg" register-staged (4 waves), "glds" direct-to-LDS 2-stage (4 waves),
         # "glds3" direct-to-LDS 3-stage, 8 waves, 256-pixel tile
-        self.variant = os.environ.get("TISE_CONV_VARIANT", "glds")
+        self.variant = os.environ.get("TISE_CONV_VARIANT", "fast")
         bn = 32 * self.tn
         self.cout_pad = -(-cout // bn) * bn
         self.k = kh * kw * cin
@@ -121,6 +121,6 @@ class SplitConv:
             else:
                 assert dst.dtype == torch.float32 and dst.shape[:3] == (n, oh, ow) and dst.is_contiguous()
                 s.ld, s.plane = dst.shape[3], 0
-        _lib.call("tise_conv_split_f16", ctypes.byref(a), self.tn | {"reg": 0, "glds": 16, "glds3": 32}[self.variant],
+        _lib.call("tise_conv_split_f16", ctypes.byref(a), self.tn | {"reg": 0, "glds": 16, "glds3": 32, "gldsb": 64, "fast": 128}[self.variant],
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         return oh, ow

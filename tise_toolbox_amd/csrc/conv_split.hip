@@ -490,11 +490,276 @@ __global__ __launch_bounds__(512) void conv_split_glds3_kernel(const ConvArgs p)
     conv_split_epilogue<TN, LDS_BYTES, BM>(p, acc_main, acc_corr, lds, m0, n0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant 4 ("gldsb"): the LDS array of variant 2 turned out to be the busiest unit (per workgroup step:
+// 32 KB of DMA writes + 16 KB of A reads + 64 KB of B reads against 24 MFMAs per wave), so the pixel
+// operand, which every wave reads exactly once, no longer goes through LDS at all: each wave loads ITS 32
+// rows straight into MFMA-fragment registers one K-step ahead (4 x 16 B per lane, zero-filled by mask), and
+// only the weight tile -- shared by the four waves -- is staged (DMA, two stages, XOR swizzle as above).
+// LDS traffic per step drops from 112 KB to 80 KB at unchanged vector-memory traffic.
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_split_gldsb_kernel(const ConvArgs p) {
+    constexpr int BN = 32 * TN;
+    constexpr int B_PLANE = BN * 64;
+    constexpr int STAGE = 2 * B_PLANE;
+    constexpr int T_BYTES = CS_BM * (BN * 2 + 16);
+    constexpr int LDS_BYTES = (2 * STAGE > T_BYTES) ? 2 * STAGE : T_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const long long nwg = (long long)gridDim.x;
+    long long bid = blockIdx.x;
+    {
+        const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long tile_m = bid / tiles_n;
+    const int tile_n = (int)(bid - tile_m * tiles_n);
+    const long long m0 = tile_m * CS_BM;
+    const int n0 = tile_n * BN;
+
+    const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
+    const _Float16* wg = reinterpret_cast<const _Float16*>(p.w);
+    // ---- A role: this lane's pixel row, fragment chunk (lane >> 5) of both 16-channel units ----------
+    const long long pix = m0 + wave * 32 + (lane & 31);
+    const bool row_ok = pix < p.M;
+    int ih0, iw0;
+    long long ibase;
+    {
+        const long long pp = row_ok ? pix : 0;
+        const int ohw = p.OH * p.OW;
+        const int n = (int)(pp / ohw);
+        const int rem = (int)(pp - (long long)n * ohw);
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        ih0 = oh * p.SH - p.PH;
+        iw0 = ow * p.SW - p.PW;
+        ibase = (long long)n * p.H * p.W * p.Cin + (lane >> 5) * 8;
+    }
+    int u_c[2], u_kh[2], u_kw[2], u_k[2];               // running (c, kh, kw, k) of unit s = 0, 1
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u_c[s] = s * 16; u_kh[s] = 0; u_kw[s] = 0; u_k[s] = s * 16;
+        while (u_c[s] >= p.Cin) { u_c[s] -= p.Cin; if (++u_kw[s] == p.KW) { u_kw[s] = 0; ++u_kh[s]; } }
+    }
+    // ---- B role (DMA): lane i -> row (i >> 2), logical chunk (i & 3) ^ ((i >> 4) & 3) ----------------
+    const int cl = (lane & 3) ^ ((lane >> 4) & 3);
+    u32x4_t an[4];                                       // next step's A fragments: [s*2 + plane]
+
+#define CB_ISSUE(STEP, STAGEBASE)                                                                         \
+    {                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
+            const int ih = ih0 + u_kh[s], iw = iw0 + u_kw[s];                                              \
+            const bool ok = row_ok && u_k[s] < p.K && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;          \
+            const long long off = ok ? ibase + ((long long)ih * p.W + iw) * p.Cin + u_c[s] : 0;            \
+            const unsigned mk = ok ? 0xffffffffu : 0u;                                                     \
+            an[2 * s] = *reinterpret_cast<const u32x4_t*>(xg + off);                                       \
+            an[2 * s + 1] = *reinterpret_cast<const u32x4_t*>(xg + p.x_plane + off);                       \
+            an[2 * s] &= mk; an[2 * s + 1] &= mk;                                                          \
+            u_k[s] += CS_BK; u_c[s] += CS_BK;                                                              \
+            if (u_c[s] >= p.Cin) { u_c[s] -= p.Cin; if (++u_kw[s] == p.KW) { u_kw[s] = 0; ++u_kh[s]; } }   \
+            if (u_c[s] >= p.Cin) { u_c[s] -= p.Cin; if (++u_kw[s] == p.KW) { u_kw[s] = 0; ++u_kh[s]; } }   \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                   \
+            const int q = wave * TN + i;                                                                   \
+            const int plane = q >= 2 * TN ? 1 : 0;                                                         \
+            const int rb = q - plane * 2 * TN;                                                             \
+            const _Float16* sw = wg + (plane ? p.w_plane : 0) + (long long)(n0 + rb * 16 + (lane >> 2)) * p.Kpad + \
+                                 (STEP) * CS_BK + cl * 8;                                                  \
+            __builtin_amdgcn_global_load_lds(sw, (lds_ptr_t)((STAGEBASE) + plane * B_PLANE + rb * 1024), 16, 0, 0); \
+        }                                                                                                  \
+    }
+
+    float16_t acc_main[TN], acc_corr[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc_main[t][j] = 0.f; acc_corr[t][j] = 0.f; }
+
+    const int nsteps = p.Kpad / CS_BK;
+    const int frow = (lane & 31) * 64;
+    const int fswz = ((lane & 31) >> 2) & 3;
+    CB_ISSUE(0, lds)
+    for (int step = 0; step < nsteps; ++step) {
+        const unsigned char* cur = lds + (step & 1) * STAGE;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        u32x4_t ac[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ac[q] = an[q];
+        if (step + 1 < nsteps) CB_ISSUE(step + 1, lds + ((step + 1) & 1) * STAGE)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int choff = ((2 * s + (lane >> 5)) ^ fswz) * 16;
+            const half8_t a_hi = __builtin_bit_cast(half8_t, ac[2 * s]);
+            const half8_t a_lo = __builtin_bit_cast(half8_t, ac[2 * s + 1]);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const unsigned char* bp = cur + t * 32 * 64 + frow + choff;
+                const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);
+                const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);
+                acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc_main[t], 0, 0, 0);
+                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc_corr[t], 0, 0, 0);
+                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc_corr[t], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    conv_split_epilogue<TN, LDS_BYTES>(p, acc_main, acc_corr, lds, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variant 5 ("fast", Cin % 32 == 0): variant 2 with the address arithmetic taken out of the K loop.
+// rocprofv3 counters on variant 2 (SQ_INSTS_VALU / SQ_VALU_MFMA_BUSY_CYCLES) showed ~130 vector and ~55
+// scalar instructions per wave per K-step next to 24 MFMAs: the per-step recomputation of every DMA source
+// address (64-bit multiplies, tap decode, bounds checks) cost about as many issue cycles as the MFMAs.
+// With Cin a multiple of 32 a K-step never straddles a filter tap, so the K loop is (tap, channel block):
+// source pointers are rebuilt only when the tap changes (wave-uniform branch) and otherwise advance by
+// 64 bytes; weight pointers always advance by 64 bytes; the two LDS stages are addressed with compile-time
+// offsets (loop unrolled by two).
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs p) {
+    constexpr int BN = 32 * TN;
+    constexpr int A_PLANE = CS_BM * 64, B_PLANE = BN * 64;
+    constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+    constexpr int T_BYTES = CS_BM * (BN * 2 + 16);
+    constexpr int LDS_BYTES = (2 * STAGE > T_BYTES) ? 2 * STAGE : T_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const long long nwg = (long long)gridDim.x;
+    long long bid = blockIdx.x;
+    {
+        const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long tile_m = bid / tiles_n;
+    const int tile_n = (int)(bid - tile_m * tiles_n);
+    const long long m0 = tile_m * CS_BM;
+    const int n0 = tile_n * BN;
+
+    const int cl = (lane & 3) ^ ((lane >> 4) & 3);        // logical 16-byte chunk this lane's DMA piece fetches
+    const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
+    const _Float16* zp = reinterpret_cast<const _Float16*>(g_conv_zero_page);
+    int ih0[2], iw0[2];
+    const _Float16* img[2];
+    bool rok[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const long long pix = m0 + (2 * wave + jj) * 16 + (lane >> 2);
+        rok[jj] = pix < p.M;
+        const long long pp = rok[jj] ? pix : 0;
+        const int ohw = p.OH * p.OW;
+        const int n = (int)(pp / ohw);
+        const int rem = (int)(pp - (long long)n * ohw);
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        ih0[jj] = oh * p.SH - p.PH;
+        iw0[jj] = ow * p.SW - p.PW;
+        img[jj] = xg + (long long)n * p.H * p.W * p.Cin + cl * 8;
+    }
+    // weight pointers of this wave's TN DMA pieces (advance 32 halfs per step)
+    const _Float16* pb[TN];
+    int pb_off[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int q = wave * TN + i;
+        const int plane = q >= 2 * TN ? 1 : 0;
+        const int rb = q - plane * 2 * TN;
+        pb[i] = reinterpret_cast<const _Float16*>(p.w) + (plane ? p.w_plane : 0) +
+                (long long)(n0 + rb * 16 + (lane >> 2)) * p.Kpad + cl * 8;
+        pb_off[i] = 2 * A_PLANE + plane * B_PLANE + rb * 1024;
+    }
+    // pixel-operand pointers for the current tap
+    const _Float16* pa[2];
+    int kh = 0, kw = 0, cblk = 0;
+    const int ncblk = p.Cin / CS_BK;
+#define CF_TAP()                                                                                          \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                     \
+        const int ih = ih0[jj] + kh, iw = iw0[jj] + kw;                                                    \
+        const bool ok = rok[jj] && kh < p.KH && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                \
+        pa[jj] = ok ? img[jj] + ((long long)ih * p.W + iw) * p.Cin : nullptr;                              \
+    }
+#define CF_ISSUE(STAGEOFF)                                                                                \
+    {                                                                                                     \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                 \
+            const _Float16* sh = pa[jj] ? pa[jj] : zp;                                                     \
+            const _Float16* sl = pa[jj] ? pa[jj] + p.x_plane : zp;                                         \
+            __builtin_amdgcn_global_load_lds(sh, (lds_ptr_t)(lds + (STAGEOFF) + (2 * wave + jj) * 1024), 16, 0, 0);            \
+            __builtin_amdgcn_global_load_lds(sl, (lds_ptr_t)(lds + (STAGEOFF) + A_PLANE + (2 * wave + jj) * 1024), 16, 0, 0);  \
+            pa[jj] = pa[jj] ? pa[jj] + CS_BK : nullptr;                                                    \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                   \
+            /* locals on purpose: with array elements as direct builtin arguments hipcc (ROCm 7.2) silently  \
+               drops the host-side launch stub of this template */                                         \
+            const _Float16* sw_ = pb[i];                                                                   \
+            unsigned char* dw_ = lds + (STAGEOFF) + pb_off[i];                                             \
+            __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)dw_, 16, 0, 0);                               \
+            pb[i] += CS_BK;                                                                                \
+        }                                                                                                  \
+        if (++cblk == ncblk) {                               /* wave-uniform: next filter tap */           \
+            cblk = 0;                                                                                      \
+            if (++kw == p.KW) { kw = 0; ++kh; }                                                            \
+            CF_TAP()                                                                                       \
+        }                                                                                                  \
+    }
+
+    float16_t acc_main[TN], acc_corr[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc_main[t][j] = 0.f; acc_corr[t][j] = 0.f; }
+
+    const int nsteps = p.K / CS_BK;                           // K = KH*KW*Cin is a multiple of 32 here
+    // fragment read offsets: row (lane & 31), logical chunk 2*s + (lane >> 5), swizzled with (row >> 2) & 3
+    const int fswz = ((lane & 31) >> 2) & 3;
+    const int fo0 = (lane & 31) * 64 + (((lane >> 5)) ^ fswz) * 16;
+    const int fo1 = (lane & 31) * 64 + ((2 + (lane >> 5)) ^ fswz) * 16;
+    const unsigned char* fa = lds + wave * 32 * 64;
+
+#define CF_COMPUTE(STAGEOFF)                                                                              \
+    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                        \
+        const int fo = s ? fo1 : fo0;                                                                      \
+        const half8_t a_hi = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + fo);                      \
+        const half8_t a_lo = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + A_PLANE + fo);            \
+        _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                                   \
+            const unsigned char* bp = lds + (STAGEOFF) + 2 * A_PLANE + t * 32 * 64 + fo;                   \
+            const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);                                    \
+            const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);                          \
+            acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc_main[t], 0, 0, 0);        \
+            acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc_corr[t], 0, 0, 0);        \
+            acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc_corr[t], 0, 0, 0);        \
+        }                                                                                                  \
+    }
+
+    CF_TAP()
+    CF_ISSUE(0)
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        CF_ISSUE(STAGE)                                       // step+1 -> stage 1
+        CF_COMPUTE(0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (step + 2 < nsteps) CF_ISSUE(0)                    // step+2 -> stage 0
+        CF_COMPUTE(STAGE)
+    }
+    if (step < nsteps) {                                      // odd tail: its data sits in stage 0
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        CF_COMPUTE(0)
+    }
+    __syncthreads();
+    conv_split_epilogue<TN, LDS_BYTES>(p, acc_main, acc_corr, lds, m0, n0);
+}
+
 extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     if (!args || !args->x || !args->w || !args->scale || !args->bias || (args->nseg & 0xff) < 1 || (args->nseg & 0xff) > 4 ||
         args->Cin % 16 != 0 || args->Cin < 32 || args->Kpad % CS_BK != 0 || args->M <= 0)
         return TISE_ERR_INVALID_ARG;
-    const bool glds = (tn & 16) != 0, glds3 = (tn & 32) != 0;
+    const bool glds = (tn & (16 | 128)) != 0, glds3 = (tn & 32) != 0, gldsb = (tn & 64) != 0;
+    const bool fast = (tn & 128) != 0 && args->Cin % 32 == 0 && args->K == args->Kpad;
     tn &= 15;
     const int bn = 32 * tn;
     const int bm = glds3 ? 256 : CS_BM;
@@ -502,6 +767,28 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)tiles), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (fast) {
+        switch (tn) {
+            case 2: hipLaunchKernelGGL(conv_split_fast_kernel<2>, grid, block, 0, st, *args); break;
+            case 3: hipLaunchKernelGGL(conv_split_fast_kernel<3>, grid, block, 0, st, *args); break;
+            case 4: hipLaunchKernelGGL(conv_split_fast_kernel<4>, grid, block, 0, st, *args); break;
+            case 5: hipLaunchKernelGGL(conv_split_fast_kernel<5>, grid, block, 0, st, *args); break;
+            default: return TISE_ERR_INVALID_ARG;
+        }
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
+    if (gldsb) {
+        switch (tn) {
+            case 2: hipLaunchKernelGGL(conv_split_gldsb_kernel<2>, grid, block, 0, st, *args); break;
+            case 3: hipLaunchKernelGGL(conv_split_gldsb_kernel<3>, grid, block, 0, st, *args); break;
+            case 4: hipLaunchKernelGGL(conv_split_gldsb_kernel<4>, grid, block, 0, st, *args); break;
+            case 5: hipLaunchKernelGGL(conv_split_gldsb_kernel<5>, grid, block, 0, st, *args); break;
+            default: return TISE_ERR_INVALID_ARG;
+        }
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
     if (glds3) {
         const dim3 block512(512);
         switch (tn) {

@@ -51,7 +51,7 @@ for (H, W, Cin, Cout, kh, kw, st, pad) in shapes:
         return e0.elapsed_time(e1) / it
     ms_s = t(lambda: conv(xs, [(0, Cout, out, 0, 0)]))
     res = {}
-    for var in ("glds", "glds3"):
+    for var in ("glds", "fast"):
         conv.variant = var
         out2 = torch.zeros_like(out)
         same = True
@@ -63,7 +63,7 @@ for (H, W, Cin, Cout, kh, kw, st, pad) in shapes:
     conv.variant = "reg"
     ms_m = t(lambda: torch.conv2d(x.permute(0, 3, 1, 2), wcl, None, st, pad))
     flop = 2.0 * B * oh * ow * Cout * Cin * kh * kw
-    tot_m += ms_m; tot_s += ms_s; tot_g += res['glds'][0]; tot_g3 += res['glds3'][0]
+    tot_m += ms_m; tot_s += ms_s; tot_g += res['glds'][0]; tot_g3 += res['fast'][0]
     print(f"{H}x{W}x{Cin}->{Cout} k{kh}x{kw} s{st} tn{conv.tn}: split {ms_s:7.3f} ms ({flop/ms_s/1e9:6.1f} TF-eq, {3*flop/ms_s/1e9:6.0f} TF fp16)  "
-          f"miopen {ms_m:7.3f} ms ({flop/ms_m/1e9:6.1f} TF)  speedup {ms_m/ms_s:4.2f}x  glds {res['glds'][0]:6.3f} ms ({3*flop/res['glds'][0]/1e9:4.0f} TF16 same={res['glds'][1]})  glds3 {res['glds3'][0]:6.3f} ms ({3*flop/res['glds3'][0]/1e9:4.0f} TF16 same={res['glds3'][1]})  err split {e_split/scale:.2e} miopen {e_mi/scale:.2e}", flush=True)
-print(f"total: reg {tot_s:.2f} ms, glds {tot_g:.2f} ms, glds3 {tot_g3:.2f} ms, miopen {tot_m:.2f} ms")
+          f"miopen {ms_m:7.3f} ms ({flop/ms_m/1e9:6.1f} TF)  speedup {ms_m/ms_s:4.2f}x  glds {res['glds'][0]:6.3f} ms ({3*flop/res['glds'][0]/1e9:4.0f} TF16 same={res['glds'][1]})  fast {res['fast'][0]:6.3f} ms ({3*flop/res['fast'][0]/1e9:4.0f} TF16 same={res['fast'][1]})  err split {e_split/scale:.2e} miopen {e_mi/scale:.2e}", flush=True)
+print(f"total: reg {tot_s:.2f} ms, glds {tot_g:.2f} ms, fast {tot_g3:.2f} ms, miopen {tot_m:.2f} ms")
