@@ -178,6 +178,13 @@ int tise_avgpool3_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_o
 int tise_maxpool3s2_split_nhwc(const void* x_dev, int64_t x_ld, int x_off, int64_t x_plane, int n, int h, int w,
                                int C, void* out_dev, int64_t out_ld, int out_off, int64_t out_plane, void* stream);
 
+/* Stem layer Conv2d_1a_3x3 (3 -> 32, 3x3, stride 2) from the fp32 NHWC input (n, h, w, 3), folded bias +
+ * ReLU + fp16 split fused: out planes (n, oh, ow, 32).  w_dev: [kh][kw][cin][cout] fp32 (27 x 32). */
+int tise_stem_conv3x3s2_split(const float* x_dev, int n, int h, int w, const float* w_dev, const float* bias_dev,
+                              void* out_dev, int64_t out_plane, void* stream);
+/* Global average of split planes (n, hw, C) -> fp32 (n, C): AdaptiveAvgPool2d((1,1)) of the last block. */
+int tise_split_mean_nhwc(const void* x_dev, int64_t x_plane, int n, int hw, int C, float* out_dev, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * (a5, convolution) Implicit-GEMM convolution on fp16 MFMA with 3-term split-precision operands.
  * Replaces the Conv2d + BatchNorm(eval) + ReLU of torchvision's BasicConv2d for NHWC tensors held as

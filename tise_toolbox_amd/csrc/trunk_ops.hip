@@ -201,6 +201,80 @@ __global__ __launch_bounds__(256) void maxpool3s2_split_kernel(const _Float16* _
     }
 }
 
+// Stem convolution Conv2d_1a_3x3 (3 -> 32 channels, 3x3, stride 2, no padding; torchvision Inception3 /
+// reference image_realism/FID/inception.py:60) straight from the fp32 NHWC network input, with the folded
+// BatchNorm bias, ReLU and the fp16 split of the result fused.  K = 27 is far too small for the MFMA
+// implicit-GEMM kernel (which needs Cin % 16 == 0), and through MIOpen this layer cost a conv launch, a
+// zero-fill launch and a separate bias/ReLU/split pass; here it is one HBM-bound pass (fp32 FMA chains in
+// (kh, kw, cin) order).  Thread = (output pixel, 8 output channels); four lanes share a pixel so a pixel's
+// 32 channels leave as one 64-byte run per plane.  Weights: w[kh][kw][cin][cout] fp32 in LDS.
+__global__ __launch_bounds__(256) void stem_conv3x3s2_split_kernel(const float* __restrict__ x, int N, int H, int W,
+                                                                   const float* __restrict__ wt,   // [27][32]
+                                                                   const float* __restrict__ bias, // [32]
+                                                                   _Float16* __restrict__ out, int64_t out_plane) {
+    __shared__ float ws[27 * 32];
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = wt[i];
+    __syncthreads();
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * OH * OW * 4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = e >> 2;
+        const int cg = (int)(e & 3) * 8;
+        const int ow = (int)(p % OW);
+        const int oh = (int)((p / OW) % OH);
+        const int64_t n = p / ((int64_t)OW * OH);
+        const float* xp = x + ((n * H + 2 * oh) * W + 2 * ow) * 3;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const float* xr = xp + (int64_t)kh * W * 3;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {                    // (kw, cin) = 9 contiguous floats of the input row
+                const float v = xr[t];
+                const float* wr = ws + (kh * 9 + t) * 32 + cg;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
+            }
+        }
+        half8v h, l;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float v = fmaxf(acc[c] + bias[cg + c], 0.f);
+            h[c] = (_Float16)v;
+            l[c] = (_Float16)((v - (float)h[c]) * 2048.f);
+        }
+        _Float16* d = out + p * 32 + cg;
+        *reinterpret_cast<half8v*>(d) = h;
+        *reinterpret_cast<half8v*>(d + out_plane) = l;
+    }
+}
+
+// split planes (N, HW, C) -> fp32 (N, C) mean over the HW positions (AdaptiveAvgPool2d((1,1)) of the last
+// block): thread = (image, 8 channels), fixed summation order.
+__global__ __launch_bounds__(256) void split_mean_kernel(const _Float16* __restrict__ x, int64_t x_plane, int N, int HW,
+                                                         int C8, float* __restrict__ out) {
+    const int64_t total = (int64_t)N * C8;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = e / C8;
+        const int c8 = (int)(e - n * C8);
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+        const _Float16* q = x + n * HW * (int64_t)C8 * 8 + c8 * 8;
+        for (int s = 0; s < HW; ++s) {
+            const half8v vh = *reinterpret_cast<const half8v*>(q + (int64_t)s * C8 * 8);
+            const half8v vl = *reinterpret_cast<const half8v*>(q + (int64_t)s * C8 * 8 + x_plane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += (float)vh[i] + (float)vl[i] * (1.f / 2048.f);
+        }
+        float* d = out + n * (int64_t)C8 * 8 + c8 * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = acc[i] / (float)HW;
+    }
+}
+
 inline int grid_for(int64_t total) {
     int64_t b = (total + 255) / 256;
     if (b > 16384) b = 16384;
@@ -293,6 +367,26 @@ int tise_maxpool3s2_split_nhwc(const void* x_dev, int64_t x_ld, int x_off, int64
     hipLaunchKernelGGL(maxpool3s2_split_kernel, dim3(grid_for((int64_t)n * oh * ow * (C / 8))), dim3(256), 0,
                        (hipStream_t)stream, reinterpret_cast<const _Float16*>(x_dev), x_ld, x_off, x_plane, n, h, w, C / 8,
                        reinterpret_cast<_Float16*>(out_dev), out_ld, out_off, out_plane);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+int tise_stem_conv3x3s2_split(const float* x_dev, int n, int h, int w, const float* w_dev, const float* bias_dev,
+                              void* out_dev, int64_t out_plane, void* stream) {
+    if (!x_dev || !w_dev || !bias_dev || !out_dev || n < 0 || h < 3 || w < 3) return TISE_ERR_INVALID_ARG;
+    if (n == 0) return TISE_OK;
+    const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
+    hipLaunchKernelGGL(stem_conv3x3s2_split_kernel, dim3(grid_for((int64_t)n * oh * ow * 4)), dim3(256), 0,
+                       (hipStream_t)stream, x_dev, n, h, w, w_dev, bias_dev, reinterpret_cast<_Float16*>(out_dev), out_plane);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+int tise_split_mean_nhwc(const void* x_dev, int64_t x_plane, int n, int hw, int C, float* out_dev, void* stream) {
+    if (!x_dev || !out_dev || n < 0 || hw <= 0 || C <= 0 || C % 8) return TISE_ERR_INVALID_ARG;
+    if (n == 0) return TISE_OK;
+    hipLaunchKernelGGL(split_mean_kernel, dim3(grid_for((int64_t)n * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const _Float16*>(x_dev), x_plane, n, hw, C / 8, out_dev);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }

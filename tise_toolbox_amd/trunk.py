@@ -255,6 +255,9 @@ class SplitTrunk(FusedTrunk):
             return SplitConv(c.w, c.b, c.stride, c.padding, self.device)
 
         self.s2a, self.s2b, self.s3b, self.s4a = sc(self.c2a), sc(self.c2b), sc(self.c3b), sc(self.c4a)
+        # stem weights for the direct kernel: [kh][kw][cin][cout] fp32
+        self.stem_w = self.c1a.w.permute(2, 3, 1, 0).contiguous().float()
+        assert tuple(self.stem_w.shape) == (3, 3, 3, 32) and self.c1a.stride == (2, 2) and self.c1a.padding == (0, 0)
         self.sblocks = [(kind, {k: sc(v) for k, v in P.items()}) for kind, P in self.blocks]
 
     # ---- helpers on split tensors (2, N, H, W, C) fp16 ------------------------------------------------
@@ -367,10 +370,10 @@ class SplitTrunk(FusedTrunk):
         x = x_nchw_channels_last.permute(0, 2, 3, 1)
         if not x.is_contiguous():
             x = x.contiguous()
-        raw = self._conv(x, self.c1a)                                   # Cin = 3: MIOpen fp32
-        n, h, w, c = raw.shape
-        a = self._new(n, h, w, c, raw.device)
-        _lib.call("tise_bias_relu_split_nhwc", _p(raw), c, 0, n * h * w, c, _p(self.c1a.b), _p(a), c, 0, a.stride(0),
+        n, h, w, _ = x.shape                                            # Cin = 3 stem layer: direct HIP kernel
+        oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        a = self._new(n, oh, ow, 32, x.device)
+        _lib.call("tise_stem_conv3x3s2_split", _p(x), n, h, w, _p(self.stem_w), _p(self.c1a.b), _p(a), a.stride(0),
                   _stream())
         a = self._sconv(self.s2a, a)
         a = self._maxpool_split(self._sconv(self.s2b, a))
@@ -379,5 +382,7 @@ class SplitTrunk(FusedTrunk):
         fn = {"A": self._sblock_a, "B": self._sblock_b, "C": self._sblock_c, "D": self._sblock_d, "E": self._sblock_e}
         for kind, P in self.sblocks:
             a = fn[kind](a, P)
-        feat = (a[0].float() + a[1].float() * (1.0 / 2048.0)).mean(dim=(1, 2), keepdim=True)   # merge + global average
-        return feat.permute(0, 3, 1, 2)
+        _, n, h, w, c = a.shape                                         # merge + global average, one pass
+        feat = torch.empty((n, c), dtype=torch.float32, device=a.device)
+        _lib.call("tise_split_mean_nhwc", _p(a), a.stride(0), n, h * w, c, _p(feat), _stream())
+        return feat.view(n, c, 1, 1)
