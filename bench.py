@@ -137,6 +137,8 @@ def main():
     rank, world, local_rank = tdist.init_from_env()
     if world != args.gpus and rank == 0:
         print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if os.environ.get("TISE_FORCE_DEVICE0"):       # testing aid: several ranks on one GPU (gloo backend only)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cl = None if args.channels_last < 0 else bool(args.channels_last)
@@ -165,8 +167,11 @@ def main():
     for s in range(W):
         eng.step_u8(data[(s % K) * B:(s % K + 1) * B], s * B)
     if W > 0:
+        eng.reduce()                                # also brings up the RCCL communicator outside the timed region
         mu_w, sig_w = eng.statistics()
         solver.distance(mu_w, sig_w, mu_ref, sigma_ref)
+    elif world > 1:
+        tdist.all_reduce_sum_(torch.zeros(1024, dtype=torch.float64, device=dev))
     torch.cuda.synchronize()
 
     # ---- timed region -------------------------------------------------------------------------------
@@ -186,6 +191,9 @@ def main():
         ev[s][3].record()
         eng.stats.update_parts(feats, cov=False, col_sum=True)
         eng.is_acc.update(logits, lo + s * B)
+        if os.environ.get("TISE_BENCH_CHECKSUM"):      # debugging aid: per-batch feature / input checksums
+            print(f"[chk] rank {rank} first_index {lo + s * B} feats {feats.double().sum().item()!r} "
+                  f"imgs {batch.double().sum().item()!r} logits {logits.double().sum().item()!r}", file=sys.stderr, flush=True)
     t_loop_host = time.perf_counter()
     eng.reduce()                                             # RCCL all-reduce of {n, s, S} and the IS* sums
     mu, sigma = eng.statistics()
@@ -200,6 +208,16 @@ def main():
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
+    from tise_toolbox_amd.trunk import SplitTrunk
+    if isinstance(eng.fused, SplitTrunk):
+        # fp32-class arithmetic: every operand carried as two fp16 numbers (22 mantissa bits), three fp16 MFMAs
+        # per product, fp32 accumulation; measured error vs an fp64 convolution is below MIOpen's fp32 kernels
+        # (tools/conv_split_probe.py, tests/test_gpu_kernels.py::test_conv_split_matches_fp64_conv)
+        conv_dtype = "f32 (split 2xf16 operands, 3 f16 MFMAs/product, f32 accumulate)"
+        trunk_desc = "hand-written HIP implicit-GEMM convs (csrc/conv_split.hip) + HIP epilogues, BN folded, NHWC"
+    else:
+        conv_dtype = "f32"
+        trunk_desc = "PyTorch-ROCm (MIOpen) fp32 convs + HIP epilogues, BN folded, " + ("channels_last" if eng.channels_last else "NCHW")
     if rank == 0:
         resize_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(K)]))
         trunk_ms = float(np.mean([ev[s][1].elapsed_time(ev[s][2]) for s in range(K)]))
@@ -234,12 +252,12 @@ def main():
             "metric": "images/sec through InceptionV3+FID on 30k 256x256 @1/2/4/8 GPU; |dFID| vs ref",
             "value": n_total / elapsed, "unit": "images/sec", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": conv_dtype, "data": "synthetic",
             "config": {"workload": f"IS*+FID on {n_rank} synthetic 256x256 images per GPU (BASELINE configs[1]: "
                                    f"30k images, 1xMI355X, InceptionV3 pool3 2048-d), batch {B}, seeded stand-in "
                                    f"InceptionV3 weights, reference stats from {args.ref_images} images",
                        "batch": B, "images_per_gpu": n_rank, "images_total": n_total, "dims": 2048,
-                       "trunk": "PyTorch-ROCm fp32, BN folded, " + ("channels_last" if eng.channels_last else "NCHW"),
+                       "trunk": trunk_desc,
                        "parallelism": f"dp{world}"},
             "roofline": roofline,
             "stage_ms_per_step": {"resize": resize_ms, "trunk_fp32": trunk_ms, "cov_syrk": syrk_ms},

@@ -25,11 +25,13 @@ def init_from_env(backend=None):
     rank, world, local_rank = env_world()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # TISE_DIST_BACKEND=gloo lets the multi-rank path be exercised on a single-GPU box (tests only)
+            backend = os.environ.get("TISE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -62,6 +64,20 @@ def all_reduce_sum_(t):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def broadcast_module_(module, src=0):
+    """Overwrite every parameter and buffer of `module` with rank `src`'s values (identity for 1 process)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return module
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            if t.numel() == 0:
+                continue
+            buf = t.detach().clone().contiguous()
+            dist.broadcast(buf, src=src)
+            t.copy_(buf)
+    return module
 
 
 def barrier():

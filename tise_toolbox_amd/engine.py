@@ -63,6 +63,9 @@ class RealismEngine:
             model = InceptionV3([block], weights=weights, num_classes=num_classes, seed=seed,
                                 normalize_input=normalize_input)
         self.model = model.to(self.device).eval()
+        # every rank must run the SAME parameters: the stand-in weights are calibrated with CPU convolutions
+        # whose rounding depends on the host thread count, so rank 0's copy is broadcast (no-op for 1 process)
+        tdist.broadcast_module_(self.model)
         if channels_last:
             self.model = self.model.to(memory_format=torch.channels_last)
         if fold_bn and hasattr(self.model, "fold_bn"):
