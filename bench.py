@@ -40,6 +40,7 @@ if ROOT not in sys.path:
 # microbenchmark recorded in profiles/ (DESIGN.md "Peaks").
 PEAK_HBM_GBS = 8000.0
 PEAK_F64_MFMA_TFLOPS = 78.6
+PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 
 
 def synth_images_device(lo, hi, device, seed=0, shift=0.0, hw=256):
@@ -176,6 +177,8 @@ def main():
 
     # ---- timed region -------------------------------------------------------------------------------
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
+    from tise_toolbox_amd.conv_split import SplitConv as _SC
+    _SC.timer = []                                  # HIP events around every convolution launch of the timed steps
     eng.begin(n_total=n_total, temperature=T_COCO, splits=10, rule="coco")
     tdist.barrier()
     torch.cuda.synchronize()
@@ -209,6 +212,9 @@ def main():
     elapsed = float(elapsed.item())
 
     from tise_toolbox_amd.trunk import SplitTrunk
+    from tise_toolbox_amd.conv_split import SplitConv
+    conv_events = SplitConv.timer or []
+    SplitConv.timer = None
     if isinstance(eng.fused, SplitTrunk):
         # fp32-class arithmetic: every operand carried as two fp16 numbers (22 mantissa bits), three fp16 MFMAs
         # per product, fp32 accumulation; measured error vs an fp64 convolution is below MIOpen's fp32 kernels
@@ -235,6 +241,17 @@ def main():
                                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "avg_ms": resize_ms,
                                           "algorithmic_bytes_per_launch": resize_bytes},
         }
+        if conv_events:
+            conv_ms = sum(a.elapsed_time(b) for a, b, _ in conv_events)
+            conv_flop = sum(f for _, _, f in conv_events)
+            n_launch = len(conv_events)
+            # algorithmic work = the convolution's 2*M*N*K flop.  The kernel spends THREE fp16 MFMA flop per
+            # algorithmic flop (hi*hi, hi*lo, lo*hi), so its ceiling is the dense fp16 MFMA peak / 3.
+            kern["conv_split_kernel"] = {
+                "bound": "mfma", "achieved": conv_flop / (conv_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3.0,
+                "unit": "TFLOP/s", "avg_ms": conv_ms / K, "avg_launch_ms": conv_ms / n_launch,
+                "launches_per_step": n_launch / K, "algorithmic_flop_per_step": conv_flop / K,
+                "mfma_tflops_f16": 3.0 * conv_flop / (conv_ms * 1e-3) / 1e12, "mfma_peak_f16": PEAK_F16_MFMA_TFLOPS}
         for k in kern.values():
             k["frac"] = k["achieved"] / k["peak"]
         traffic = None
@@ -247,7 +264,8 @@ def main():
                 traffic = None
         roofline = {"kernel": dom, "bound": kern[dom]["bound"], "achieved": kern[dom]["achieved"],
                     "peak": kern[dom]["peak"], "unit": kern[dom]["unit"], "frac": kern[dom]["frac"],
-                    "traffic": traffic, "avg_launch_ms": kern[dom]["avg_ms"], "kernels": kern}
+                    "traffic": traffic, "avg_launch_ms": kern[dom].get("avg_launch_ms", kern[dom]["avg_ms"]),
+                    "kernels": kern}
         out = {
             "metric": "images/sec through InceptionV3+FID on 30k 256x256 @1/2/4/8 GPU; |dFID| vs ref",
             "value": n_total / elapsed, "unit": "images/sec", "n_gpus": world, "steps": K, "warmup": W,

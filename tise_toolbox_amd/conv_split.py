@@ -61,6 +61,9 @@ def pick_tn(cout):
 class SplitConv:
     """One (possibly channel-concatenated) convolution with folded scale/bias, packed for the kernel."""
 
+    # measurement hook (bench.py): when a list, every launch appends (start_event, end_event, flop)
+    timer = None
+
     def __init__(self, weight, bias, stride, padding, device, tn=None):
         """weight: (Cout, Cin, KH, KW) fp32 (BatchNorm already folded), bias: (Cout,) fp32."""
         cout, cin, kh, kw = weight.shape
@@ -121,6 +124,13 @@ class SplitConv:
             else:
                 assert dst.dtype == torch.float32 and dst.shape[:3] == (n, oh, ow) and dst.is_contiguous()
                 s.ld, s.plane = dst.shape[3], 0
+        timer = SplitConv.timer
+        if timer is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.call("tise_conv_split_f16", ctypes.byref(a), self.tn | {"reg": 0, "glds": 16, "glds3": 32, "gldsb": 64, "fast": 128}[self.variant],
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if timer is not None:
+            e1.record()
+            timer.append((e0, e1, 2.0 * a.M * self.cout * self.k))
         return oh, ow
