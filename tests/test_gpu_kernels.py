@@ -408,3 +408,43 @@ def test_split_trunk_matches_module_graph(dev):
     assert got.shape == want.shape
     err = (got - want).abs().max().item()
     assert err <= 2e-4 * want.abs().max().item(), err
+
+
+@pytest.mark.parametrize("variant", ["reg", "glds", "glds3", "gldsb", "fast"])
+def test_conv_split_variants_bitwise_identical_and_repeatable(dev, variant):
+    """All kernel variants implement the same arithmetic in the same order: outputs must be bit-identical to
+    the register-staged kernel, run after run (a DMA/LDS race would show up as a mismatch)."""
+    from tise_toolbox_amd.conv_split import SplitConv, split
+    g = torch.Generator(device="cpu").manual_seed(7)
+    for (n, H, W, Cin, Cout, kh, kw, st, pad) in [(37, 17, 17, 128, 192, 7, 1, 1, (3, 0)), (3, 35, 35, 64, 96, 3, 3, 1, (1, 1)),
+                                                  (64, 8, 8, 448, 384, 3, 3, 1, (1, 1)), (1, 9, 9, 32, 64, 3, 3, 2, (0, 0))]:
+        x = (torch.rand((n, H, W, Cin), generator=g) * 2.0).to(dev)
+        w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
+        b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+        conv = SplitConv(w, b, (st, st), pad, dev)
+        xs = split(x)
+        oh, ow = conv.out_hw(H, W)
+        conv.variant = "reg"
+        ref = torch.zeros((2, n, oh, ow, Cout), dtype=torch.float16, device=dev)
+        conv(xs, [(0, Cout, ref, 0, 0)])
+        conv.variant = variant
+        for rep in range(6):
+            out = torch.full_like(ref, 7.0)
+            conv(xs, [(0, Cout, out, 0, 0)])
+            assert torch.equal(out, ref), (variant, rep, (n, H, W, Cin, Cout))
+
+
+def test_split_trunk_batch_sizes_and_determinism(dev):
+    """pool3 features must not depend on how images are batched, and must repeat bit for bit."""
+    from tise_toolbox_amd.inception import InceptionV3
+    from tise_toolbox_amd.trunk import SplitTrunk
+    m = InceptionV3([3], seed=0).to(dev).eval()
+    trunk = SplitTrunk(m, dev)
+    x = torch.rand((11, 3, 299, 299), device=dev).contiguous(memory_format=torch.channels_last)
+    full = trunk(x).clone()
+    again = trunk(x)
+    assert torch.equal(full, again)
+    one = torch.cat([trunk(x[i:i + 1].contiguous(memory_format=torch.channels_last)) for i in range(11)], 0)
+    chunks = torch.cat([trunk(x[:4].contiguous(memory_format=torch.channels_last)),
+                        trunk(x[4:].contiguous(memory_format=torch.channels_last))], 0)
+    assert torch.equal(one, full) and torch.equal(chunks, full)

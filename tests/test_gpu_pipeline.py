@@ -165,3 +165,36 @@ def test_is_cli(setup, tmp_path):
     idx = [int(os.path.basename(f).split(".")[0]) for f in files]
     want = is_oracle.inception_score_from_logits(setup["lg"][idx], is_oracle.T_COCO, 10, "coco", dtype=np.float32)
     assert abs(mean - want[0]) <= 1e-4 and abs(std - want[1]) <= 1e-4
+
+
+def test_object_centric_inception_score(setup, tmp_path):
+    """O-IS drop-in (object_fidelity/O-IS/object_centric_inception_score.py): 80-class head, [-1,1] input,
+    T = 2.1737587451934814, N // splits rows per split -- against the oracle on the same crops and weights."""
+    from PIL import Image
+    from tise_toolbox_amd import object_centric_inception_score as ois
+    from tise_toolbox_amd.inception import build_inception3
+    d = tmp_path / "crops"
+    d.mkdir()
+    rng = np.random.default_rng(0)
+    sizes = [(64, 48), (120, 90), (33, 71)]
+    for i in range(37):                                                   # ragged crop sizes, 37 = 3*10 + 7 (tail dropped)
+        h, w = sizes[i % 3]
+        Image.fromarray(setup["gen"][i % N_GEN][:h, :w]).save(d / f"img{i:03d}_person_{i}.png")
+    ds = ois.IgnoreLabelDataset(str(d))
+    assert len(ds) == 37 and ds[0].dtype == torch.uint8
+    out = tmp_path / "ois.txt"
+    mean, std = ois.main(["--image_dir", str(d), "--saved_file", str(out), "--gpu_id", "0"])
+    assert out.read_text() == f"O-IS: {mean} +-  {std}"
+    # oracle: PIL-exact resize, (x - 0.5) / 0.5, CPU fp32 trunk without the inception.py:120-124 affine, 80-class fc
+    sd = {k: v.float() for k, v in build_inception3(num_classes=80, seed=0, calibration="pm1").state_dict().items()}
+    logits = []
+    for name in ds.namelist:
+        im = np.asarray(Image.open(d / name).convert("RGB"))
+        x = resize_oracle.to_tensor(resize_oracle.resize_bilinear_u8(im, 299, 299))
+        x = (x - np.float32(0.5)) / np.float32(0.5)
+        o = inception_oracle.inception_forward(sd, torch.from_numpy(x[None]), resize_input=False, normalize_input=False)[3]
+        logits.append(inception_oracle.logits_from_pool3(sd, o).numpy())
+    want = is_oracle.inception_score_from_logits(np.concatenate(logits), is_oracle.T_OIS, 10, "ois", dtype=np.float64)
+    assert abs(mean - want[0]) <= 1e-4 and abs(std - want[1]) <= 1e-4
+    with pytest.raises(AssertionError):
+        ois.inception_score(ds, batch_size=64)                            # N > batch_size (reference :26)

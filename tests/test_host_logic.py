@@ -118,6 +118,22 @@ def test_cli_surface():
     assert b.temperature == 0.9091363549232483
 
 
+def test_ois_surface(tmp_path):
+    """object_centric_inception_score.py: --image_dir/--saved_file/--gpu_id, listdir-ordered dataset, asserts."""
+    from PIL import Image
+    from tise_toolbox_amd import object_centric_inception_score as ois
+    a = ois.parse_args(["--image_dir", "d", "--saved_file", "o.txt", "--gpu_id", "2"])
+    assert (a.image_dir, a.saved_file, a.gpu_id) == ("d", "o.txt", 2)
+    assert ois.T_OIS == 2.1737587451934814 and ois.DEFAULT_WEIGHTS.endswith("inceptionv3_fine_to_with_80_coco_classes.pth")
+    for i in range(3):
+        Image.fromarray(np.full((5 + i, 4, 3), i, np.uint8)).save(tmp_path / f"c{i}.png")
+    ds = ois.IgnoreLabelDataset(str(tmp_path))
+    assert ds.namelist == os.listdir(str(tmp_path)) and len(ds) == 3
+    assert ds[0].dtype == torch.uint8 and ds[0].shape[2] == 3
+    with pytest.raises(AssertionError):
+        ois.inception_score(ds, batch_size=3)          # reference :26 requires N > batch_size
+
+
 def test_missing_path_raises_like_reference(tmp_path):
     from tise_toolbox_amd import fid_score
     with pytest.raises(RuntimeError, match="Invalid path: "):

@@ -9,7 +9,7 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtise_hip.so")
+LIB_PATH = os.environ.get("TISE_LIB_PATH") or os.path.join(_HERE, "libtise_hip.so")   # override: kernel A/B builds
 
 
 class TiseLibraryError(RuntimeError):

@@ -717,19 +717,41 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     const int fo1 = (lane & 31) * 64 + ((2 + (lane >> 5)) ^ fswz) * 16;
     const unsigned char* fa = lds + wave * 32 * 64;
 
+// One K-step of MFMAs.  All fragment reads of the step are written first and the MFMAs after them; the
+// sched_group_barrier sequence then tells the scheduler to emit them interleaved (first operand pair, then
+// "next pair of reads + 3 MFMAs" repeatedly), so that LDS latency is covered by the wave's own MFMAs instead
+// of four exposed lgkmcnt(0) waits per step (cdna guide T19).
 #define CF_COMPUTE(STAGEOFF)                                                                              \
-    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                        \
-        const int fo = s ? fo1 : fo0;                                                                      \
-        const half8_t a_hi = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + fo);                      \
-        const half8_t a_lo = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + A_PLANE + fo);            \
-        _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                                   \
-            const unsigned char* bp = lds + (STAGEOFF) + 2 * A_PLANE + t * 32 * 64 + fo;                   \
-            const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);                                    \
-            const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);                          \
-            acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc_main[t], 0, 0, 0);        \
-            acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc_corr[t], 0, 0, 0);        \
-            acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc_corr[t], 0, 0, 0);        \
+    {                                                                                                     \
+        half8_t fa_[2][2], fb_[2][TN][2];                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
+            const int fo = s ? fo1 : fo0;                                                                  \
+            fa_[s][0] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + fo);                           \
+            fa_[s][1] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + A_PLANE + fo);                 \
+            _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
+                const unsigned char* bp = lds + (STAGEOFF) + 2 * A_PLANE + t * 32 * 64 + fo;               \
+                fb_[s][t][0] = *reinterpret_cast<const half8_t*>(bp);                                      \
+                fb_[s][t][1] = *reinterpret_cast<const half8_t*>(bp + B_PLANE);                            \
+            }                                                                                              \
         }                                                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \
+            _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
+                acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[s][0], fb_[s][t][0], acc_main[t], 0, 0, 0); \
+                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[s][0], fb_[s][t][1], acc_corr[t], 0, 0, 0); \
+                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[s][1], fb_[s][t][0], acc_corr[t], 0, 0, 0); \
+            }                                                                                              \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);             /* a(s0), b(s0, t0) */              \
+        _Pragma("unroll") for (int i = 0; i < TN - 1; ++i) {                                               \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         /* b(s0, t i+1) */                  \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);         /* MFMAs (s0, t i) */               \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);             /* a(s1), b(s1, t0) */              \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);             /* MFMAs (s0, t TN-1) */            \
+        _Pragma("unroll") for (int i = 0; i < TN - 1; ++i) {                                               \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                             \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                 \
     }
 
     CF_TAP()

@@ -197,7 +197,7 @@ _SEEDED_CACHE = {}
 
 
 @torch.no_grad()
-def seeded_init_(net, seed=0):
+def seeded_init_(net, seed=0, calibration="fid"):
     """Deterministic stand-in weights (no pretrained file exists offline).
 
     He-normal conv weights, then a data-dependent BatchNorm calibration: one train-mode pass over a
@@ -209,7 +209,7 @@ def seeded_init_(net, seed=0):
     generator, so CPU and GPU runs see identical parameters.  Throughput is weight-independent;
     scores obtained with these weights are only comparable between paths run on them.
     """
-    key = (seed, net.fc.out_features)
+    key = (seed, net.fc.out_features, calibration)
     if key in _SEEDED_CACHE:
         net.load_state_dict(_SEEDED_CACHE[key])
         return net
@@ -231,9 +231,12 @@ def seeded_init_(net, seed=0):
     x = torch.rand((n_cal, 3, 10, 10), generator=g)
     x = F.interpolate(x, size=(299, 299), mode="bicubic", align_corners=False).clamp_(0.0, 1.0)
     x = x + 0.05 * torch.rand((n_cal, 3, 299, 299), generator=g)
-    x[:, 0] = x[:, 0] * (0.229 / 0.5) + (0.485 - 0.5) / 0.5
-    x[:, 1] = x[:, 1] * (0.224 / 0.5) + (0.456 - 0.5) / 0.5
-    x[:, 2] = x[:, 2] * (0.225 / 0.5) + (0.406 - 0.5) / 0.5
+    if calibration == "pm1":             # O-IS convention: Normalize((.5,.5,.5),(.5,.5,.5)) -> [-1, 1]
+        x = (x - 0.5) / 0.5
+    else:                                # FID wrapper convention: inception.py:120-124 on [0, 1] pixels
+        x[:, 0] = x[:, 0] * (0.229 / 0.5) + (0.485 - 0.5) / 0.5
+        x[:, 1] = x[:, 1] * (0.224 / 0.5) + (0.456 - 0.5) / 0.5
+        x[:, 2] = x[:, 2] * (0.225 / 0.5) + (0.406 - 0.5) / 0.5
     bns = [m for m in net.modules() if isinstance(m, nn.BatchNorm2d)]
     old = [m.momentum for m in bns]
     for m in bns:
@@ -258,7 +261,7 @@ def seeded_init_(net, seed=0):
     return net
 
 
-def build_inception3(weights=None, num_classes=1000, seed=0):
+def build_inception3(weights=None, num_classes=1000, seed=0, calibration="fid"):
     """Construct ``Inception3`` and load ``weights`` (a torchvision-format state_dict
     path) or, when ``weights`` is None, the seeded stand-in parameters."""
     net = Inception3(num_classes=num_classes, aux_logits=True)
@@ -268,7 +271,7 @@ def build_inception3(weights=None, num_classes=1000, seed=0):
             sd = sd["state_dict"]
         net.load_state_dict(sd, strict=True)
     else:
-        seeded_init_(net, seed)
+        seeded_init_(net, seed, calibration)
     return net.eval()
 
 
@@ -285,7 +288,7 @@ class InceptionV3(nn.Module):
     BLOCK_INDEX_BY_DIM = {64: 0, 192: 1, 768: 2, 2048: 3}   # inception.py:14-19
 
     def __init__(self, output_blocks=[DEFAULT_BLOCK_INDEX], resize_input=True, normalize_input=True,
-                 requires_grad=False, weights=None, num_classes=1000, seed=0):
+                 requires_grad=False, weights=None, num_classes=1000, seed=0, calibration="fid"):
         super().__init__()
         self.resize_input = resize_input
         self.normalize_input = normalize_input
@@ -293,7 +296,7 @@ class InceptionV3(nn.Module):
         self.last_needed_block = max(output_blocks)
         assert self.last_needed_block <= 3, "Last possible output block index is 3"   # inception.py:53
 
-        inception = build_inception3(weights, num_classes, seed)
+        inception = build_inception3(weights, num_classes, seed, calibration)
         self.blocks = nn.ModuleList()
         self.blocks.append(nn.Sequential(                                   # inception.py:59-66
             inception.Conv2d_1a_3x3, inception.Conv2d_2a_3x3, inception.Conv2d_2b_3x3,
