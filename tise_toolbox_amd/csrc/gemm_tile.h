@@ -98,8 +98,8 @@ __device__ __forceinline__ void gemm_tile_64x64(const TA* __restrict__ A, int64_
     }
 }
 
-// write / accumulate the wave's 32x32 sub-tile.  ACCUM: C += acc.
-template <bool ACCUM>
+// write / accumulate the wave's 32x32 sub-tile.  MODE 0: C = acc, 1 (true): C += acc, 2: C -= acc.
+template <int MODE>
 __device__ __forceinline__ void gemm_tile_store(double* __restrict__ C, int64_t ldc, int M, int N, int m0, int n0,
                                                 const double4_t (&acc)[2][2]) {
     const int lane = threadIdx.x & 63;
@@ -115,7 +115,8 @@ __device__ __forceinline__ void gemm_tile_store(double* __restrict__ C, int64_t 
                 const int col = n0 + wc * 32 + tn * 16 + (lane & 15);
                 if (row < M && col < N) {
                     double* p = C + (int64_t)row * ldc + col;
-                    if (ACCUM) *p += acc[tm][tn][r];
+                    if (MODE == 1) *p += acc[tm][tn][r];
+                    else if (MODE == 2) *p -= acc[tm][tn][r];
                     else *p = acc[tm][tn][r];
                 }
             }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void syrk_f32_upper_kernel(const float* __rest
         for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
     // A(m,k) = X[k][m0+m], B(k,n) = X[k][n0+n]
     gemm_tile_64x64<float, float>(X, 1, ld, X, ld, 1, d, d, rows, tm * 64, tn * 64, acc, lds);
-    gemm_tile_store<true>(S, d, d, d, tm * 64, tn * 64, acc);
+    gemm_tile_store<1>(S, d, d, d, tm * 64, tn * 64, acc);
 }
 
 // Fast path (d % 64 == 0, 16-byte aligned rows): K is walked 64 feature rows at a time.
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void syrk_f32_upper_bk64_kernel(const float
         }
         __syncthreads();
     }
-    gemm_tile_store<true>(S, d, d, d, tm * 64, tn * 64, acc);
+    gemm_tile_store<1>(S, d, d, d, tm * 64, tn * 64, acc);
 }
 
 // 256 threads = 64 columns x 4 row phases; fixed summation order => bitwise reproducible.
