@@ -209,6 +209,11 @@ def seeded_init_(net, seed=0, calibration="fid"):
     generator, so CPU and GPU runs see identical parameters.  Throughput is weight-independent;
     scores obtained with these weights are only comparable between paths run on them.
     """
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+        # data-parallel run: rank 0 calibrates and the engine broadcasts its parameters to every rank
+        # (engine.RealismEngine -> dist.broadcast_module_), so the other ranks skip the CPU convolutions
+        return net
     key = (seed, net.fc.out_features, calibration)
     if key in _SEEDED_CACHE:
         net.load_state_dict(_SEEDED_CACHE[key])
