@@ -43,13 +43,13 @@ def merge(planes):
 
 # relative efficiency of the kernel by tile width (tools/conv_split_probe.py): narrow tiles re-read the
 # pixel operand more often per MFMA
-_TN_EFF = {2: 0.78, 3: 0.90, 4: 1.0, 5: 1.0}
+_TN_EFF = {1: 0.55, 2: 0.78, 3: 0.90, 4: 1.0, 5: 1.0}
 
 
 def pick_tn(cout):
-    """Tile width 32*tn (tn in 2..5): least padded work weighted by the measured tile efficiency."""
+    """Tile width 32*tn (tn in 1..5; 1 only exists in the DMA variants): least padded work weighted by the measured tile efficiency."""
     best = None
-    for tn in (5, 4, 3, 2):
+    for tn in (5, 4, 3, 2, 1):
         bn = 32 * tn
         padded = -(-cout // bn) * bn
         cost = padded / _TN_EFF[tn]

@@ -791,6 +791,7 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (fast) {
         switch (tn) {
+            case 1: hipLaunchKernelGGL(conv_split_fast_kernel<1>, grid, block, 0, st, *args); break;
             case 2: hipLaunchKernelGGL(conv_split_fast_kernel<2>, grid, block, 0, st, *args); break;
             case 3: hipLaunchKernelGGL(conv_split_fast_kernel<3>, grid, block, 0, st, *args); break;
             case 4: hipLaunchKernelGGL(conv_split_fast_kernel<4>, grid, block, 0, st, *args); break;
@@ -825,6 +826,7 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     }
     if (glds) {
         switch (tn) {
+            case 1: hipLaunchKernelGGL(conv_split_glds_kernel<1>, grid, block, 0, st, *args); break;
             case 2: hipLaunchKernelGGL(conv_split_glds_kernel<2>, grid, block, 0, st, *args); break;
             case 3: hipLaunchKernelGGL(conv_split_glds_kernel<3>, grid, block, 0, st, *args); break;
             case 4: hipLaunchKernelGGL(conv_split_glds_kernel<4>, grid, block, 0, st, *args); break;
