@@ -434,6 +434,46 @@ def test_conv_split_variants_bitwise_identical_and_repeatable(dev, variant):
             assert torch.equal(out, ref), (variant, rep, (n, H, W, Cin, Cout))
 
 
+@pytest.mark.parametrize("shape", [(17, 17, 160, 160, 1, 7, (0, 3), None), (35, 35, 48, 64, 5, 5, (2, 2), None),
+                                   (21, 19, 80, 192, 3, 3, (0, 0), 3), (23, 23, 32, 32, 3, 3, (0, 0), 1),
+                                   (11, 7, 32, 48, 3, 3, (1, 1), None), (8, 8, 448, 384, 3, 3, (1, 1), None),
+                                   (17, 17, 128, 192, 7, 1, (3, 0), 2)])
+def test_conv_split_window_kernel_matches_fp64_conv(dev, shape):
+    """The window-resident variant (input window of 128 + (KH-1)W + KW-1 grid pixels kept in LDS, taps as row
+    offsets) sums K in (channel block, tap) order, so it is checked against fp64 like the default kernel, not
+    bitwise against it: valid and padded borders, Cin not a multiple of 32 (80, 48), one and two window buffers,
+    image boundaries inside a tile, three destination segments, repeatability."""
+    from tise_toolbox_amd.conv_split import SplitConv, merge, split
+    H, W, Cin, Cout, kh, kw, pad, tn = shape
+    g = torch.Generator(device="cpu").manual_seed(Cin + Cout + kh)
+    n = 7
+    x = (torch.rand((n, H, W, Cin), generator=g) * 3.0).to(dev)
+    w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+    conv = SplitConv(w, b, (1, 1), pad, dev, tn=tn, variant="win")
+    assert conv.win
+    oh, ow = conv.out_hw(H, W)
+    ref_lin = torch.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, pad).permute(0, 2, 3, 1)
+    ref = torch.relu(ref_lin + b.double())
+    scale = ref.abs().max().item()
+    first = None
+    for rep in range(3):
+        out = torch.zeros((2, n, oh, ow, Cout + 32), dtype=torch.float16, device=dev)
+        raw = torch.zeros((n, oh, ow, 16), dtype=torch.float32, device=dev)
+        segs = [(0, 16, out, 16, 0), (16, 32, raw, 0, 1)] + ([(32, Cout, out, 64, 0)] if Cout > 32 else [])
+        conv(split(x), segs)
+        got = merge(out)
+        assert (got[..., 16:32].double() - ref[..., 0:16]).abs().max().item() <= 4e-6 * scale
+        if Cout > 32:
+            assert (got[..., 64:].double() - ref[..., 32:]).abs().max().item() <= 4e-6 * scale
+        assert (raw.double() - ref_lin[..., 16:32]).abs().max().item() <= 4e-6 * scale
+        assert got[..., :16].abs().max().item() == 0 and got[..., 32:64].abs().max().item() == 0
+        if first is None:
+            first = (out.clone(), raw.clone())
+        else:
+            assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
+
+
 def test_split_trunk_batch_sizes_and_determinism(dev):
     """pool3 features must not depend on how images are batched, and must repeat bit for bit."""
     from tise_toolbox_amd.inception import InceptionV3

@@ -64,7 +64,7 @@ class SplitConv:
     # measurement hook (bench.py): when a list, every launch appends (start_event, end_event, flop)
     timer = None
 
-    def __init__(self, weight, bias, stride, padding, device, tn=None):
+    def __init__(self, weight, bias, stride, padding, device, tn=None, variant=None):
         """weight: (Cout, Cin, KH, KW) fp32 (BatchNorm already folded), bias: (Cout,) fp32."""
         cout, cin, kh, kw = weight.shape
         assert cin % 16 == 0 and cin >= 32, "conv_split needs Cin % 16 == 0 and Cin >= 32"
@@ -73,8 +73,10 @@ class SplitConv:
         self.padding = tuple(padding)
         self.tn = tn or pick_tn(cout)
         # kernel variant: "reg" register-staged (4 waves), "glds" direct-to-LDS 2-stage (4 waves),
-        # "glds3" direct-to-LDS 3-stage, 8 waves, 256-pixel tile
-        self.variant = os.environ.get("TISE_CONV_VARIANT", "fast")
+        # "glds3" direct-to-LDS 3-stage, 8 waves, 256-pixel tile, "gldsb" weights straight to registers,
+        # "fast" = glds with hoisted addressing (default), "win" = window-resident input for stride-1
+        # multi-tap layers (A/B variant: measured equal to "fast" within +-3 %, profiles/r01g_conv_window_probe.txt)
+        self.variant = variant or os.environ.get("TISE_CONV_VARIANT", "fast")
         bn = 32 * self.tn
         self.cout_pad = -(-cout // bn) * bn
         self.k = kh * kw * cin
@@ -86,6 +88,13 @@ class SplitConv:
         wp = torch.zeros((self.cout_pad, self.kpad), dtype=torch.float32)
         wp[:cout, :self.k] = wk
         self.w = split(wp).to(device).contiguous()                  # (2, Cout_pad, Kpad) fp16
+        # window kernel (stride 1, more than one tap): weights packed [tap][Cin rounded up to 32]
+        self.win = self.variant == "win" and self.stride == (1, 1) and kh * kw > 1
+        if self.win:
+            cin_pad = -(-cin // 32) * 32
+            ww = torch.zeros((self.cout_pad, kh * kw, cin_pad), dtype=torch.float32)
+            ww[:cout, :, :cin] = wk.reshape(cout, kh * kw, cin)
+            self.w = split(ww.reshape(self.cout_pad, -1)).to(device).contiguous()
         sc = torch.zeros(self.cout_pad, dtype=torch.float32)
         sc[:cout] = 1.0 / pre
         bs = torch.zeros(self.cout_pad, dtype=torch.float32)
@@ -128,7 +137,8 @@ class SplitConv:
         if timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.call("tise_conv_split_f16", ctypes.byref(a), self.tn | {"reg": 0, "glds": 16, "glds3": 32, "gldsb": 64, "fast": 128}[self.variant],
+        flag = 256 if self.win else {"reg": 0, "glds": 16, "glds3": 32, "gldsb": 64, "fast": 128, "win": 128}[self.variant]
+        _lib.call("tise_conv_split_f16", ctypes.byref(a), self.tn | flag,
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         if timer is not None:
             e1.record()

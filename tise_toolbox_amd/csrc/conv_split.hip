@@ -38,8 +38,22 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // native ve
 typedef tise_conv_seg ConvSeg;
 typedef tise_conv_args ConvArgs;
 
-// Epilogue shared by both kernels (see the comment inside).  LDS_BYTES is the size of the caller's LDS array.
-template <int TN, int LDS_BYTES, int BM = CS_BM>
+// Tile row -> output pixel index (or -1).  GRID = false: tile rows ARE output pixels.  GRID = true (window
+// kernel): tile rows are pixels of the INPUT grid (n, y, x); the output pixel is (n, y, x) when it exists.
+template <bool GRID>
+__device__ __forceinline__ long long conv_out_pixel(const ConvArgs& p, long long g) {
+    if (!GRID) return g < p.M ? g : -1;
+    const long long hw = (long long)p.H * p.W;
+    if (g >= (long long)p.N * hw) return -1;
+    const long long n = g / hw;
+    const int rem = (int)(g - n * hw);
+    const int y = rem / p.W, x = rem - y * p.W;
+    if (y >= p.OH || x >= p.OW) return -1;
+    return (n * p.OH + y) * p.OW + x;
+}
+
+// Epilogue shared by all kernels (see the comment inside).  LDS_BYTES is the size of the caller's LDS array.
+template <int TN, int LDS_BYTES, int BM = CS_BM, bool GRID = false>
 __device__ __forceinline__ void conv_split_epilogue(const ConvArgs& p, float16_t (&acc_main)[TN], float16_t (&acc_corr)[TN],
                                                     unsigned char* lds, long long m0, int n0) {
     constexpr int BN = 32 * TN;
@@ -84,8 +98,8 @@ __device__ __forceinline__ void conv_split_epilogue(const ConvArgs& p, float16_t
                         *reinterpret_cast<_Float16*>(trow + r * T_PITCH) = hi;
                     } else {
                         lo_keep[t][j] = (_Float16)0.f;
-                        const long long pp = m0 + wave * 32 + r + 4 * (lane >> 5);
-                        if (col_ok && pp < p.M) reinterpret_cast<float*>(s_dst)[pp * s_ld + s_off + (col - s_c0)] = v;
+                        const long long pp = conv_out_pixel<GRID>(p, m0 + wave * 32 + r + 4 * (lane >> 5));
+                        if (col_ok && pp >= 0) reinterpret_cast<float*>(s_dst)[pp * s_ld + s_off + (col - s_c0)] = v;
                     }
                 } else {
                     *reinterpret_cast<_Float16*>(trow + r * T_PITCH) = lo_keep[t][j];
@@ -96,8 +110,9 @@ __device__ __forceinline__ void conv_split_epilogue(const ConvArgs& p, float16_t
         for (int idx = tid; idx < BM * NCH; idx += BM * 2) {
             const int r = idx / NCH, c = idx - r * NCH;
             const int col = n0 + c * 8;
-            const long long pp = m0 + r;
-            if (col >= p.Cout || pp >= p.M) continue;
+            if (col >= p.Cout) continue;
+            const long long pp = conv_out_pixel<GRID>(p, m0 + r);
+            if (pp < 0) continue;
             void* s_dst = p.seg[0].dst;
             long long s_ld = p.seg[0].ld, s_plane = p.seg[0].plane;
             int s_off = p.seg[0].off, s_mode = p.seg[0].mode, s_c0 = p.seg[0].c0;
@@ -776,12 +791,200 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     conv_split_epilogue<TN, LDS_BYTES>(p, acc_main, acc_corr, lds, m0, n0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant 6 ("win", stride-1 convolutions with more than one tap): the implicit-GEMM kernels above fetch a
+// 128-pixel x 32-channel operand tile per TAP, i.e. every input element KH*KW times (from L2, but through the
+// texture/DMA path and LDS each time) -- for the 32..96-channel layers at 147^2..35^2 that traffic, not the
+// MFMAs, sets the pace.  Here the tile rows are 128 CONSECUTIVE PIXELS OF THE INPUT GRID and the taps are
+// plain row offsets (kh-PH)*W + (kw-PW) into one resident WINDOW of 128 + (KH-1)*W + (KW-1) grid pixels per
+// 32-channel block: the window is DMA'd once, all KH*KW taps read their fragments from it (LDS row = lane row +
+// tap offset), only the weight tile streams per tap.  Input traffic drops by KH*KW / (1 + ((KH-1)W+KW-1)/128):
+// 2.7x (3x3 @147), 4.2x (3x3 @73), 5.8x (3x3 @35), 11.8x (5x5 @35), 3.9x (7x1 @17).
+// Border handling: a "valid" convolution simply computes the few grid pixels without an output (y >= OH or
+// x >= OW, 2.7 % at 149->147) and drops them in the epilogue; a padded one masks, per lane and tap, the
+// fragments whose source pixel lies outside the image (bit mask over the taps built once per lane).
+// Channel blocks beyond Cin (Cin = 80: third block half empty) read the zero page; the weights are packed
+// [tap][Cin rounded up to 32] for this kernel.
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_split_win_kernel(const ConvArgs p, const int R16, const int ncb,
+                                                                const int nwin) {
+    constexpr int BN = 32 * TN;
+    constexpr int B_PLANE = BN * 64;
+    constexpr int BSTAGE = 2 * B_PLANE;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int win_plane = R16 * 64;                       // bytes per plane of one window buffer
+    const int win_bytes = 2 * win_plane;
+    unsigned char* bst = lds + nwin * win_bytes;          // two weight stages follow the window buffer(s)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.Cout + BN - 1) / BN;
+    const long long nwg = (long long)gridDim.x;
+    long long bid = blockIdx.x;
+    {
+        const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long tile_m = bid / tiles_n;
+    const int tile_n = (int)(bid - tile_m * tiles_n);
+    const long long m0 = tile_m * CS_BM;
+    const int n0 = tile_n * BN;
+    const long long mgrid = (long long)p.N * p.H * p.W;
+    const int ntaps = p.KH * p.KW;
+    const int cin_pad = ncb * CS_BK;
+    const int kwin = ntaps * cin_pad;                     // weight row length for this kernel
+    const int minoff = -p.PH * p.W - p.PW;
+
+    const int cl = (lane & 3) ^ ((lane >> 4) & 3);        // logical 16-byte chunk of this lane's DMA pieces
+    const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
+    const _Float16* wg = reinterpret_cast<const _Float16*>(p.w);
+    const _Float16* zp = reinterpret_cast<const _Float16*>(g_conv_zero_page);
+
+    // per-lane tap validity (padded convolutions): bit t set <=> tap t reads inside the image for this lane's pixel
+    unsigned tapmask = 0xffffffffu;
+    if (p.PH | p.PW) {
+        const long long g = m0 + wave * 32 + (lane & 31);
+        const long long hw = (long long)p.H * p.W;
+        const int rem = (int)(g % hw);
+        const int y = rem / p.W, x = rem - y * p.W;
+        tapmask = 0u;
+        for (int kh = 0, t = 0; kh < p.KH; ++kh)
+            for (int kw = 0; kw < p.KW; ++kw, ++t) {
+                const int yy = y + kh - p.PH, xx = x + kw - p.PW;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) tapmask |= 1u << t;
+            }
+    }
+
+    // DMA of one window (channel block cb) into window buffer wbuf: 2 planes x R16/16 pieces over 4 waves
+#define CW_WINDOW(CB, WBUF)                                                                               \
+    {                                                                                                     \
+        const int npieces = 2 * (R16 >> 4);                                                               \
+        const int c = (CB) * CS_BK + cl * 8;                                                               \
+        const bool c_ok = c < p.Cin;                                                                       \
+        for (int q = wave; q < npieces; q += 4) {                                                          \
+            const int plane = q >= (R16 >> 4) ? 1 : 0;                                                     \
+            const int rb = q - plane * (R16 >> 4);                                                         \
+            const long long g = m0 + minoff + rb * 16 + (lane >> 2);                                       \
+            const bool ok = c_ok && g >= 0 && g < mgrid;                                                   \
+            const _Float16* src = xg + (plane ? p.x_plane : 0) + g * p.Cin + c;                            \
+            src = ok ? src : zp;                                                                           \
+            unsigned char* dst = lds + (WBUF) * win_bytes + plane * win_plane + rb * 1024;                 \
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);                               \
+        }                                                                                                  \
+    }
+    // DMA of the weight tile of (channel block, tap) into weight stage SBUF
+#define CW_WEIGHTS(CB, TAP, SBUF)                                                                         \
+    _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                       \
+        const int q = wave * TN + i;                                                                       \
+        const int plane = q >= 2 * TN ? 1 : 0;                                                             \
+        const int rb = q - plane * 2 * TN;                                                                 \
+        const _Float16* sw_ = wg + (plane ? p.w_plane : 0) + (long long)(n0 + rb * 16 + (lane >> 2)) * kwin + \
+                              (TAP) * cin_pad + (CB) * CS_BK + cl * 8;                                     \
+        unsigned char* dw_ = bst + (SBUF) * BSTAGE + plane * B_PLANE + rb * 1024;                          \
+        __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)dw_, 16, 0, 0);                                   \
+    }
+
+    float16_t acc_main[TN], acc_corr[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc_main[t][j] = 0.f; acc_corr[t][j] = 0.f; }
+
+    const int lrow = wave * 32 + (lane & 31);             // this lane's tile row
+    const int fswz = ((lane & 31) >> 2) & 3;              // swizzle of the (row-aligned) weight tile
+    const int fb0 = (lane & 31) * 64 + ((lane >> 5) ^ fswz) * 16;
+    const int fb1 = (lane & 31) * 64 + ((2 + (lane >> 5)) ^ fswz) * 16;
+
+    CW_WINDOW(0, 0)
+    CW_WEIGHTS(0, 0, 0)
+    int cb = 0, tap = 0, kh = 0, kw = 0;
+    const int nsteps = ncb * ntaps;
+    for (int step = 0; step < nsteps; ++step) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (nwin == 1 && tap == 0 && cb > 0) {            // single window buffer: reload it between channel blocks
+            CW_WINDOW(cb, 0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // prefetch: next weight tile; at the first tap of a block also the next block's window
+        if (step + 1 < nsteps) {
+            const int ntap = tap + 1 == ntaps ? 0 : tap + 1;
+            const int ncbb = tap + 1 == ntaps ? cb + 1 : cb;
+            if ((step + 1) & 1) { CW_WEIGHTS(ncbb, ntap, 1) } else { CW_WEIGHTS(ncbb, ntap, 0) }
+        }
+        if (nwin > 1 && tap == 0 && cb + 1 < ncb) CW_WINDOW(cb + 1, (cb + 1) & 1)
+        // fragments of this tap: window row = tile row + tap offset
+        const int wrow = lrow + (kh - p.PH) * p.W + (kw - p.PW) - minoff;
+        const int aswz = (wrow >> 2) & 3;
+        const unsigned char* wb = lds + (nwin > 1 ? (cb & 1) : 0) * win_bytes + wrow * 64;
+        const unsigned char* bb = bst + (step & 1) * BSTAGE;
+        const unsigned am = (tapmask >> tap) & 1u ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ao = ((2 * s + (lane >> 5)) ^ aswz) * 16;
+            u32x4_t ah = *reinterpret_cast<const u32x4_t*>(wb + ao);
+            u32x4_t al = *reinterpret_cast<const u32x4_t*>(wb + win_plane + ao);
+            ah &= am; al &= am;
+            const half8_t a_hi = __builtin_bit_cast(half8_t, ah);
+            const half8_t a_lo = __builtin_bit_cast(half8_t, al);
+            const int fo = s ? fb1 : fb0;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const unsigned char* bp = bb + t * 32 * 64 + fo;
+                const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);
+                const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);
+                acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc_main[t], 0, 0, 0);
+                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc_corr[t], 0, 0, 0);
+                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc_corr[t], 0, 0, 0);
+            }
+        }
+        if (++tap == ntaps) { tap = 0; kh = 0; kw = 0; ++cb; }
+        else if (++kw == p.KW) { kw = 0; ++kh; }
+    }
+    __syncthreads();
+    conv_split_epilogue<TN, (1 << 30), CS_BM, true>(p, acc_main, acc_corr, lds, m0, n0);
+}
+
 extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     if (!args || !args->x || !args->w || !args->scale || !args->bias || (args->nseg & 0xff) < 1 || (args->nseg & 0xff) > 4 ||
-        args->Cin % 16 != 0 || args->Cin < 32 || args->Kpad % CS_BK != 0 || args->M <= 0)
+        args->Cin % 16 != 0 || args->Cin < 32 || (args->Kpad % CS_BK != 0 && !(tn & 256)) || args->M <= 0)
         return TISE_ERR_INVALID_ARG;
     const bool glds = (tn & (16 | 128)) != 0, glds3 = (tn & 32) != 0, gldsb = (tn & 64) != 0;
     const bool fast = (tn & 128) != 0 && args->Cin % 32 == 0 && args->K == args->Kpad;
+    if (tn & 256) {                                    // window kernel: stride 1, weights packed [tap][Cin_pad]
+        const int t = tn & 15;
+        if (args->SH != 1 || args->SW != 1 || args->KH * args->KW > 32 || t < 1 || t > 5) return TISE_ERR_INVALID_ARG;
+        const int ncb = (args->Cin + 31) / 32;
+        const int R = CS_BM + (args->KH - 1) * args->W + (args->KW - 1);
+        const int R16 = (R + 15) & ~15;
+        const int bnw = 32 * t;
+        // two window buffers (prefetch the next channel block) only while two workgroups still fit a CU
+        const int nwin = (ncb > 1 && 2 * (size_t)R16 * 128 + 2 * (size_t)bnw * 128 <= 80 * 1024) ? 2 : 1;
+        size_t lds = (size_t)nwin * R16 * 128 + 2 * (size_t)bnw * 128;
+        const size_t tb = (size_t)CS_BM * (bnw * 2 + 16);
+        if (lds < tb) lds = tb;
+        if (lds > 160 * 1024) return TISE_ERR_UNSUPPORTED;
+        const long long mg = (long long)args->N * args->H * args->W;
+        const long long tl = ((mg + CS_BM - 1) / CS_BM) * ((args->Cout + bnw - 1) / bnw);
+        if (tl > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
+        hipStream_t stw = (hipStream_t)stream;
+#define CW_LAUNCH(T)                                                                                          \
+        {                                                                                                     \
+            if (lds > 48 * 1024)                                                                              \
+                TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_win_kernel<T>),    \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+            hipLaunchKernelGGL(conv_split_win_kernel<T>, dim3((unsigned)tl), dim3(256), lds, stw, *args, R16, ncb, nwin); \
+        }
+        switch (t) {
+            case 1: CW_LAUNCH(1) break;
+            case 2: CW_LAUNCH(2) break;
+            case 3: CW_LAUNCH(3) break;
+            case 4: CW_LAUNCH(4) break;
+            default: CW_LAUNCH(5) break;
+        }
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
     tn &= 15;
     const int bn = 32 * tn;
     const int bm = glds3 ? 256 : CS_BM;
