@@ -474,6 +474,70 @@ def test_conv_split_window_kernel_matches_fp64_conv(dev, shape):
             assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
 
 
+@pytest.mark.parametrize("case", [
+    # (H, W, Cin, Cout, kh, kw, stride, pad, pipe_cfg)
+    (17, 17, 160, 160, 1, 7, 1, (0, 3), 0), (35, 35, 48, 64, 5, 5, 1, (2, 2), 2), (21, 19, 80, 192, 3, 3, 1, (0, 0), 1),
+    (35, 35, 288, 384, 3, 3, 2, (0, 0), 0), (8, 8, 320, 1344, 1, 1, 1, (0, 0), 8), (9, 9, 64, 80, 1, 1, 1, (0, 0), 9),
+    (11, 7, 32, 48, 3, 3, 1, (1, 1), 5), (13, 13, 96, 208, 1, 1, 1, (0, 0), 3), (12, 12, 64, 96, 3, 3, 1, (1, 1), 4),
+    (17, 17, 128, 192, 7, 1, 1, (3, 0), 11), (21, 19, 80, 192, 3, 3, 1, (0, 0), 12), (35, 35, 48, 64, 5, 5, 1, (2, 2), 13),
+    (23, 23, 32, 32, 3, 3, 1, (0, 0), 14), (19, 19, 96, 96, 3, 3, 1, (1, 1), 15), (17, 17, 192, 224, 1, 7, 1, (0, 3), 7)])
+def test_conv_pipe_kernels_match_fp64_conv(dev, case):
+    """conv_pipe.hip (persistent 3-stage kernel, lockstep and ping-pong schedules, and its window form): every tile
+    width / wave layout against an fp64 convolution: M tails, Cout tails, channel tails (80 -> 96, 48 -> 64),
+    padding, stride, three destination segments, run-to-run repeatability.  (More tiles than compute units:
+    test_conv_pipe_many_tiles_per_workgroup.)"""
+    from tise_toolbox_amd.conv_split import SplitConv, merge, split
+    H, W, Cin, Cout, kh, kw, st, pad, cfg = case
+    g = torch.Generator(device="cpu").manual_seed(Cin + Cout + kh + cfg)
+    n = 41                                                 # 41 * 17 * 17 = 11849 pixels = 47 tiles of 256
+    x = (torch.rand((n, H, W, Cin), generator=g) * 3.0).to(dev)
+    w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+    conv = SplitConv(w, b, (st, st), pad, dev, variant="pipe", pipe_cfg=cfg)
+    oh, ow = conv.out_hw(H, W)
+    ref_lin = torch.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, st, pad).permute(0, 2, 3, 1)
+    ref = torch.relu(ref_lin + b.double())
+    scale = ref.abs().max().item()
+    first = None
+    for rep in range(3):
+        out = torch.zeros((2, n, oh, ow, Cout + 32), dtype=torch.float16, device=dev)
+        raw = torch.zeros((n, oh, ow, 16), dtype=torch.float32, device=dev)
+        segs = [(0, 16, out, 16, 0), (16, 32, raw, 0, 1)] + ([(32, Cout, out, 64, 0)] if Cout > 32 else [])
+        conv(split(x), segs)
+        got = merge(out)
+        assert (got[..., 16:32].double() - ref[..., 0:16]).abs().max().item() <= 4e-6 * scale
+        if Cout > 32:
+            assert (got[..., 64:].double() - ref[..., 32:]).abs().max().item() <= 4e-6 * scale
+        assert (raw.double() - ref_lin[..., 16:32]).abs().max().item() <= 4e-6 * scale
+        assert got[..., :16].abs().max().item() == 0 and got[..., 32:64].abs().max().item() == 0
+        if first is None:
+            first = (out.clone(), raw.clone())
+        else:
+            assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
+
+
+def test_conv_pipe_many_tiles_per_workgroup(dev):
+    """More tiles than compute units: the persistent kernel's DMA cursor crosses tile boundaries ahead of the
+    MFMA cursor (12 and 3 K-steps per tile), compared bit for bit with the default kernel (same K order)."""
+    from tise_toolbox_amd.conv_split import SplitConv, split
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for (n, H, Cin, Cout, kh, cfg) in [(300, 17, 128, 128, 1, 0), (300, 17, 96, 160, 1, 1), (260, 9, 64, 64, 3, 2), (64, 35, 32, 64, 1, 8)]:
+        x = (torch.rand((n, H, H, Cin), generator=g) * 2.0).to(dev)
+        w = (torch.randn((Cout, Cin, kh, kh), generator=g) * (2.0 / (Cin * kh * kh)) ** 0.5).to(dev)
+        b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+        xs = split(x)
+        outs = []
+        for variant, c in (("fast", None), ("pipe", cfg)):
+            conv = SplitConv(w, b, (1, 1), (kh // 2, kh // 2), dev, variant=variant, pipe_cfg=c)
+            out = torch.zeros((2, n, H, H, Cout), dtype=torch.float16, device=dev)
+            conv(xs, [(0, Cout, out, 0, 0)])
+            outs.append(out)
+        assert (outs[0].float() - outs[1].float()).abs().max().item() <= 2e-3 * outs[0].float().abs().max().item()
+        from tise_toolbox_amd.conv_split import merge
+        d = (merge(outs[0]).double() - merge(outs[1]).double()).abs().max().item()
+        assert d <= 2e-6 * merge(outs[0]).abs().max().item(), d
+
+
 def test_split_trunk_batch_sizes_and_determinism(dev):
     """pool3 features must not depend on how images are batched, and must repeat bit for bit."""
     from tise_toolbox_amd.inception import InceptionV3

@@ -58,13 +58,29 @@ def pick_tn(cout):
     return best[1]
 
 
+# conv_pipe.hip tile widths by configuration index, and the configuration for a given Cout: least padded work,
+# ties to the wider tile
+PIPE_BN = {0: 128, 1: 96, 2: 64, 3: 160, 4: 64, 5: 32, 6: 128, 8: 128, 9: 96, 10: 64, 11: 128, 12: 96, 13: 64, 14: 32, 7: 128, 15: 96}
+
+
+def pick_pipe_cfg(cout):
+    best = None
+    for cfg in (0, 1, 2, 5):
+        bn = PIPE_BN[cfg]
+        work = -(-cout // bn) * bn
+        key = (work, -bn)
+        if best is None or key < best[0]:
+            best = (key, cfg)
+    return best[1]
+
+
 class SplitConv:
     """One (possibly channel-concatenated) convolution with folded scale/bias, packed for the kernel."""
 
     # measurement hook (bench.py): when a list, every launch appends (start_event, end_event, flop)
     timer = None
 
-    def __init__(self, weight, bias, stride, padding, device, tn=None, variant=None):
+    def __init__(self, weight, bias, stride, padding, device, tn=None, variant=None, pipe_cfg=None):
         """weight: (Cout, Cin, KH, KW) fp32 (BatchNorm already folded), bias: (Cout,) fp32."""
         cout, cin, kh, kw = weight.shape
         assert cin % 16 == 0 and cin >= 32, "conv_split needs Cin % 16 == 0 and Cin >= 32"
@@ -72,12 +88,16 @@ class SplitConv:
         self.stride = tuple(stride)
         self.padding = tuple(padding)
         self.tn = tn or pick_tn(cout)
+        self.pipe_cfg = None
         # kernel variant: "reg" register-staged (4 waves), "glds" direct-to-LDS 2-stage (4 waves),
         # "glds3" direct-to-LDS 3-stage, 8 waves, 256-pixel tile, "gldsb" weights straight to registers,
         # "fast" = glds with hoisted addressing (default), "win" = window-resident input for stride-1
         # multi-tap layers (A/B variant: measured equal to "fast" within +-3 %, profiles/r01g_conv_window_probe.txt)
         self.variant = variant or os.environ.get("TISE_CONV_VARIANT", "fast")
         bn = 32 * self.tn
+        if self.variant == "pipe":                              # persistent 3-stage kernel (conv_pipe.hip)
+            self.pipe_cfg = pick_pipe_cfg(cout) if pipe_cfg is None else pipe_cfg
+            bn = PIPE_BN[self.pipe_cfg]
         self.cout_pad = -(-cout // bn) * bn
         self.k = kh * kw * cin
         self.kpad = -(-self.k // 32) * 32
@@ -90,7 +110,7 @@ class SplitConv:
         self.w = split(wp).to(device).contiguous()                  # (2, Cout_pad, Kpad) fp16
         # window kernel (stride 1, more than one tap): weights packed [tap][Cin rounded up to 32]
         self.win = self.variant == "win" and self.stride == (1, 1) and kh * kw > 1
-        if self.win:
+        if self.win or self.pipe_cfg is not None:
             cin_pad = -(-cin // 32) * 32
             ww = torch.zeros((self.cout_pad, kh * kw, cin_pad), dtype=torch.float32)
             ww[:cout, :, :cin] = wk.reshape(cout, kh * kw, cin)
@@ -133,12 +153,19 @@ class SplitConv:
             else:
                 assert dst.dtype == torch.float32 and dst.shape[:3] == (n, oh, ow) and dst.is_contiguous()
                 s.ld, s.plane = dst.shape[3], 0
+        if getattr(self, "debug_ptr", None):                    # tools/conv_stamps.py
+            a.seg[3].dst = self.debug_ptr
         timer = SplitConv.timer
         if timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        flag = 256 if self.win else {"reg": 0, "glds": 16, "glds3": 32, "gldsb": 64, "fast": 128, "win": 128}[self.variant]
-        _lib.call("tise_conv_split_f16", ctypes.byref(a), self.tn | flag,
+        if self.pipe_cfg is not None:
+            code = 512 | self.pipe_cfg
+        elif self.win:
+            code = 256 | self.tn
+        else:
+            code = self.tn | {"reg": 0, "glds": 16, "glds3": 32, "gldsb": 64, "fast": 128, "win": 128}[self.variant]
+        _lib.call("tise_conv_split_f16", ctypes.byref(a), code,
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         if timer is not None:
             e1.record()

@@ -769,18 +769,21 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                 \
     }
 
+    // ablation switches for tools/conv_ablate.py (bits above the segment count; never set by the product path):
+    // 0x100 no DMA after the first stage, 0x200 no fragment reads / MFMAs, 0x400 no epilogue
+    const bool ab_dma = !(p.nseg & 0x100), ab_mma = !(p.nseg & 0x200);
     CF_TAP()
     CF_ISSUE(0)
     int step = 0;
     for (; step + 1 < nsteps; step += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        CF_ISSUE(STAGE)                                       // step+1 -> stage 1
-        CF_COMPUTE(0)
+        if (ab_dma) CF_ISSUE(STAGE)                           // step+1 -> stage 1
+        if (ab_mma) CF_COMPUTE(0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (step + 2 < nsteps) CF_ISSUE(0)                    // step+2 -> stage 0
-        CF_COMPUTE(STAGE)
+        if (step + 2 < nsteps && ab_dma) CF_ISSUE(0)          // step+2 -> stage 0
+        if (ab_mma) CF_COMPUTE(STAGE)
     }
     if (step < nsteps) {                                      // odd tail: its data sits in stage 0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -788,6 +791,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         CF_COMPUTE(0)
     }
     __syncthreads();
+    if ((p.nseg & 0x400) && p.M > 0) return;                  // (M > 0 always: keeps the accumulators live)
     conv_split_epilogue<TN, LDS_BYTES>(p, acc_main, acc_corr, lds, m0, n0);
 }
 
@@ -945,10 +949,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_win_kernel(const ConvArgs p
     conv_split_epilogue<TN, (1 << 30), CS_BM, true>(p, acc_main, acc_corr, lds, m0, n0);
 }
 
+int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream);   // conv_pipe.hip
+
 extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     if (!args || !args->x || !args->w || !args->scale || !args->bias || (args->nseg & 0xff) < 1 || (args->nseg & 0xff) > 4 ||
-        args->Cin % 16 != 0 || args->Cin < 32 || (args->Kpad % CS_BK != 0 && !(tn & 256)) || args->M <= 0)
+        args->Cin % 16 != 0 || args->Cin < 32 || (args->Kpad % CS_BK != 0 && !(tn & (256 | 512))) || args->M <= 0)
         return TISE_ERR_INVALID_ARG;
+    if (tn & 512) return tise_conv_pipe_launch(args, tn & 15, stream);   // persistent 3-stage kernel, weights [tap][Cin_pad]
     const bool glds = (tn & (16 | 128)) != 0, glds3 = (tn & 32) != 0, gldsb = (tn & 64) != 0;
     const bool fast = (tn & 128) != 0 && args->Cin % 32 == 0 && args->K == args->Kpad;
     if (tn & 256) {                                    // window kernel: stride 1, weights packed [tap][Cin_pad]
