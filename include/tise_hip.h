@@ -190,10 +190,21 @@ int tise_split_mean_nhwc(const void* x_dev, int64_t x_plane, int n, int hw, int 
  * Replaces the Conv2d + BatchNorm(eval) + ReLU of torchvision's BasicConv2d for NHWC tensors held as
  * two fp16 planes (v ~= hi + lo * 2^-11): D = max(scale * conv(x, w) + bias, 0), re-split and written
  * into up to four destination channel slices (mode 0), or raw fp32 scale*conv (mode 1, pool branch).
- * `args` points to a host-side tise_conv_args (copied into the launch).  tn in {2,3,4,5}: the output
- * tile is 128 pixels x 32*tn channels; weights must be padded to a multiple of 32*tn rows and of 32 in K.
- * tn | 16 selects the direct-to-LDS (global_load_lds) double-buffered variant of the same computation,
- * tn | 32 the 8-wave, 256-pixel-tile, three-stage variant (bitwise identical results).
+ * `args` points to a host-side tise_conv_args (copied into the launch).  `tn` = tile width | kernel variant:
+ * the low four bits give the output tile, 128 pixels x 32*tn channels with tn in {1..5} (tn = 1 only with the
+ * DMA variants); weights and scale/bias must be padded to a multiple of 32*tn rows and of 32 in K.
+ * Variant bits (same arithmetic; the first five give bit-identical results):
+ *   0    operands staged through registers          16   direct-to-LDS DMA, two stages
+ *   32   8 waves, 256-pixel tile, three stages      64   weights straight to registers
+ *   128  DMA with the address arithmetic hoisted out of the K loop when Cin % 32 == 0 (the default of the
+ *        Python layer; falls back to 16 otherwise)
+ *   256  window-resident input for stride-1 multi-tap convolutions; weights packed [cout][tap][Cin rounded
+ *        up to 32], K order (channel block, tap)
+ *   512  conv_pipe.hip: persistent 8-wave kernels, 256-pixel tiles, three stages; the low four bits then
+ *        select tile width / wave layout / schedule (see tise_conv_pipe_launch in conv_pipe.hip); weights
+ *        packed as for 256, rows padded to the configuration's tile width.
+ * Bits 8..11 of args->nseg are measurement switches (tools/conv_ablate.py, tools/conv_stamps.py) and must be
+ * zero in product calls.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int c0, c1;             /* output-channel range [c0, c1) of this segment                           */

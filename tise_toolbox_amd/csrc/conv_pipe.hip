@@ -33,6 +33,7 @@
 //        after its epilogue.
 #include <hip/hip_fp16.h>
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -46,24 +47,9 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __device__ __attribute__((aligned(64))) unsigned char g_pipe_zero_page[64];
 
-// Tile row -> output pixel index (or -1).  GRID = false: tile rows are output pixels.  GRID = true (window
-// kernel): tile rows are pixels of the INPUT grid (n, y, x); the output pixel is (n, y, x) when it exists.
-template <bool GRID>
-__device__ __forceinline__ long long pipe_out_pixel(const ConvArgs& p, long long g) {
-    if (!GRID) return g < p.M ? g : -1;
-    const long long hw = (long long)p.H * p.W;
-    if (g >= (long long)p.N * hw) return -1;
-    const long long n = g / hw;
-    const int rem = (int)(g - n * hw);
-    const int y = rem / p.W, x = rem - y * p.W;
-    if (y >= p.OH || x >= p.OW) return -1;
-    return (n * p.OH + y) * p.OW + x;
-}
-
 #define CP_BM 256
 #define CP_BK 32
-#define CP_TPITCH 144                    // staging row: 32 couts x 4 B + 16 B pad
-#define CP_TWAVE (32 * CP_TPITCH)        // staging bytes per wave (one 32 x 32 accumulator tile)
+#define CP_TWAVE (conv_epi::Staging<1>::BYTES)   // staging bytes per wave (one 32 x 32 accumulator tile)
 
 // WN waves along couts, 8 / WN along pixels; a wave owns TMW x TNW accumulator tiles of 32 x 32.
 template <int WN, int TMW, int TNW, bool PP>
@@ -258,69 +244,14 @@ __global__ __launch_bounds__(512, 1) void conv_pipe_kernel(const ConvArgs p, con
                 acc_corr[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pb_[s][t][0], pa_[s][i][1], acc_corr[i][t], 0, 0, 0); \
             }
 
-    // ---- epilogue of the tile c_v, staging through the stage at SB (private 4.5 KB per wave) ------------
-    // lane: pixel (lane & 31) of accumulator tile (i, t), couts 8*(j>>2) + 4*(lane>>5) + (j&3).
-    // staging row of a pixel: per 8-cout chunk k a 32-byte slot: [hi x8 | lo x8] (split segment) or fp32 x8.
-    const int nseg = p.nseg & 0xff;
-#define CP_SEG(COL, DST, LD, PLANE, OFF, MODE, C0)                                                        \
-    void* DST = p.seg[0].dst;                                                                             \
-    long long LD = p.seg[0].ld, PLANE = p.seg[0].plane;                                                   \
-    int OFF = p.seg[0].off, MODE = p.seg[0].mode, C0 = p.seg[0].c0;                                       \
-    _Pragma("unroll") for (int s_ = 1; s_ < 4; ++s_)                                                       \
-        if (s_ < nseg && (COL) >= p.seg[s_].c0) {                                                          \
-            DST = p.seg[s_].dst; LD = p.seg[s_].ld; PLANE = p.seg[s_].plane;                               \
-            OFF = p.seg[s_].off; MODE = p.seg[s_].mode; C0 = p.seg[s_].c0;                                 \
-        }
+    // ---- epilogue of the tile c_v, staging through the stage at SB (private 4.5 KB per wave): conv_epilogue.h
 #define CP_EPILOGUE(SB)                                                                                   \
     {                                                                                                     \
         const long long tm_ = c_v / tiles_n;                                                              \
         const int n0 = (int)(c_v - tm_ * tiles_n) * BN;                                                   \
         const long long m0 = tm_ * CP_BM;                                                                 \
-        unsigned char* tw = (SB) + wave * CP_TWAVE;                                                        \
-        _Pragma("unroll") for (int i = 0; i < TMW; ++i)                                                    \
-            _Pragma("unroll") for (int t = 0; t < TNW; ++t) {                                              \
-                const int cb0 = n0 + (wn * TNW + t) * 32;                                                  \
-                unsigned char* trow = tw + (lane & 31) * CP_TPITCH;                                        \
-                _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                            \
-                    const int ch = cb0 + 8 * g + 4 * (lane >> 5);                                          \
-                    const float4_t sc = *reinterpret_cast<const float4_t*>(p.scale + ch);                  \
-                    const float4_t bs = *reinterpret_cast<const float4_t*>(p.bias + ch);                   \
-                    CP_SEG(ch, sd_, sl_, sp_, so_, smode, sc0_)                                            \
-                    (void)sd_; (void)sl_; (void)sp_; (void)so_; (void)sc0_;                                \
-                    float4_t v;                                                                            \
-                    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                          \
-                        v[k] = (acc_main[i][t][4 * g + k] + acc_corr[i][t][4 * g + k] * (1.0f / 2048.0f)) * sc[k]; \
-                    if (smode == 0) {                                                                      \
-                        half4_t hi, lo;                                                                    \
-                        _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                    \
-                            const float r = fmaxf(v[k] + bs[k], 0.f);                                      \
-                            hi[k] = (_Float16)r;                                                           \
-                            lo[k] = (_Float16)((r - (float)hi[k]) * 2048.0f);                              \
-                        }                                                                                  \
-                        *reinterpret_cast<half4_t*>(trow + g * 32 + (lane >> 5) * 8) = hi;                 \
-                        *reinterpret_cast<half4_t*>(trow + g * 32 + 16 + (lane >> 5) * 8) = lo;            \
-                    } else {                                                                               \
-                        *reinterpret_cast<float4_t*>(trow + g * 32 + (lane >> 5) * 16) = v;                \
-                    }                                                                                      \
-                }                                                                                          \
-                /* same wave wrote and reads: LDS executes a wave's operations in order */                 \
-                _Pragma("unroll") for (int r4 = 0; r4 < 4; ++r4) {                                         \
-                    const int row = r4 * 8 + (lane >> 3), q = lane & 7;                                    \
-                    const int col = cb0 + 8 * (q >> 1);                                                    \
-                    const long long pp = pipe_out_pixel<EPI_GRID>(p, m0 + (wm * TMW + i) * 32 + row);      \
-                    const u32x4_t val = *reinterpret_cast<const u32x4_t*>(tw + row * CP_TPITCH + q * 16);  \
-                    CP_SEG(col, sd_, sl_, sp_, so_, smode, sc0_)                                           \
-                    if (col < p.Cout && pp >= 0) {                                                         \
-                        if (smode == 0) {                                                                  \
-                            _Float16* d = reinterpret_cast<_Float16*>(sd_) + ((q & 1) ? sp_ : 0) + pp * sl_ + so_ + (col - sc0_); \
-                            *reinterpret_cast<u32x4_t*>(d) = val;                                          \
-                        } else {                                                                           \
-                            float* d = reinterpret_cast<float*>(sd_) + pp * sl_ + so_ + (col - sc0_) + 4 * (q & 1); \
-                            *reinterpret_cast<u32x4_t*>(d) = val;                                          \
-                        }                                                                                  \
-                    }                                                                                      \
-                }                                                                                          \
-            }                                                                                              \
+        conv_epi::store_tiles<TMW, TNW, EPI_GRID, 1>(p, acc_main, acc_corr, (SB) + wave * CP_TWAVE,       \
+                                                     m0 + wm * TMW * 32, n0 + wn * TNW * 32);             \
     }
 
     // ---- pipeline -----------------------------------------------------------------------------------
@@ -725,7 +656,6 @@ __global__ __launch_bounds__(512, 1) void conv_pipew_kernel(const ConvArgs p, co
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    const int nseg = p.nseg & 0xff;
     CP_EPILOGUE(lds)
 }
 

@@ -25,6 +25,7 @@
 // fetched with global_load_lds).
 #include <hip/hip_fp16.h>
 #include "common.h"
+#include "conv_epilogue.h"
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
@@ -338,11 +339,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs 
         if (a_c >= p.Cin) { a_c -= p.Cin; if (++a_kw == p.KW) { a_kw = 0; ++a_kh; } }                      \
     }
 
-    float16_t acc_main[TN], acc_corr[TN];
+    float16_t acc_main[1][TN], acc_corr[1][TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { acc_main[t][j] = 0.f; acc_corr[t][j] = 0.f; }
+        for (int j = 0; j < 16; ++j) { acc_main[0][t][j] = 0.f; acc_corr[0][t][j] = 0.f; }
 
     const int nsteps = p.Kpad / CS_BK;
     // fragment read: row (lane & 31) of a 32-row block, logical chunk 2*s + (lane >> 5), swizzled
@@ -365,14 +366,17 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs 
                 const unsigned char* bp = cur + 2 * A_PLANE + t * 32 * 64 + frow + choff;
                 const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);
                 const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);
-                acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc_main[t], 0, 0, 0);
-                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc_corr[t], 0, 0, 0);
-                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc_corr[t], 0, 0, 0);
+                // weight fragment first: the accumulator is D[cout][pixel] (conv_epilogue.h)
+                acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_hi, acc_main[0][t], 0, 0, 0);
+                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo, a_hi, acc_corr[0][t], 0, 0, 0);
+                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_lo, acc_corr[0][t], 0, 0, 0);
             }
         }
     }
     __syncthreads();                                           // all fragment reads done before LDS is reused
-    conv_split_epilogue<TN, LDS_BYTES>(p, acc_main, acc_corr, lds, m0, n0);
+    constexpr int ETW = TN > 1 ? 2 : 1;                       // accumulator tiles staged together: 128-byte runs
+    static_assert(4 * conv_epi::Staging<ETW>::BYTES <= LDS_BYTES, "epilogue staging must fit the operand LDS");
+    conv_epi::store_tiles<1, TN, false, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, m0 + wave * 32, n0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -719,11 +723,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         }                                                                                                  \
     }
 
-    float16_t acc_main[TN], acc_corr[TN];
+    float16_t acc_main[1][TN], acc_corr[1][TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { acc_main[t][j] = 0.f; acc_corr[t][j] = 0.f; }
+        for (int j = 0; j < 16; ++j) { acc_main[0][t][j] = 0.f; acc_corr[0][t][j] = 0.f; }
 
     const int nsteps = p.K / CS_BK;                           // K = KH*KW*Cin is a multiple of 32 here
     // fragment read offsets: row (lane & 31), logical chunk 2*s + (lane >> 5), swizzled with (row >> 2) & 3
@@ -751,9 +755,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         }                                                                                                  \
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \
             _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
-                acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[s][0], fb_[s][t][0], acc_main[t], 0, 0, 0); \
-                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[s][0], fb_[s][t][1], acc_corr[t], 0, 0, 0); \
-                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa_[s][1], fb_[s][t][0], acc_corr[t], 0, 0, 0); \
+                /* weight fragment first: the accumulator is D[cout][pixel] (conv_epilogue.h) */                \
+                acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][0], acc_main[0][t], 0, 0, 0); \
+                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][1], fa_[s][0], acc_corr[0][t], 0, 0, 0); \
+                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][1], acc_corr[0][t], 0, 0, 0); \
             }                                                                                              \
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);             /* a(s0), b(s0, t0) */              \
         _Pragma("unroll") for (int i = 0; i < TN - 1; ++i) {                                               \
@@ -792,7 +797,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     }
     __syncthreads();
     if ((p.nseg & 0x400) && p.M > 0) return;                  // (M > 0 always: keeps the accumulators live)
-    conv_split_epilogue<TN, LDS_BYTES>(p, acc_main, acc_corr, lds, m0, n0);
+    constexpr int ETW = TN > 1 ? 2 : 1;                       // accumulator tiles staged together: 128-byte runs
+    static_assert(4 * conv_epi::Staging<ETW>::BYTES <= LDS_BYTES, "epilogue staging must fit the operand LDS");
+    conv_epi::store_tiles<1, TN, false, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, m0 + wave * 32, n0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense a rocprofv3 --kernel-trace --stats run into a small committed summary.
 
-usage: summarize_prof.py <dir with *_kernel_stats.csv and *_kernel_trace.csv> <out.md> [K steps]
+usage: summarize_prof.py <dir with *_kernel_stats.csv and *_kernel_trace.csv, or a rocpd *_results.db> <out.md> [K steps]
 Two tables: (1) the library's hand-written kernels over the whole run (calls, total, avg, min, max);
 (2) steady-state per-step breakdown of the LAST K steps of the timed loop (window from the K-th last
 resize kernel to the first pchol_init after it), which excludes MIOpen's find-mode trial kernels."""
@@ -9,29 +9,54 @@ import collections
 import csv
 import glob
 import os
+import re
 import sys
+
+
+def short(name):
+    """Kernel name without the anonymous-namespace prefix, arguments or Itanium mangling."""
+    m = re.match(r"_ZN12_GLOBAL__N_1(\d+)", name)
+    if m:
+        k = int(m.group(1))
+        return name[m.end():m.end() + k]
+    return name.replace("(anonymous namespace)::", "").split("(")[0]
 
 MINE = ("syrk_f32", "colsum", "stats_finalize", "resize_bilinear", "is_row", "is_col", "is_final", "pchol", "sytrd",
         "bisect", "gershgorin", "gemm_f64", "symmetrize", "frechet_finish", "axpy", "zero_rows", "bias_relu",
-        "avgpool", "maxpool", "tise_")
+        "avgpool", "maxpool", "tise_", "conv_split", "conv_pipe", "stem_conv", "split_mean")
 
 
 def main():
     d, out = sys.argv[1], sys.argv[2]
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-    stats = glob.glob(os.path.join(d, "*kernel_stats.csv"))[0]
-    trace = glob.glob(os.path.join(d, "*kernel_trace.csv"))[0]
-    rows = list(csv.DictReader(open(stats)))
+    dbs = glob.glob(os.path.join(d, "*_results.db"))
+    if dbs and not glob.glob(os.path.join(d, "*kernel_stats.csv")):
+        # rocprofv3's default output (rocpd sqlite): rebuild the two CSV views from the `kernels` view
+        import sqlite3
+        con = sqlite3.connect(dbs[0])
+        disp = con.execute("select name, start, end from kernels").fetchall()
+        per = collections.defaultdict(list)
+        for n, s0, e0 in disp:
+            per[n].append(e0 - s0)
+        rows = [{"Name": n, "Calls": len(v), "TotalDurationNs": sum(v), "AverageNs": sum(v) / len(v), "MinNs": min(v),
+                 "MaxNs": max(v)} for n, v in sorted(per.items(), key=lambda kv: -sum(kv[1]))]
+        stats = dbs[0]
+        trace_rows = [{"Start_Timestamp": s0, "End_Timestamp": e0, "Kernel_Name": n} for n, s0, e0 in disp]
+    else:
+        stats = glob.glob(os.path.join(d, "*kernel_stats.csv"))[0]
+        trace = glob.glob(os.path.join(d, "*kernel_trace.csv"))[0]
+        rows = list(csv.DictReader(open(stats)))
+        trace_rows = list(csv.DictReader(open(trace)))
     lines = ["# rocprofv3 --kernel-trace --stats summary", "", f"source: `{os.path.basename(stats)}`", "",
              "## hand-written kernels (whole run)", "",
              "| kernel | calls | total ms | avg us | min us | max us |", "|---|---:|---:|---:|---:|---:|"]
     for r in rows:
         if any(k in r["Name"] for k in MINE):
-            name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0]
+            name = short(r["Name"])
             lines.append(f"| {name} | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e3:.2f} | "
                          f"{float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} |")
     tr = []
-    for r in csv.DictReader(open(trace)):
+    for r in trace_rows:
         tr.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     tr.sort()
     res = [i for i, r in enumerate(tr) if "resize_bilinear" in r[2]]
@@ -48,7 +73,7 @@ def main():
             elif n.startswith("igemm"):
                 key = "MIOpen: igemm_fwd_gtcx35_nhwc_fp32 asm conv"
             else:
-                key = n.replace("(anonymous namespace)::", "").split("(")[0][:80]
+                key = short(n)[:80]
             agg[key] += (e - s) / 1e6
             cnt[key] += 1
         lines += ["", f"## steady state: last {K} steps of the timed loop", "",
