@@ -186,6 +186,20 @@ int tise_stem_conv3x3s2_split(const float* x_dev, int n, int h, int w, const flo
 int tise_split_mean_nhwc(const void* x_dev, int64_t x_plane, int n, int hw, int C, float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * (a11, section 8 f3) Top-1 text retrieval for R-precision and the 2-way softmax test of PA.
+ * Replaces the tail of the per-item loop of text_relevance/RP_coco.py:72-78 (logits_per_image ->
+ * softmax -> argmax == 0) and positional_alignment/PA.py:37-42 (softmax[0] > 0.6) for n items at once.
+ * img_emb: (n, d); txt_emb: a table of DISTINCT caption embeddings (rows, d); txt_index: (n, c) int32 rows of
+ * that table, candidate 0 = the true caption (NULL: item i's candidates are table rows i*c .. i*c+c-1).
+ * dtype 0 = fp32, 1 = fp16 embeddings; normalize != 0 divides by both norms (cosine), 0 takes the dot product
+ * of already normalised features as CLIP.forward does.  top1_out[i] = first argmax_j of
+ * logit_scale * <img_i, txt_j>; p0_out (nullable) = softmax over the c candidates, entry 0.
+ * ------------------------------------------------------------------------------------------ */
+int tise_cosine_top1(const void* img_emb_dev, const void* txt_emb_dev, const int32_t* txt_index_dev, int64_t n, int c,
+                     int d, int dtype, int normalize, float logit_scale, int32_t* top1_out_dev, float* p0_out_dev,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * (a5, convolution) Implicit-GEMM convolution on fp16 MFMA with 3-term split-precision operands.
  * Replaces the Conv2d + BatchNorm(eval) + ReLU of torchvision's BasicConv2d for NHWC tensors held as
  * two fp16 planes (v ~= hi + lo * 2^-11): D = max(scale * conv(x, w) + bias, 0), re-split and written

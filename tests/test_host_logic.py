@@ -154,3 +154,64 @@ def test_dataset_yields_uint8_hwc(tmp_path):
     np.testing.assert_array_equal(items["gray.png"].numpy()[..., 2], a[..., 0])
     assert isinstance(img_data.collate_u8([items["a.png"], items["gray.png"]]), torch.Tensor)
     assert isinstance(img_data.collate_u8([items["a.png"], items["a.png"][:10]]), list)
+
+
+# ------------------------------------------------------------------------------------------- RP-COCO host logic (f3)
+@pytest.mark.parametrize("name", ["rp_stub_57x10.npz", "rp_stub_40x100.npz"])
+def test_rp_host_logic_matches_reference_script_run(golden_dir, name):
+    """Bins, success counting, mean / std and the result text of tise_toolbox_amd.RP_coco against what the
+    reference script wrote (stub CLIP, tests/golden/make_golden_rp.py); the success flags come from the fixture's
+    logits here, from csrc/retrieval.hip in the GPU test."""
+    from tise_toolbox_amd import RP_coco
+    g = np.load(os.path.join(golden_dir, name))
+    success = (np.argmax(g["logits"], axis=1) == 0).astype(np.int64)
+    mean, std, scores = RP_coco.r_precision_from_success(success, g["perm"].tolist())
+    assert f"R-precision: {mean} +- {std}" == str(g["expected_text"])
+    import random
+    random.seed(int(g["seed"]))
+    ids = list(range(int(g["n_items"])))
+    random.shuffle(ids)
+    assert ids == g["perm"].tolist() == RP_coco.shuffled_ids(int(g["n_items"]), int(g["seed"]))
+
+
+def test_rp_caption_table_dedup():
+    from tise_toolbox_amd import RP_coco
+    items = [{"caption_id": 1, "caption": "a", "mismatched_captions": ["b", "c"]},
+             {"caption_id": 2, "caption": "b", "mismatched_captions": ["a", "d"]}]
+    caps, idx = RP_coco.caption_table(items)
+    assert caps == ["a", "b", "c", "d"] and idx.dtype == np.int32
+    assert idx.tolist() == [[0, 1, 2], [1, 0, 3]]
+    with pytest.raises(ValueError):
+        RP_coco.caption_table(items + [{"caption_id": 3, "caption": "e", "mismatched_captions": ["a"]}])
+
+
+def test_clip_towers_have_the_published_shape():
+    from tise_toolbox_amd import clip_model
+    m = clip_model.build_clip(seed=1)
+    assert sum(p.numel() for p in m.parameters()) == 151277313          # ViT-B/32 CLIP
+    keys = set(m.state_dict())
+    for k in ("visual.conv1.weight", "visual.class_embedding", "visual.positional_embedding", "visual.proj",
+              "visual.transformer.resblocks.11.attn.in_proj_weight", "visual.transformer.resblocks.0.mlp.c_fc.weight",
+              "transformer.resblocks.11.attn.out_proj.bias", "token_embedding.weight", "positional_embedding",
+              "ln_final.weight", "text_projection", "logit_scale"):
+        assert k in keys, k
+    assert m.visual.positional_embedding.shape == (50, 768) and m.positional_embedding.shape == (77, 512)
+
+
+def test_bpe_tokenizer_on_synthetic_merges(tmp_path):
+    import gzip
+    from tise_toolbox_amd import clip_model
+    merges = ["#version: synthetic", "r e", "re d</w>", "b u", "bu s</w>", "t h", "th e</w>"]
+    path = tmp_path / "bpe.txt.gz"
+    with gzip.open(path, "wb") as f:
+        f.write("\n".join(merges).encode())
+    tok = clip_model.BPETokenizer(str(path))
+    n_base = 512
+    assert tok.encoder["red</w>"] == n_base + 1 and tok.encoder["bus</w>"] == n_base + 3
+    ids = tok.encode("The  RED bus")
+    assert ids == [tok.encoder["the</w>"], tok.encoder["red</w>"], tok.encoder["bus</w>"]]
+    out = tok(["the red bus", "bus"])
+    assert out.shape == (2, 77) and out[0, 0] == tok.encoder["<|startoftext|>"] and out[1, 2] == tok.encoder["<|endoftext|>"]
+    assert out[0, 5:].sum() == 0
+    with pytest.raises(RuntimeError):
+        tok(["bus " * 100])

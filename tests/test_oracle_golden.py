@@ -120,3 +120,31 @@ def test_d2048_cases_regenerate(golden_dir):
         np.testing.assert_allclose(s1[:4, :4], g["sigma1_probe"], rtol=1e-12)
         np.testing.assert_allclose(s2[:4, :4], g["sigma2_probe"], rtol=1e-12)
         assert np.trace(s1) == pytest.approx(float(g["trace1"]), rel=1e-12)
+
+
+# ------------------------------------------------------------------------------------------- RP / PA reductions
+@pytest.mark.parametrize("name", ["rp_stub_57x10.npz", "rp_stub_40x100.npz"])
+def test_rp_oracle_matches_reference_script_run(golden_dir, name):
+    """Fixture = what text_relevance/RP_coco.py itself wrote when run with a stub CLIP (make_golden_rp.py)."""
+    from oracle import rp_oracle
+    g = np.load(os.path.join(golden_dir, name))
+    success = rp_oracle.rp_success_from_logits(g["logits"])
+    mean, std, scores = rp_oracle.rp_score(success, g["perm"].tolist())
+    assert rp_oracle.rp_text(mean, std) == str(g["expected_text"])
+    assert len(scores) == 10
+
+
+def test_rp_bins_remainder_rule():
+    from oracle import rp_oracle
+    bins = rp_oracle.rp_bins(57, list(range(57)))
+    assert [len(b) for b in bins] == [5] * 9 + [12]
+    bins = rp_oracle.rp_bins(40, list(range(40)))
+    assert [len(b) for b in bins] == [4] * 10
+
+
+def test_pa_oracle_matches_reference_script_run(golden_dir):
+    import json
+    from oracle import rp_oracle
+    g = json.load(open(os.path.join(golden_dir, "pa_stub.json")))
+    pa, per = rp_oracle.pa_score({p: np.array(g["logits"][p]) for p in g["phrases"]})
+    assert f"PA = {pa}" == g["expected_text"]

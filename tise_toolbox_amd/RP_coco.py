@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""R-precision on COCO captions: drop-in for text_relevance/RP_coco.py.
+
+Same CLI (RP_coco.py:17-25: --image_dir --rp_input_file --saved_file_path --gpu_id), same input pickle (list of
+{caption_id, caption, mismatched_captions}), same bins (:41-52), same success rule (:72-78), same result text
+(:85-90).  What changes is the order of work: the reference runs CLIP once per item with batch 1 on the image and
+~100 captions (30 k items -> 3 M text-tower passes); here
+    1. the DISTINCT captions of the whole input are tokenised and embedded once, in batches (text table),
+    2. the images are embedded in batches,
+    3. csrc/retrieval.hip scores all items at once against int32 index lists into the text table.
+The shuffle that forms the bins is unseeded in the reference (:43); `--seed` makes it reproducible (default: unseeded
+like the reference).  The towers are clip_model.py (see its header: scaffolding on library kernels, parity unpinned).
+"""
+import argparse
+import os
+import pickle
+import random
+
+import numpy as np
+import torch
+
+from . import _lib, clip_model, device
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description="Calculating R-precision")
+    parser.add_argument("--image_dir", default="", type=str, help="Path to the folder containing generated images.")
+    parser.add_argument("--rp_input_file", default="captions/COCO_RP_captions.pkl", type=str)
+    parser.add_argument("--saved_file_path", default=None, type=str, help="Path to file saving result")
+    parser.add_argument("--gpu_id", default="0", type=str)
+    parser.add_argument("--weights", default=None, type=str, help="OpenAI CLIP ViT-B/32 state_dict (.pt); seeded stand-in otherwise")
+    parser.add_argument("--vocab", default=None, type=str, help="bpe_simple_vocab_16e6.txt.gz; word-hash stand-in otherwise")
+    parser.add_argument("--seed", default=None, type=int, help="seed of the bin shuffle (reference: unseeded)")
+    parser.add_argument("--batch-size", default=256, type=int)
+    return parser.parse_args(argv)
+
+
+def make_bins(num_captions, perm, num_bins=10):
+    """RP_coco.py:41-52."""
+    samples_per_bin = int(len(perm) / num_bins)
+    bins = []
+    for i in range(num_bins):
+        if i == (num_bins - 1) and num_captions % num_bins != 0:
+            bins.append(perm[i * samples_per_bin:])
+        else:
+            bins.append(perm[i * samples_per_bin:(i + 1) * samples_per_bin])
+    return bins
+
+
+def shuffled_ids(num_captions, seed=None):
+    ids = list(range(num_captions))
+    (random.Random(seed) if seed is not None else random).shuffle(ids)
+    return ids
+
+
+def caption_table(rp_input):
+    """Distinct captions and the (N, 1 + mismatched) int32 index lists, candidate 0 = the true caption (:68-70).
+    Items must carry the same number of mismatched captions (they do in COCO_RP_captions.pkl: 99)."""
+    table, index = {}, []
+    for item in rp_input:
+        row = [table.setdefault(c, len(table)) for c in [item["caption"]] + list(item["mismatched_captions"])]
+        index.append(row)
+    widths = {len(r) for r in index}
+    if len(widths) != 1:
+        raise ValueError(f"items carry different numbers of candidate captions: {sorted(widths)}")
+    return list(table), np.asarray(index, dtype=np.int32)
+
+
+def r_precision_from_success(success, perm, num_bins=10):
+    """success: (N,) 0/1 per item.  Returns (mean, std, bin scores) as RP_coco.py:79-84."""
+    success = np.asarray(success)
+    scores = []
+    for b in make_bins(len(success), perm, num_bins):
+        scores.append(int(success[np.asarray(b, dtype=np.int64)].sum()) * 1.0 / len(b))
+    return np.mean(scores), np.std(scores), scores
+
+
+def r_precision(img_emb, txt_emb, txt_index, perm, normalize=True, logit_scale=100.0, num_bins=10):
+    """Embeddings on the GPU -> (mean, std, bin scores); the scoring runs in csrc/retrieval.hip."""
+    top1, _ = device.cosine_top1(img_emb, txt_emb, txt_index, normalize=normalize, logit_scale=logit_scale, want_p0=False)
+    return r_precision_from_success((top1 == 0).cpu().numpy().astype(np.int64), perm, num_bins)
+
+
+@torch.no_grad()
+def embed_texts(model, tokenizer, captions, dev, batch):
+    out = []
+    for i in range(0, len(captions), batch):
+        tok = tokenizer(captions[i:i + batch]).to(dev)
+        f = model.encode_text(tok)
+        out.append(f / f.norm(dim=-1, keepdim=True))
+    return torch.cat(out).contiguous()
+
+
+class _Images(torch.utils.data.Dataset):
+    def __init__(self, image_dir, ids):
+        self.image_dir, self.ids = image_dir, ids
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, i):
+        from PIL import Image
+        return clip_model.preprocess(Image.open(os.path.join(self.image_dir, str(self.ids[i]) + ".png")).convert("RGB"))
+
+
+@torch.no_grad()
+def embed_images(model, image_dir, caption_ids, dev, batch, workers=8):
+    loader = torch.utils.data.DataLoader(_Images(image_dir, caption_ids), batch_size=batch, shuffle=False, num_workers=workers)
+    out = []
+    for x in loader:
+        f = model.encode_image(x.to(dev).to(next(model.parameters()).dtype))
+        out.append(f / f.norm(dim=-1, keepdim=True))
+    return torch.cat(out).contiguous()
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if not torch.cuda.is_available():
+        raise _lib.TiseLibraryError("RP_coco needs an MI355X: there is no CPU path")
+    dev = torch.device(f"cuda:{args.gpu_id}")
+    model = clip_model.build_clip(args.weights).to(dev).half()         # clip.load on a GPU serves fp16 weights
+    tokenizer = clip_model.BPETokenizer(args.vocab) if args.vocab else clip_model.HashTokenizer()
+    with open(args.rp_input_file, "rb") as f:
+        rp_input = pickle.load(f)
+    captions, index = caption_table(rp_input)
+    txt = embed_texts(model, tokenizer, captions, dev, args.batch_size)
+    img = embed_images(model, args.image_dir, [it["caption_id"] for it in rp_input], dev, args.batch_size)
+    perm = shuffled_ids(len(rp_input), args.seed)
+    scale = float(model.logit_scale.detach().exp())
+    # features are already normalised in the model's dtype, as CLIP.forward does before the matmul
+    mean, std, scores = r_precision(img, txt, torch.from_numpy(index).to(dev), perm, normalize=False, logit_scale=scale)
+    for bin_idx, s in enumerate(scores):
+        print(f"Bin: {bin_idx}, RP: {s}")
+    print(f"R-precision: {mean} +- {std}")
+    if args.saved_file_path is not None:
+        with open(args.saved_file_path, "w") as f:
+            f.write(f"R-precision: {mean} +- {std}")
+    return mean, std
+
+
+if __name__ == "__main__":
+    main()

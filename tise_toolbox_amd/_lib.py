@@ -39,6 +39,8 @@ SIGNATURES = {
     "tise_device_info": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]),
     "tise_resize_bilinear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                          POINTER(c_float), c_void_p, c_void_p]),
+    "tise_cosine_top1": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                  c_void_p, c_void_p]),
     "tise_stats_create": (c_int, [c_int, POINTER(c_void_p)]),
     "tise_stats_destroy": (c_int, [c_void_p]),
     "tise_stats_reset": (c_int, [c_void_p, c_void_p]),

@@ -270,3 +270,29 @@ def gemm_f64(a, b):
     _lib.call("tise_gemm_f64", _ptr(a), a.stride(0), a.stride(1), _ptr(b), b.stride(0), b.stride(1), _ptr(c), n,
               m, n, k, _stream())
     return c
+
+
+def cosine_top1(img_emb, txt_emb, txt_index=None, normalize=True, logit_scale=100.0, want_p0=True):
+    """Top-1 text retrieval (RP_coco.py:72-78 / PA.py:37-42) for all items at once.
+
+    img_emb (n, d), txt_emb (rows, d): fp32 or fp16 device tensors; txt_index (n, c) int32 rows of txt_emb per item,
+    candidate 0 = true caption (None: txt_emb is (n*c, d), item-major).  Returns (top1 int32 (n,), p0 fp32 (n,) or None).
+    """
+    _require_cuda(img_emb, txt_emb, txt_index)
+    assert img_emb.dim() == 2 and txt_emb.dim() == 2 and img_emb.shape[1] == txt_emb.shape[1]
+    assert img_emb.dtype == txt_emb.dtype and img_emb.dtype in (torch.float32, torch.float16)
+    img_emb, txt_emb = img_emb.contiguous(), txt_emb.contiguous()
+    n, d = img_emb.shape
+    if txt_index is not None:
+        assert txt_index.dtype == torch.int32 and txt_index.dim() == 2 and txt_index.shape[0] == n
+        txt_index = txt_index.contiguous()
+        c = txt_index.shape[1]
+    else:
+        assert txt_emb.shape[0] % max(n, 1) == 0
+        c = txt_emb.shape[0] // max(n, 1)
+    top1 = torch.empty(n, dtype=torch.int32, device=img_emb.device)
+    p0 = torch.empty(n, dtype=torch.float32, device=img_emb.device) if want_p0 else None
+    _lib.call("tise_cosine_top1", _ptr(img_emb), _ptr(txt_emb), _ptr(txt_index) if txt_index is not None else None,
+              ctypes.c_int64(n), int(c), int(d), 0 if img_emb.dtype == torch.float32 else 1, 1 if normalize else 0,
+              ctypes.c_float(logit_scale), _ptr(top1), _ptr(p0) if p0 is not None else None, _stream())
+    return top1, p0

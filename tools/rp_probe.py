@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Measurement for the RP-COCO row (section 8 f3, BASELINE config 4 shape: 30 k items x 100 captions, 512-d):
+the retrieval kernel against its gather-byte roofline, and the stand-in CLIP towers' batch throughput."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tise_toolbox_amd import clip_model, device
+
+dev = torch.device("cuda:0")
+n, c, d = 30000, 100, 512
+for dtype, eb in ((torch.float16, 2), (torch.float32, 4)):
+    for rows, label in ((40000, "de-duplicated table, 40 k distinct captions"), (n * c, "no de-duplication, 3 M rows")):
+        img = torch.randn((n, d), device=dev).to(dtype)
+        txt = torch.randn((rows, d), device=dev).to(dtype)
+        idx = torch.randint(0, rows, (n, c), device=dev, dtype=torch.int32) if rows != n * c else None
+        for _ in range(2):
+            device.cosine_top1(img, txt, idx)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            device.cosine_top1(img, txt, idx)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        gb = (n * c * d * eb + n * d * eb + (n * c * 4 if idx is not None else 0)) / 1e9
+        print(f"cosine_top1 {str(dtype):14s} {label:46s} {ms:7.3f} ms  {gb / ms * 1e3:7.0f} GB/s gathered  ({n / ms * 1e3 / 1e6:.1f} M items/s)", flush=True)
+        del img, txt, idx
+model = clip_model.build_clip().to(dev).half()
+tok = clip_model.HashTokenizer()
+caps = [f"a photo of item number {i} on the grass" for i in range(2048)]
+with torch.no_grad():
+    t = tok(caps).to(dev)
+    x = torch.randn((512, 3, 224, 224), device=dev, dtype=torch.float16)
+    for _ in range(2):
+        model.encode_text(t); model.encode_image(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5):
+        model.encode_text(t)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    for _ in range(5):
+        model.encode_image(x)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"text tower  (library kernels, fp16, batch 2048): {5 * 2048 / (t1 - t0):9.0f} captions/s")
+print(f"image tower (library kernels, fp16, batch 512):  {5 * 512 / (t2 - t1):9.0f} images/s")
+print("reference structure: batch 1 image + ~100 captions per item, every caption re-encoded per item")
