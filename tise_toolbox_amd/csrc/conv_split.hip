@@ -755,9 +755,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         }                                                                                                  \
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \
             _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
-                /* weight fragment first: the accumulator is D[cout][pixel] (conv_epilogue.h) */                \
-                acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][0], acc_main[0][t], 0, 0, 0); \
+                /* weight fragment first: the accumulator is D[cout][pixel] (conv_epilogue.h).  The two    \
+                   updates of acc_corr[t] are kept one MFMA apart (TN > 1: by the next tile's main MFMA) so  \
+                   that no MFMA waits on the result of the one issued just before it */                    \
                 acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][1], fa_[s][0], acc_corr[0][t], 0, 0, 0); \
+                acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][0], acc_main[0][t], 0, 0, 0); \
                 acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][1], acc_corr[0][t], 0, 0, 0); \
             }                                                                                              \
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);             /* a(s0), b(s0, t0) */              \
