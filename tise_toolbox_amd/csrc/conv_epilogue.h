@@ -104,21 +104,44 @@ __device__ __forceinline__ void store_tiles(const tise_conv_args& p, float16_t (
             // read back: 8 * nt lanes per pixel row, 16 bytes each
             const int lpr = 8 * nt;                                  // lanes per row: 8 or 16
             const int rows_per_pass = 64 / lpr;
+            const int row0 = lane / lpr, q = lane % lpr;
+            const int col = n0w + t0 * 32 + 8 * (q >> 1);
+            CONV_EPI_SEG(col, sd_, sl_, sp_, so_, smode, sc0_)
+            const bool col_ok = col < p.Cout;
+            if (!GRID) {
+                // tile rows are output pixels: one 64-bit address per lane, advanced by a constant per pass, and a
+                // wave-uniform row limit instead of per-store pixel arithmetic
+                const long long pp0 = m0w + i * 32 + row0;
+                const long long left = p.M - (m0w + i * 32);          // rows of this tile that exist
+                const int rows_ok = left > 32 ? 32 : (left < 0 ? 0 : (int)left);
+                const long long esz = smode == 0 ? 2 : 4;
+                unsigned char* d = reinterpret_cast<unsigned char*>(sd_) +
+                                   (((smode == 0 && (q & 1)) ? sp_ : 0) + pp0 * sl_ + so_ + (col - sc0_) +
+                                    ((smode != 0 && (q & 1)) ? 4 : 0)) * esz;
+                const long long step = (long long)rows_per_pass * sl_ * esz;
+                const unsigned char* src = tw + row0 * PITCH + q * 16;
 #pragma unroll
-            for (int r4 = 0; r4 < 32 * TW / 8; ++r4) {
-                if (r4 * rows_per_pass >= 32) continue;
-                const int row = r4 * rows_per_pass + lane / lpr, q = lane % lpr;
-                const int col = n0w + t0 * 32 + 8 * (q >> 1);
-                const long long pp = out_pixel<GRID>(p, m0w + i * 32 + row);
-                const u32x4_t val = *reinterpret_cast<const u32x4_t*>(tw + row * PITCH + q * 16);
-                CONV_EPI_SEG(col, sd_, sl_, sp_, so_, smode, sc0_)
-                if (col < p.Cout && pp >= 0) {
-                    if (smode == 0) {
-                        _Float16* d = reinterpret_cast<_Float16*>(sd_) + ((q & 1) ? sp_ : 0) + pp * sl_ + so_ + (col - sc0_);
-                        *reinterpret_cast<u32x4_t*>(d) = val;
-                    } else {
-                        float* d = reinterpret_cast<float*>(sd_) + pp * sl_ + so_ + (col - sc0_) + 4 * (q & 1);
-                        *reinterpret_cast<u32x4_t*>(d) = val;
+                for (int r4 = 0; r4 < 32 * TW / 8; ++r4) {
+                    if (r4 * rows_per_pass >= 32) continue;
+                    const u32x4_t val = *reinterpret_cast<const u32x4_t*>(src + r4 * rows_per_pass * PITCH);
+                    if (col_ok && row0 + r4 * rows_per_pass < rows_ok) *reinterpret_cast<u32x4_t*>(d) = val;
+                    d += step;
+                }
+            } else {
+#pragma unroll
+                for (int r4 = 0; r4 < 32 * TW / 8; ++r4) {
+                    if (r4 * rows_per_pass >= 32) continue;
+                    const int row = r4 * rows_per_pass + row0;
+                    const long long pp = out_pixel<GRID>(p, m0w + i * 32 + row);
+                    const u32x4_t val = *reinterpret_cast<const u32x4_t*>(tw + row * PITCH + q * 16);
+                    if (col_ok && pp >= 0) {
+                        if (smode == 0) {
+                            _Float16* d = reinterpret_cast<_Float16*>(sd_) + ((q & 1) ? sp_ : 0) + pp * sl_ + so_ + (col - sc0_);
+                            *reinterpret_cast<u32x4_t*>(d) = val;
+                        } else {
+                            float* d = reinterpret_cast<float*>(sd_) + pp * sl_ + so_ + (col - sc0_) + 4 * (q & 1);
+                            *reinterpret_cast<u32x4_t*>(d) = val;
+                        }
                     }
                 }
             }

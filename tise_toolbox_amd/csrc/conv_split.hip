@@ -645,7 +645,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     constexpr int LDS_BYTES = (2 * STAGE > T_BYTES) ? 2 * STAGE : T_BYTES;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS / DMA addresses stay on the SALU
     const int tiles_n = (p.Cout + BN - 1) / BN;
     const long long nwg = (long long)gridDim.x;
     long long bid = blockIdx.x;
@@ -689,28 +690,37 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
                 (long long)(n0 + rb * 16 + (lane >> 2)) * p.Kpad + cl * 8;
         pb_off[i] = 2 * A_PLANE + plane * B_PLANE + rb * 1024;
     }
-    // pixel-operand pointers for the current tap
-    const _Float16* pa[2];
+    // pixel-operand pointers for the current tap: ALWAYS loadable (the zero page when the tap falls outside the
+    // image or the row outside M) with a per-lane advance of 64 bytes or 0, so that a K-step issues its DMA
+    // straight from the registers and spends one 64-bit add per pointer (the null-pointer selects this replaces
+    // were 16 of the ~23 vector instructions per step; SQ_INSTS_VALU / SQ_INSTS_MFMA was 3.4-5.7)
+    const unsigned char* pa_hi[2];
+    const unsigned char* pa_lo[2];
+    long long pa_inc[2];                                      // bytes
     int kh = 0, kw = 0, cblk = 0;
     const int ncblk = p.Cin / CS_BK;
 #define CF_TAP()                                                                                          \
     _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                     \
         const int ih = ih0[jj] + kh, iw = iw0[jj] + kw;                                                    \
         const bool ok = rok[jj] && kh < p.KH && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                \
-        pa[jj] = ok ? img[jj] + ((long long)ih * p.W + iw) * p.Cin : nullptr;                              \
+        const _Float16* src = img[jj] + ((long long)ih * p.W + iw) * p.Cin;                                \
+        pa_hi[jj] = reinterpret_cast<const unsigned char*>(ok ? src : zp);                                 \
+        pa_lo[jj] = reinterpret_cast<const unsigned char*>(ok ? src + p.x_plane : zp);                     \
+        pa_inc[jj] = ok ? CS_BK * 2 : 0;                                                                   \
     }
 #define CF_ISSUE(STAGEOFF)                                                                                \
     {                                                                                                     \
         _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                 \
-            const _Float16* sh = pa[jj] ? pa[jj] : zp;                                                     \
-            const _Float16* sl = pa[jj] ? pa[jj] + p.x_plane : zp;                                         \
-            __builtin_amdgcn_global_load_lds(sh, (lds_ptr_t)(lds + (STAGEOFF) + (2 * wave + jj) * 1024), 16, 0, 0);            \
-            __builtin_amdgcn_global_load_lds(sl, (lds_ptr_t)(lds + (STAGEOFF) + A_PLANE + (2 * wave + jj) * 1024), 16, 0, 0);  \
-            pa[jj] = pa[jj] ? pa[jj] + CS_BK : nullptr;                                                    \
-        }                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                   \
             /* locals on purpose: with array elements as direct builtin arguments hipcc (ROCm 7.2) silently  \
                drops the host-side launch stub of this template */                                         \
+            const unsigned char* sh = pa_hi[jj];                                                           \
+            const unsigned char* sl = pa_lo[jj];                                                           \
+            __builtin_amdgcn_global_load_lds(sh, (lds_ptr_t)(lds + (STAGEOFF) + (2 * wave + jj) * 1024), 16, 0, 0);            \
+            __builtin_amdgcn_global_load_lds(sl, (lds_ptr_t)(lds + (STAGEOFF) + A_PLANE + (2 * wave + jj) * 1024), 16, 0, 0);  \
+            pa_hi[jj] = sh + pa_inc[jj];                                                                   \
+            pa_lo[jj] = sl + pa_inc[jj];                                                                   \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                   \
             const _Float16* sw_ = pb[i];                                                                   \
             unsigned char* dw_ = lds + (STAGEOFF) + pb_off[i];                                             \
             __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)dw_, 16, 0, 0);                               \
