@@ -148,4 +148,110 @@ __device__ __forceinline__ void store_tiles(const tise_conv_args& p, float16_t (
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Descriptor form (the 128-pixel kernels, tile rows = output pixels).  The epilogue above looks the destination
+// segment up with per-lane select chains and loads scale / bias from global memory inside the tile loop -- the
+// ISA showed one `s_waitcnt vmcnt(0)` per 8-cout group (each also waiting for the previous group's stores) and
+// 30 exec-mask branches per tile.  Here the workgroup first writes, once, into LDS:
+//   * scale[BN], bias[BN] (prefetched into registers before the K loop),
+//   * one 32-byte descriptor per 8-cout chunk: {byte address of (pixel 0, first cout of the chunk, plane 0),
+//     bytes per pixel, byte offset of the second half (lo plane / couts 4..7), mode, valid},
+// and the tile loop only reads LDS; the segment mode of a group is wave-uniform (segments start on multiples
+// of 8 couts), so it is taken through readfirstlane and the split / raw paths become scalar branches.
+struct ChunkDesc {
+    long long base, row_stride, second;
+    int mode, valid;
+};
+
+template <int BN>
+struct EpiArea {
+    static constexpr int DESC = 0, SCALE = (BN / 8) * 32, BIAS = SCALE + BN * 4, BYTES = BIAS + BN * 4;
+};
+
+// all threads of the workgroup; area = LDS behind the staging tiles.  sc_pre / bs_pre: scale / bias of couts
+// n0 + 4*tid .. +3 held by threads tid < BN / 4.  Caller issues __syncthreads() afterwards.
+template <int BN>
+__device__ __forceinline__ void prepare(const tise_conv_args& p, unsigned char* area, int n0, float4_t sc_pre, float4_t bs_pre) {
+    const int tid = threadIdx.x;
+    const int nseg = p.nseg & 0xff;
+    if (tid < BN / 4) {
+        *reinterpret_cast<float4_t*>(area + EpiArea<BN>::SCALE + tid * 16) = sc_pre;
+        *reinterpret_cast<float4_t*>(area + EpiArea<BN>::BIAS + tid * 16) = bs_pre;
+    }
+    if (tid < BN / 8) {
+        const int col = n0 + 8 * tid;
+        CONV_EPI_SEG(col, sd_, sl_, sp_, so_, smode, sc0_)
+        const long long esz = smode == 0 ? 2 : 4;
+        ChunkDesc d;
+        d.base = (long long)reinterpret_cast<unsigned char*>(sd_) + (so_ + (col - sc0_)) * esz;
+        d.row_stride = sl_ * esz;
+        d.second = smode == 0 ? sp_ * 2 : 16;
+        d.mode = smode;
+        d.valid = col < p.Cout ? 1 : 0;
+        *reinterpret_cast<ChunkDesc*>(area + EpiArea<BN>::DESC + tid * 32) = d;
+    }
+}
+
+// acc[0][t]: tile rows m0w .. m0w+31 (this wave), couts n0 + 32*t .. +31.  tw: the wave's staging bytes.
+template <int TNW, int TW>
+__device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float16_t (&acc_main)[1][TNW],
+                                                 float16_t (&acc_corr)[1][TNW], unsigned char* tw,
+                                                 const unsigned char* area, long long m0w) {
+    constexpr int BN = 32 * TNW;
+    constexpr int PITCH = Staging<TW>::PITCH;
+    const int lane = threadIdx.x & 63;
+    const long long left = p.M - m0w;                         // rows of this tile that exist (wave-uniform)
+    const int rows_ok = left > 32 ? 32 : (left < 0 ? 0 : (int)left);
+#pragma unroll
+    for (int t0 = 0; t0 < TNW; t0 += TW) {
+        const int nt = (TNW - t0) < TW ? (TNW - t0) : TW;
+        unsigned char* trow = tw + (lane & 31) * PITCH;
+#pragma unroll
+        for (int u = 0; u < TW; ++u) {
+            if (u >= nt) continue;
+            const int t = t0 + u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int chunk = t * 4 + g;
+                const int mode = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(area + EpiArea<BN>::DESC + chunk * 32 + 24));
+                const int ch = chunk * 8 + 4 * (lane >> 5);
+                const float4_t sc = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::SCALE + ch * 4);
+                float4_t v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    v[k] = (acc_main[0][t][4 * g + k] + acc_corr[0][t][4 * g + k] * (1.0f / 2048.0f)) * sc[k];
+                unsigned char* slot = trow + u * 128 + g * 32;
+                if (mode == 0) {
+                    const float4_t bs = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::BIAS + ch * 4);
+                    half4_t hi, lo;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float r = fmaxf(v[k] + bs[k], 0.f);
+                        hi[k] = (_Float16)r;
+                        lo[k] = (_Float16)((r - (float)hi[k]) * 2048.0f);
+                    }
+                    *reinterpret_cast<half4_t*>(slot + (lane >> 5) * 8) = hi;
+                    *reinterpret_cast<half4_t*>(slot + 16 + (lane >> 5) * 8) = lo;
+                } else {
+                    *reinterpret_cast<float4_t*>(slot + (lane >> 5) * 16) = v;
+                }
+            }
+        }
+        const int lpr = 8 * nt;                               // lanes per pixel row: 8 or 16
+        const int rows_per_pass = 64 / lpr;
+        const int row0 = lane / lpr, q = lane % lpr;
+        const ChunkDesc cd = *reinterpret_cast<const ChunkDesc*>(area + EpiArea<BN>::DESC + (t0 * 4 + (q >> 1)) * 32);
+        unsigned char* d = reinterpret_cast<unsigned char*>(cd.base + (m0w + row0) * cd.row_stride + ((q & 1) ? cd.second : 0));
+        const long long step = rows_per_pass * cd.row_stride;
+        const unsigned char* src = tw + row0 * PITCH + q * 16;
+#pragma unroll
+        for (int r4 = 0; r4 < 32 * TW / 8; ++r4) {
+            if (r4 * rows_per_pass >= 32) continue;
+            const u32x4_t val = *reinterpret_cast<const u32x4_t*>(src + r4 * rows_per_pass * PITCH);
+            if (cd.valid && row0 + r4 * rows_per_pass < rows_ok) *reinterpret_cast<u32x4_t*>(d) = val;
+            d += step;
+        }
+    }
+}
+
 }  // namespace conv_epi

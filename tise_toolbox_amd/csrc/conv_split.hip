@@ -344,6 +344,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs 
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) { acc_main[0][t][j] = 0.f; acc_corr[0][t][j] = 0.f; }
+    // scale / bias of this tile's couts, 4 per thread, fetched now so that the epilogue never waits on global memory
+    conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
+    if (tid < BN / 4) {
+        sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + n0 + 4 * tid);
+        bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + n0 + 4 * tid);
+    }
 
     const int nsteps = p.Kpad / CS_BK;
     // fragment read: row (lane & 31) of a 32-row block, logical chunk 2*s + (lane >> 5), swizzled
@@ -375,8 +381,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs 
     }
     __syncthreads();                                           // all fragment reads done before LDS is reused
     constexpr int ETW = TN > 1 ? 2 : 1;                       // accumulator tiles staged together: 128-byte runs
-    static_assert(4 * conv_epi::Staging<ETW>::BYTES <= LDS_BYTES, "epilogue staging must fit the operand LDS");
-    conv_epi::store_tiles<1, TN, false, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, m0 + wave * 32, n0);
+    constexpr int EPI0 = 4 * conv_epi::Staging<ETW>::BYTES;   // scale / bias / chunk descriptors behind the staging tiles
+    static_assert(EPI0 + conv_epi::EpiArea<BN>::BYTES <= LDS_BYTES, "epilogue staging must fit the operand LDS");
+    conv_epi::prepare<BN>(p, lds + EPI0, n0, sc_pre, bs_pre);
+    __syncthreads();
+    conv_epi::store_tiles_desc<TN, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, lds + EPI0, m0 + wave * 32);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -738,6 +747,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     for (int t = 0; t < TN; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) { acc_main[0][t][j] = 0.f; acc_corr[0][t][j] = 0.f; }
+    // scale / bias of this tile's couts, 4 per thread, fetched now so that the epilogue never waits on global memory
+    conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
+    if (tid < BN / 4) {
+        sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + n0 + 4 * tid);
+        bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + n0 + 4 * tid);
+    }
 
     const int nsteps = p.K / CS_BK;                           // K = KH*KW*Cin is a multiple of 32 here
     // fragment read offsets: row (lane & 31), logical chunk 2*s + (lane >> 5), swizzled with (row >> 2) & 3
@@ -810,8 +825,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     __syncthreads();
     if ((p.nseg & 0x400) && p.M > 0) return;                  // (M > 0 always: keeps the accumulators live)
     constexpr int ETW = TN > 1 ? 2 : 1;                       // accumulator tiles staged together: 128-byte runs
-    static_assert(4 * conv_epi::Staging<ETW>::BYTES <= LDS_BYTES, "epilogue staging must fit the operand LDS");
-    conv_epi::store_tiles<1, TN, false, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, m0 + wave * 32, n0);
+    constexpr int EPI0 = 4 * conv_epi::Staging<ETW>::BYTES;   // scale / bias / chunk descriptors behind the staging tiles
+    static_assert(EPI0 + conv_epi::EpiArea<BN>::BYTES <= LDS_BYTES, "epilogue staging must fit the operand LDS");
+    conv_epi::prepare<BN>(p, lds + EPI0, n0, sc_pre, bs_pre);
+    __syncthreads();
+    conv_epi::store_tiles_desc<TN, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, lds + EPI0, m0 + wave * 32);
 }
 
 // ------------------------------------------------------------------------------------------------
