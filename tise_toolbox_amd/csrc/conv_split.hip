@@ -656,16 +656,18 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS / DMA addresses stay on the SALU
-    const int tiles_n = (p.Cout + BN - 1) / BN;
-    const long long nwg = (long long)gridDim.x;
-    long long bid = blockIdx.x;
+    // 32-bit index arithmetic throughout the prologue (the launcher sends M >= 2^31 to the glds kernel): the 64-bit
+    // divisions of the generic kernels cost several hundred instructions per workgroup, ~15 % of a 27-step tile
+    const unsigned tiles_n = (unsigned)(p.Cout + BN - 1) / BN;
+    const unsigned nwg = gridDim.x;
+    unsigned bid = blockIdx.x;
     {
-        const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const long long tile_m = bid / tiles_n;
+    const unsigned tile_m = bid / tiles_n;
     const int tile_n = (int)(bid - tile_m * tiles_n);
-    const long long m0 = tile_m * CS_BM;
+    const long long m0 = (long long)tile_m * CS_BM;
     const int n0 = tile_n * BN;
 
     const int cl = (lane & 3) ^ ((lane >> 4) & 3);        // logical 16-byte chunk this lane's DMA piece fetches
@@ -674,17 +676,17 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     int ih0[2], iw0[2];
     const _Float16* img[2];
     bool rok[2];
+    const unsigned ohw = (unsigned)(p.OH * p.OW), M32 = (unsigned)p.M;
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj) {
-        const long long pix = m0 + (2 * wave + jj) * 16 + (lane >> 2);
-        rok[jj] = pix < p.M;
-        const long long pp = rok[jj] ? pix : 0;
-        const int ohw = p.OH * p.OW;
-        const int n = (int)(pp / ohw);
-        const int rem = (int)(pp - (long long)n * ohw);
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        ih0[jj] = oh * p.SH - p.PH;
-        iw0[jj] = ow * p.SW - p.PW;
+        const unsigned pix = tile_m * CS_BM + (2 * wave + jj) * 16 + (lane >> 2);
+        rok[jj] = pix < M32;
+        const unsigned pp = rok[jj] ? pix : 0u;
+        const unsigned n = pp / ohw;
+        const unsigned rem = pp - n * ohw;
+        const unsigned oh = rem / (unsigned)p.OW, ow = rem - oh * (unsigned)p.OW;
+        ih0[jj] = (int)oh * p.SH - p.PH;
+        iw0[jj] = (int)ow * p.SW - p.PW;
         img[jj] = xg + (long long)n * p.H * p.W * p.Cin + cl * 8;
     }
     // weight pointers of this wave's TN DMA pieces (advance 32 halfs per step)
@@ -994,7 +996,7 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
         return TISE_ERR_INVALID_ARG;
     if (tn & 512) return tise_conv_pipe_launch(args, tn & 15, stream);   // persistent 3-stage kernel, weights [tap][Cin_pad]
     const bool glds = (tn & (16 | 128)) != 0, glds3 = (tn & 32) != 0, gldsb = (tn & 64) != 0;
-    const bool fast = (tn & 128) != 0 && args->Cin % 32 == 0 && args->K == args->Kpad;
+    const bool fast = (tn & 128) != 0 && args->Cin % 32 == 0 && args->K == args->Kpad && args->M < 0x7fffff00LL;
     if (tn & 256) {                                    // window kernel: stride 1, weights packed [tap][Cin_pad]
         const int t = tn & 15;
         if (args->SH != 1 || args->SW != 1 || args->KH * args->KW > 32 || t < 1 || t > 5) return TISE_ERR_INVALID_ARG;
