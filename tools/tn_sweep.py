@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Every distinct trunk conv shape x tile width TN = 1..5 with the default kernel: which TN is fastest (batch 500)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from tise_toolbox_amd.conv_split import SplitConv, split, pick_tn
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conv_pipe_probe_layers import LAYERS
+
+dev = torch.device("cuda:0")
+N = 500
+tot_cur = tot_best = 0.0
+for (H, Cin, Cout, kh, kw, st, pad, cnt) in LAYERS:
+    g = torch.Generator(device="cpu").manual_seed(1)
+    w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+    x = split(torch.relu(torch.randn((N, H, H, Cin), device=dev)))        # ReLU-like sparsity, as inside the trunk
+    res = {}
+    for tn in range(1, 6):
+        if 32 * tn >= 2 * max(32, Cout) and tn > 1:
+            continue
+        conv = SplitConv(w, b, (st, st), pad, dev, tn=tn, variant="fast")
+        oh, ow = conv.out_hw(H, H)
+        out = torch.zeros((2, N, oh, ow, Cout), dtype=torch.float16, device=dev)
+        for _ in range(3):
+            conv(x, [(0, Cout, out, 0, 0)])
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            conv(x, [(0, Cout, out, 0, 0)])
+        e1.record(); torch.cuda.synchronize()
+        res[tn] = e0.elapsed_time(e1) / 10
+        del out
+    cur = pick_tn(Cout)
+    best = min(res, key=res.get)
+    tot_cur += res[cur] * cnt; tot_best += res[best] * cnt
+    print(f"{H}x{H}x{Cin}->{Cout} k{kh}x{kw} s{st} x{cnt}: cur tn{cur} {res[cur]:.3f}  best tn{best} {res[best]:.3f}  " +
+          " ".join(f"tn{t}={v:.3f}" for t, v in res.items()), flush=True)
+    del x
+print(f"total: current table {tot_cur:.2f} ms, per-layer best {tot_best:.2f} ms")
