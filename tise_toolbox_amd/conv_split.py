@@ -115,6 +115,17 @@ class SplitConv:
             ww = torch.zeros((self.cout_pad, kh * kw, cin_pad), dtype=torch.float32)
             ww[:cout, :, :cin] = wk.reshape(cout, kh * kw, cin)
             self.w = split(ww.reshape(self.cout_pad, -1)).to(device).contiguous()
+        elif self.variant == "fast" and cin % 32 == 16:
+            # default kernel, Cin = 32 * nfull + 16: K order = (tap, full 32-channel block) for all taps, then the
+            # 16-channel tails two taps per 32-wide step (conv_split.hip, conv_split_fast_kernel)
+            ntaps, nfull = kh * kw, cin // 32
+            w3 = torch.zeros((self.cout_pad, ntaps, cin), dtype=torch.float32)
+            w3[:cout] = wk.reshape(cout, ntaps, cin)
+            full = w3[:, :, :nfull * 32].reshape(self.cout_pad, ntaps * nfull * 32)
+            tails = torch.zeros((self.cout_pad, (ntaps + 1) // 2 * 2, 16), dtype=torch.float32)
+            tails[:, :ntaps] = w3[:, :, nfull * 32:]
+            self.w = split(torch.cat([full, tails.reshape(self.cout_pad, -1)], 1)).to(device).contiguous()
+            self.kpad = self.w.shape[2]
         sc = torch.zeros(self.cout_pad, dtype=torch.float32)
         sc[:cout] = 1.0 / pre
         bs = torch.zeros(self.cout_pad, dtype=torch.float32)

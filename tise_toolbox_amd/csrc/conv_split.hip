@@ -687,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         const unsigned oh = rem / (unsigned)p.OW, ow = rem - oh * (unsigned)p.OW;
         ih0[jj] = (int)oh * p.SH - p.PH;
         iw0[jj] = (int)ow * p.SW - p.PW;
-        img[jj] = xg + (long long)n * p.H * p.W * p.Cin + cl * 8;
+        img[jj] = xg + (long long)n * p.H * p.W * p.Cin;
     }
     // weight pointers of this wave's TN DMA pieces (advance 32 halfs per step)
     const _Float16* pb[TN];
@@ -708,16 +708,30 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     const unsigned char* pa_hi[2];
     const unsigned char* pa_lo[2];
     long long pa_inc[2];                                      // bytes
-    int kh = 0, kw = 0, cblk = 0;
-    const int ncblk = p.Cin / CS_BK;
-#define CF_TAP()                                                                                          \
+    // K order.  Phase A: (tap, full 32-channel block), nA = KH*KW*(Cin/32) steps.  Phase B (Cin % 32 == 16 only):
+    // the 16-channel tails of the taps, TWO TAPS PER STEP -- chunks 0,1 of a step carry the tail of tap 2j, chunks
+    // 2,3 that of tap 2j+1 (lanes pick their tap by their chunk) -- so no MFMA runs on padding except in the last
+    // step of an odd tap count.  The weights are packed in the same order (conv_split.py).
+    int kh = 0, kw = 0, cblk = 0, istep = 0;
+    const int ncblk = p.Cin / CS_BK, ntaps = p.KH * p.KW;
+    const int nA = ntaps * ncblk;
+    const int nB = (p.Cin & 16) ? (ntaps + 1) / 2 : 0;
+#define CF_TAP_AT(KH_, KW_, CH_, VALID_)                                                                  \
     _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                     \
-        const int ih = ih0[jj] + kh, iw = iw0[jj] + kw;                                                    \
-        const bool ok = rok[jj] && kh < p.KH && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                \
-        const _Float16* src = img[jj] + ((long long)ih * p.W + iw) * p.Cin;                                \
+        const int ih = ih0[jj] + (KH_), iw = iw0[jj] + (KW_);                                              \
+        const bool ok = rok[jj] && (VALID_) && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                 \
+        const _Float16* src = img[jj] + ((long long)ih * p.W + iw) * p.Cin + (CH_);                        \
         pa_hi[jj] = reinterpret_cast<const unsigned char*>(ok ? src : zp);                                 \
         pa_lo[jj] = reinterpret_cast<const unsigned char*>(ok ? src + p.x_plane : zp);                     \
         pa_inc[jj] = ok ? CS_BK * 2 : 0;                                                                   \
+    }
+#define CF_TAP() CF_TAP_AT(kh, kw, cl * 8, kh < p.KH)
+// phase B step j: this lane's tap is 2j + (cl >> 1), its 8 channels start at 32*ncblk + 8*(cl & 1)
+#define CF_TAP_B(J)                                                                                       \
+    {                                                                                                     \
+        const int tl = 2 * (J) + (cl >> 1);                                                                \
+        const int lkh = tl / p.KW, lkw = tl - lkh * p.KW;                                                  \
+        CF_TAP_AT(lkh, lkw, ncblk * CS_BK + (cl & 1) * 8, tl < ntaps)                                      \
     }
 #define CF_ISSUE(STAGEOFF)                                                                                \
     {                                                                                                     \
@@ -737,7 +751,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
             __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)dw_, 16, 0, 0);                               \
             pb[i] += CS_BK;                                                                                \
         }                                                                                                  \
-        if (++cblk == ncblk) {                               /* wave-uniform: next filter tap */           \
+        ++istep;                                             /* the step whose pointers are prepared now */ \
+        if (istep >= nA) {                                   /* wave-uniform */                            \
+            if (istep < nA + nB) CF_TAP_B(istep - nA)                                                      \
+        } else if (++cblk == ncblk) {                        /* next filter tap */                         \
             cblk = 0;                                                                                      \
             if (++kw == p.KW) { kw = 0; ++kh; }                                                            \
             CF_TAP()                                                                                       \
@@ -756,7 +773,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + n0 + 4 * tid);
     }
 
-    const int nsteps = p.K / CS_BK;                           // K = KH*KW*Cin is a multiple of 32 here
+    const int nsteps = nA + nB;
     // fragment read offsets: row (lane & 31), logical chunk 2*s + (lane >> 5), swizzled with (row >> 2) & 3
     const int fswz = ((lane & 31) >> 2) & 3;
     const int fo0 = (lane & 31) * 64 + (((lane >> 5)) ^ fswz) * 16;
@@ -996,7 +1013,9 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
         return TISE_ERR_INVALID_ARG;
     if (tn & 512) return tise_conv_pipe_launch(args, tn & 15, stream);   // persistent 3-stage kernel, weights [tap][Cin_pad]
     const bool glds = (tn & (16 | 128)) != 0, glds3 = (tn & 32) != 0, gldsb = (tn & 64) != 0;
-    const bool fast = (tn & 128) != 0 && args->Cin % 32 == 0 && args->K == args->Kpad && args->M < 0x7fffff00LL;
+    // fast path: K order (tap, full 32-channel block) then paired 16-channel tails (see the kernel); Kpad says which
+    const int fast_kpad = (args->KH * args->KW * (args->Cin / 32) + ((args->Cin & 16) ? (args->KH * args->KW + 1) / 2 : 0)) * 32;
+    const bool fast = (tn & 128) != 0 && args->Cin % 16 == 0 && args->Kpad == fast_kpad && args->M < 0x7fffff00LL;
     if (tn & 256) {                                    // window kernel: stride 1, weights packed [tap][Cin_pad]
         const int t = tn & 15;
         if (args->SH != 1 || args->SW != 1 || args->KH * args->KW > 32 || t < 1 || t > 5) return TISE_ERR_INVALID_ARG;
