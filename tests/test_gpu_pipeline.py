@@ -198,3 +198,22 @@ def test_object_centric_inception_score(setup, tmp_path):
     assert abs(mean - want[0]) <= 1e-4 and abs(std - want[1]) <= 1e-4
     with pytest.raises(AssertionError):
         ois.inception_score(ds, batch_size=64)                            # N > batch_size (reference :26)
+
+
+def test_hipgraph_replay_matches_eager(cuda_device, monkeypatch):
+    """TISE_GRAPH=1: resize + trunk captured once per batch shape and replayed; features and logits must be bit-identical
+    to eager launching, for every batch after the capture and for a second batch shape."""
+    from tise_toolbox_amd.engine import RealismEngine
+    imgs = torch.from_numpy(_cases.smooth_images(40, 256, 256, seed=21)).to(cuda_device)
+    monkeypatch.setenv("TISE_GRAPH", "0")
+    eager = RealismEngine(dims=2048, seed=0, with_logits=True)
+    monkeypatch.setenv("TISE_GRAPH", "1")
+    graphed = RealismEngine(dims=2048, seed=0, with_logits=True)
+    assert graphed._graph_ok and not eager._graph_ok
+    for rep in range(5):                                   # batches 0,1 eager (cache warm-up), 2 captured, 3,4 replayed
+        for lo, hi in ((0, 16), (16, 24)):                 # two batch shapes -> two graphs
+            batch = imgs[lo + rep:hi + rep]
+            f0, l0 = eager.features_from_u8(batch)
+            f1, l1 = graphed.features_from_u8(batch)
+            assert torch.equal(f0, f1) and torch.equal(l0, l1), (rep, lo)
+    assert sum(1 for k in graphed._graphs if not (isinstance(k[0], str))) == 2
