@@ -51,7 +51,8 @@ def _build_parser():
     parser.add_argument("--seed", type=int, default=0, help="seed of the stand-in weights when --weights is absent")
     parser.add_argument("--save-stats", type=str, default="", help="write mu/sigma of --path2 to this .npz")
     parser.add_argument("--label", type=str, default="FID", choices=["FID", "O-FID"])
-    parser.add_argument("--num-workers", type=int, default=8)
+    parser.add_argument("--num-workers", type=int, default=min(32, os.cpu_count() or 8),
+                        help="PNG-decoding DataLoader workers (the reference hard-codes 8, fid_score.py:216)")
     return parser
 
 

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Host-inclusive rate of the drop-in CLI: PNG files on disk -> PIL decode in DataLoader workers -> pinned uint8
+batches over PCIe -> the device path.  Writes N synthetic 256x256 PNGs, saves reference statistics once, then
+times `fid_score` for several worker counts and batch sizes."""
+import os, sys, time, tempfile, subprocess
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from PIL import Image
+from concurrent.futures import ProcessPoolExecutor
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 6000
+
+
+def write(args):
+    d, i = args
+    rng = np.random.default_rng(i)
+    yy, xx = np.mgrid[0:256, 0:256].astype(np.float32)
+    img = np.zeros((256, 256, 3), np.float32)
+    for c in range(3):
+        for _ in range(4):
+            fx, fy, ph = rng.uniform(0.01, 0.15, 2).tolist() + [rng.uniform(0, 6.28)]
+            img[..., c] += np.sin(xx * fx + yy * fy + ph)
+    img = ((img - img.min()) / (img.max() - img.min() + 1e-9) * 255).astype(np.uint8)
+    Image.fromarray(img).save(os.path.join(d, f"{i:05d}.png"))
+
+
+if __name__ == "__main__":
+    root = tempfile.mkdtemp(prefix="tise_cli_")
+    d = os.path.join(root, "gen"); os.makedirs(d)
+    t0 = time.perf_counter()
+    with ProcessPoolExecutor(32) as ex:
+        list(ex.map(write, [(d, i) for i in range(N)], chunksize=64))
+    print(f"wrote {N} PNGs in {time.perf_counter() - t0:.1f} s ({sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)) / N / 1e3:.0f} KB each)", flush=True)
+    ref = os.path.join(root, "ref.npz")
+    env = dict(os.environ)
+    base = [sys.executable, "-m", "tise_toolbox_amd.fid_score", "--path1", ref, "--path2", d, "--saved_file", os.path.join(root, "out.txt")]
+    subprocess.run([sys.executable, "-m", "tise_toolbox_amd.fid_score", "--path1", d, "--path2", d, "--batch-size", "50",
+                    "--save-stats", ref, "--saved_file", os.path.join(root, "o0.txt"), "--num-workers", "32"], check=True,
+                   capture_output=True, env=env)
+    for bs, nw in ((50, 8), (50, 32), (500, 32), (500, 64)):
+        t0 = time.perf_counter()
+        r = subprocess.run(base + ["--batch-size", str(bs), "--num-workers", str(nw)], capture_output=True, text=True, env=env)
+        dt = time.perf_counter() - t0
+        print(f"batch {bs:3d} workers {nw:2d}: {dt:6.1f} s wall for {N} images incl. start-up -> {N / dt:7.0f} images/s   {r.stdout.strip().splitlines()[-1] if r.stdout else r.stderr[-200:]}", flush=True)
