@@ -552,3 +552,20 @@ def test_split_trunk_batch_sizes_and_determinism(dev):
     chunks = torch.cat([trunk(x[:4].contiguous(memory_format=torch.channels_last)),
                         trunk(x[4:].contiguous(memory_format=torch.channels_last))], 0)
     assert torch.equal(one, full) and torch.equal(chunks, full)
+
+
+def test_conv_split_rejects_misaligned_segments(dev):
+    """Segments must tile [0, Cout) in order, start on multiples of 8 couts and land on 16-byte boundaries."""
+    from tise_toolbox_amd import _lib
+    from tise_toolbox_amd.conv_split import SplitConv, split
+    w = torch.randn((64, 32, 1, 1), device=dev)
+    conv = SplitConv(w, torch.zeros(64, device=dev), (1, 1), (0, 0), dev)
+    x = split(torch.rand((2, 5, 5, 32), device=dev))
+    out = torch.zeros((2, 2, 5, 5, 80), dtype=torch.float16, device=dev)
+    conv(x, [(0, 32, out, 0, 0), (32, 64, out, 40, 0)])                     # fine
+    for segs in ([(0, 28, out, 0, 0), (28, 64, out, 32, 0)],               # boundary not a multiple of 8
+                 [(0, 32, out, 4, 0), (32, 64, out, 40, 0)],               # destination offset not 16-byte aligned
+                 [(0, 32, out, 0, 0), (40, 64, out, 40, 0)],               # gap
+                 [(8, 64, out, 0, 0)]):                                     # does not start at 0
+        with pytest.raises(_lib.TiseStatusError):
+            conv(x, segs)

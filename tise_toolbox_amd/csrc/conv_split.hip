@@ -1011,6 +1011,16 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     if (!args || !args->x || !args->w || !args->scale || !args->bias || (args->nseg & 0xff) < 1 || (args->nseg & 0xff) > 4 ||
         args->Cin % 16 != 0 || args->Cin < 32 || (args->Kpad % CS_BK != 0 && !(tn & (256 | 512))) || args->M <= 0)
         return TISE_ERR_INVALID_ARG;
+    // the epilogues work on 8-cout chunks and 16-byte stores: segments must start on multiples of 8 couts and land
+    // on 16-byte boundaries (fp16 planes: 8 elements, fp32: 4 elements)
+    for (int i = 0; i < (args->nseg & 0xff); ++i) {
+        const tise_conv_seg& g = args->seg[i];
+        const int al = g.mode == 0 ? 8 : 4;
+        if (!g.dst || g.c0 % 8 != 0 || g.c1 <= g.c0 || g.off % al != 0 || g.ld % al != 0 || (g.mode == 0 && g.plane % 8 != 0) ||
+            (reinterpret_cast<uintptr_t>(g.dst) & 15) != 0 || (i > 0 && g.c0 != args->seg[i - 1].c1) || (g.mode != 0 && g.mode != 1))
+            return TISE_ERR_INVALID_ARG;
+    }
+    if (args->seg[0].c0 != 0) return TISE_ERR_INVALID_ARG;
     if (tn & 512) return tise_conv_pipe_launch(args, tn & 15, stream);   // persistent 3-stage kernel, weights [tap][Cin_pad]
     const bool glds = (tn & (16 | 128)) != 0, glds3 = (tn & 32) != 0, gldsb = (tn & 64) != 0;
     // fast path: K order (tap, full 32-channel block) then paired 16-channel tails (see the kernel); Kpad says which
