@@ -569,3 +569,40 @@ def test_conv_split_rejects_misaligned_segments(dev):
                  [(8, 64, out, 0, 0)]):                                     # does not start at 0
         with pytest.raises(_lib.TiseStatusError):
             conv(x, segs)
+
+
+@pytest.mark.parametrize("case", [(149, 149, 32, (0, 0), 3), (35, 35, 32, (1, 1), 5), (23, 23, 32, (0, 0), 3), (9, 11, 64, (1, 1), 2),
+                                  (149, 149, 32, (0, 0), 40), (147, 147, 64, (1, 1), 9)])
+def test_conv_win32_sliding_window_kernel(dev, case):
+    """conv_pipe.hip, configuration 33: resident weights + sliding ring window + compute / service wave split, for the
+    32-channel 3x3 stride-1 layers.  Against fp64 (valid and padded borders, image boundaries inside tiles, one tile
+    per workgroup up to 27, tails of the grid, 64 couts = two launches, three destination segments) and bit-identical
+    over repeated runs (the hand-off between the wave groups is the new synchronisation here)."""
+    from tise_toolbox_amd.conv_split import SplitConv, merge, split
+    H, W, Cout, pad, n = case
+    g = torch.Generator(device="cpu").manual_seed(H + Cout + n)
+    x = (torch.rand((n, H, W, 32), generator=g) * 3.0).to(dev)
+    w = (torch.randn((Cout, 32, 3, 3), generator=g) * (2.0 / 288) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+    conv = SplitConv(w, b, (1, 1), pad, dev, variant="pipe", pipe_cfg=33)
+    oh, ow = conv.out_hw(H, W)
+    ref_lin = torch.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, pad).permute(0, 2, 3, 1)
+    ref = torch.relu(ref_lin + b.double())
+    scale = ref.abs().max().item()
+    xs = split(x)
+    first = None
+    for rep in range(4):
+        out = torch.zeros((2, n, oh, ow, Cout + 32), dtype=torch.float16, device=dev)
+        raw = torch.zeros((n, oh, ow, 16), dtype=torch.float32, device=dev)
+        segs = [(0, 16, out, 16, 0), (16, 32, raw, 0, 1)] + ([(32, Cout, out, 64, 0)] if Cout > 32 else [])
+        conv(xs, segs)
+        got = merge(out)
+        assert (got[..., 16:32].double() - ref[..., 0:16]).abs().max().item() <= 4e-6 * scale
+        if Cout > 32:
+            assert (got[..., 64:].double() - ref[..., 32:]).abs().max().item() <= 4e-6 * scale
+        assert (raw.double() - ref_lin[..., 16:32]).abs().max().item() <= 4e-6 * scale
+        assert got[..., :16].abs().max().item() == 0 and got[..., 32:64].abs().max().item() == 0
+        if first is None:
+            first = (out.clone(), raw.clone())
+        else:
+            assert torch.equal(out, first[0]) and torch.equal(raw, first[1])

@@ -193,14 +193,16 @@ __device__ __forceinline__ void prepare(const tise_conv_args& p, unsigned char* 
 }
 
 // acc[0][t]: tile rows m0w .. m0w+31 (this wave), couts n0 + 32*t .. +31.  tw: the wave's staging bytes.
-template <int TNW, int TW>
+// GRID = true (window kernels): tile rows are pixels of the input grid; the (n, y, x) of a lane's first row comes
+// from two 32-bit divisions and is stepped forward per pass (grid pixel counts < 2^31: launcher).
+template <int TNW, int TW, bool GRID = false>
 __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float16_t (&acc_main)[1][TNW],
                                                  float16_t (&acc_corr)[1][TNW], unsigned char* tw,
                                                  const unsigned char* area, long long m0w) {
     constexpr int BN = 32 * TNW;
     constexpr int PITCH = Staging<TW>::PITCH;
     const int lane = threadIdx.x & 63;
-    const long long left = p.M - m0w;                         // rows of this tile that exist (wave-uniform)
+    const long long left = (GRID ? (long long)p.N * p.H * p.W : p.M) - m0w;   // rows of this tile that exist (wave-uniform)
     const int rows_ok = left > 32 ? 32 : (left < 0 ? 0 : (int)left);
 #pragma unroll
     for (int t0 = 0; t0 < TNW; t0 += TW) {
@@ -241,15 +243,36 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float1
         const int rows_per_pass = 64 / lpr;
         const int row0 = lane / lpr, q = lane % lpr;
         const ChunkDesc cd = *reinterpret_cast<const ChunkDesc*>(area + EpiArea<BN>::DESC + (t0 * 4 + (q >> 1)) * 32);
-        unsigned char* d = reinterpret_cast<unsigned char*>(cd.base + (m0w + row0) * cd.row_stride + ((q & 1) ? cd.second : 0));
-        const long long step = rows_per_pass * cd.row_stride;
         const unsigned char* src = tw + row0 * PITCH + q * 16;
+        if (!GRID) {
+            unsigned char* d = reinterpret_cast<unsigned char*>(cd.base + (m0w + row0) * cd.row_stride + ((q & 1) ? cd.second : 0));
+            const long long step = rows_per_pass * cd.row_stride;
 #pragma unroll
-        for (int r4 = 0; r4 < 32 * TW / 8; ++r4) {
-            if (r4 * rows_per_pass >= 32) continue;
-            const u32x4_t val = *reinterpret_cast<const u32x4_t*>(src + r4 * rows_per_pass * PITCH);
-            if (cd.valid && row0 + r4 * rows_per_pass < rows_ok) *reinterpret_cast<u32x4_t*>(d) = val;
-            d += step;
+            for (int r4 = 0; r4 < 32 * TW / 8; ++r4) {
+                if (r4 * rows_per_pass >= 32) continue;
+                const u32x4_t val = *reinterpret_cast<const u32x4_t*>(src + r4 * rows_per_pass * PITCH);
+                if (cd.valid && row0 + r4 * rows_per_pass < rows_ok) *reinterpret_cast<u32x4_t*>(d) = val;
+                d += step;
+            }
+        } else {
+            const unsigned g0 = (unsigned)(m0w + row0);
+            const unsigned hw = (unsigned)(p.H * p.W);
+            unsigned n = g0 / hw;
+            const unsigned rem = g0 - n * hw;
+            unsigned y = rem / (unsigned)p.W, x = rem - y * (unsigned)p.W;
+            const long long half_off = (q & 1) ? cd.second : 0;
+#pragma unroll
+            for (int r4 = 0; r4 < 32 * TW / 8; ++r4) {
+                if (r4 * rows_per_pass >= 32) continue;
+                const u32x4_t val = *reinterpret_cast<const u32x4_t*>(src + r4 * rows_per_pass * PITCH);
+                const bool ok = cd.valid && row0 + r4 * rows_per_pass < rows_ok && y < (unsigned)p.OH && x < (unsigned)p.OW;
+                if (ok) {
+                    const long long pp = ((long long)n * p.OH + y) * p.OW + x;
+                    *reinterpret_cast<u32x4_t*>(cd.base + pp * cd.row_stride + half_off) = val;
+                }
+                x += rows_per_pass;                               // next pass: rows_per_pass grid pixels further (W >= 8)
+                if (x >= (unsigned)p.W) { x -= (unsigned)p.W; if (++y == (unsigned)p.H) { y = 0; ++n; } }
+            }
         }
     }
 }

@@ -686,11 +686,247 @@ int launch_win(const ConvArgs* a, hipStream_t st) {
     return TISE_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Resident-weights sliding-window kernel for the two 32-channel 3x3 layers of the stem (Conv2d_2a 149^2 x 32 -> 32
+// valid, Conv2d_2b 147^2 x 32 -> 64 padded, as two 32-cout launches; 3.0 of the trunk's 21.5 conv ms).  With
+// Cin = 32 a K-step is one tap, 6 MFMAs per wave per 32 couts, and the per-tap implicit GEMM moves 16 KB of pixels
+// + 4 KB of weights for it: 5-6x more DMA cycles than MFMA cycles.  Here, per workgroup (8 waves, one per CU,
+// persistent over a CONTIGUOUS run of 128-pixel tiles of the input grid):
+//   * the weights of all 9 taps (36 KB) are DMA'd once and stay in LDS;
+//   * the input lives in a RING of 128 + 2W + 2 (+ 256) grid pixels x 32 channels x 2 planes: a tap is a row offset
+//     (kh-PH)*W + (kw-PW) into it, and a new tile only adds the 128 grid pixels behind the previous window (16 KB
+//     instead of 9 x 16 KB per tile), fetched two tiles ahead;
+//   * waves 0-3 (one per SIMD) do nothing but fragment reads and MFMAs -- 54 back-to-back MFMAs per tile, the next
+//     tap's fragments requested before the current tap's MFMAs -- and hand the combined fp32 accumulators to LDS;
+//   * waves 4-7 issue the DMA (an LDS-DMA instruction holds its wave ~125 cycles once the queue is full) and run
+//     the epilogue of the PREVIOUS tile from the hand-off buffer (scale, bias, ReLU, re-split, 16-byte stores),
+//     so neither ever stalls the MFMA stream;
+//   * one workgroup barrier per tile.
+// Ordering per tile `it` (barrier X(it) at the end of the iteration):
+//   compute waves:  taps(it) from ring rows [128 it, 128 it + R16)  ->  hand-off buffer it & 1
+//   service waves:  epilogue(it-1) from hand-off (it-1) & 1;  DMA of the rows of tile it+2 (they replace the oldest
+//                   128 rows of tile it-1, whose taps ended before X(it-1));  vmcnt(4): the rows of tile it+1 have
+//                   landed (loads return in order, and the only younger loads are the four just issued; the
+//                   epilogue's stores were issued BEFORE them, so they can only make the wait longer)
+// Border handling as the other window kernels (valid: grid pixels without an output are computed and dropped;
+// padded: fragments masked per lane and tap).
+template <int KHC, int KWC>
+__global__ __launch_bounds__(512, 1) void conv_win32_kernel(const ConvArgs p, const int R16, const long long ntiles,
+                                                            const int n0) {
+    constexpr int BN = 32;
+    constexpr int B_PLANE = BN * 64;                      // one plane of one tap's weight tile
+    constexpr int B_TAP = 2 * B_PLANE;
+    constexpr int ntaps = KHC * KWC;                      // compile-time filter: the tap loop is fully unrolled
+    constexpr int HAND = conv_epi::Staging<1>::BYTES;     // hand-off bytes per wave and buffer (>= 4 KB; doubles as staging)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ring = R16 + 256;                           // rows per plane
+    const int win_plane = ring * 64, win_bytes = 2 * win_plane;
+    unsigned char* bres = lds;                            // resident weights
+    unsigned char* wbuf = lds + ntaps * B_TAP;            // window ring
+    unsigned char* epi_area = wbuf + win_bytes;           // chunk descriptors + scale / bias, prepared once
+    unsigned char* hand = epi_area + 2048;                // 2 buffers x 4 waves x HAND
+
+    const long long G = (long long)gridDim.x;
+    const long long slot = blockIdx.x;
+    const long long mgrid = (long long)p.N * p.H * p.W;
+    const int minoff = -p.PH * p.W - p.PW;
+    const int cl = (lane & 3) ^ ((lane >> 4) & 3);
+    const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
+    const _Float16* wgt = reinterpret_cast<const _Float16*>(p.w);
+    const _Float16* zp = reinterpret_cast<const _Float16*>(g_pipe_zero_page);
+
+    // a workgroup walks a contiguous run of tiles
+    const long long per = (ntiles + G - 1) / G;
+    const long long t_begin = slot * per, t_end = (t_begin + per < ntiles) ? t_begin + per : ntiles;
+    if (t_begin >= ntiles) return;
+    const long long g_base = t_begin * 128 + minoff;      // grid pixel of relative row 0
+    const long long ntl = t_end - t_begin;
+
+    // resident weights: tap t, plane, 16-row block rb  ->  bres + t * B_TAP + plane * B_PLANE + rb * 1024
+    for (int q = wave; q < ntaps * 4; q += 8) {
+        const int t = q >> 2, r = q & 3;
+        const int plane = r >> 1, rb = r & 1;
+        const _Float16* src = wgt + (plane ? p.w_plane : 0) + (long long)(n0 + rb * 16 + (lane >> 2)) * p.Kpad + t * CP_BK + cl * 8;
+        unsigned char* dst = bres + t * B_TAP + plane * B_PLANE + rb * 1024;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
+    }
+// DMA of NPC 16-row pieces per plane starting at relative row REL0 (relative to g_base; a multiple of 16);
+// physical row = relative row mod ring
+#define W32_ROWS(REL0, NPC, Q0, QS)                                                                       \
+    {                                                                                                     \
+        for (int q = (Q0); q < 2 * (NPC); q += (QS)) {                                                     \
+            const int plane = q >= (NPC) ? 1 : 0;                                                          \
+            const int rb = q - plane * (NPC);                                                              \
+            const long long rel = (REL0) + rb * 16;                                                        \
+            const long long g = g_base + rel + (lane >> 2);                                                \
+            const bool ok = g >= 0 && g < mgrid;                                                           \
+            const _Float16* src = xg + (plane ? p.x_plane : 0) + g * p.Cin + cl * 8;                       \
+            src = ok ? src : zp;                                                                           \
+            unsigned char* dst = wbuf + plane * win_plane + (int)(rel % ring) * 64;                        \
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);                               \
+        }                                                                                                  \
+    }
+    // window of the first tile and the new rows of the second (R16 + 128 rows), by all eight waves
+    W32_ROWS(0, (R16 >> 4) + 8, wave, 8)
+    {
+        conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
+        if (tid < BN / 4) {
+            sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + n0 + 4 * tid);
+            bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + n0 + 4 * tid);
+        }
+        static_assert(conv_epi::EpiArea<BN>::BYTES <= 2048, "epilogue area");
+        conv_epi::prepare<BN>(p, epi_area, n0, sc_pre, bs_pre);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    if (wave >= 4) {
+        // ---- service waves: DMA two tiles ahead, epilogue one tile behind ------------------------------------
+        const int cw = wave - 4;                           // the compute wave whose tiles this wave finishes
+        for (long long it = 0; it <= ntl; ++it) {          // iteration ntl only drains the last epilogue
+            if (it >= 1 && !(p.nseg & 0x400)) {
+                const unsigned char* hb = hand + ((it - 1) & 1) * 4 * HAND + cw * HAND;
+                float16_t am[1][1], ac[1][1];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const conv_epi::float4_t v = *reinterpret_cast<const conv_epi::float4_t*>(hb + (g * 64 + lane) * 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { am[0][0][4 * g + k] = v[k]; ac[0][0][4 * g + k] = 0.f; }
+                }
+                // the hand-off bytes of this wave are consumed (LDS operations of a wave execute in order): reuse them
+                // as the staging tile of the stores
+                conv_epi::store_tiles_desc<1, 1, true>(p, am, ac, const_cast<unsigned char*>(hb), epi_area,
+                                                       (t_begin + it - 1) * 128 + cw * 32);
+            }
+            if (it + 2 < ntl) { W32_ROWS((long long)R16 + (it + 1) * 128, 8, cw, 4) }
+            if (it < ntl) {
+                if (it + 2 < ntl) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();              // X(it)
+                asm volatile("" ::: "memory");
+            }
+        }
+        return;
+    }
+    // ---- compute waves ------------------------------------------------------------------------------------------
+    const int fswz = ((lane & 31) >> 2) & 3;
+    const int fb0 = (lane & 31) * 64 + ((lane >> 5) ^ fswz) * 16;
+    const int fb1 = (lane & 31) * 64 + ((2 + (lane >> 5)) ^ fswz) * 16;
+    const int lrow0 = wave * 32 + (lane & 31) - minoff;   // window row of this lane's tile row at offset 0
+    const unsigned hw = (unsigned)(p.H * p.W);
+    for (long long it = 0; it < ntl; ++it) {
+        const long long tile = t_begin + it;
+        unsigned tapmask = 0xffffffffu;                    // per-lane tap validity (padded convolutions)
+        if (p.PH | p.PW) {
+            const unsigned g = (unsigned)(tile * 128) + wave * 32 + (lane & 31);      // grid pixels < 2^31 (launcher)
+            const unsigned rem = g % hw;
+            const int y = (int)(rem / (unsigned)p.W), x = (int)rem - y * p.W;
+            tapmask = 0u;
+#pragma unroll
+            for (int t = 0; t < ntaps; ++t) {
+                const int yy = y + t / KWC - p.PH, xx = x + t % KWC - p.PW;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) tapmask |= 1u << t;
+            }
+        }
+        float16_t acc_main, acc_corr;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc_main[j] = 0.f; acc_corr[j] = 0.f; }
+        const int wstart = (int)((it * 128) % ring);       // physical row of this tile's window row 0
+        half8_t fa_[2][2][2], fb_[2][2][2];
+#define W32_READS(TAP, BUF)                                                                               \
+        {                                                                                                  \
+            const int kh_ = (TAP) / KWC, kw_ = (TAP) % KWC;                                                \
+            int wrow = wstart + lrow0 + (kh_ - p.PH) * p.W + (kw_ - p.PW);                                 \
+            wrow = wrow >= ring ? wrow - ring : wrow;                                                      \
+            const int aswz = (wrow >> 2) & 3;                                                              \
+            const unsigned char* ap = wbuf + wrow * 64;                                                    \
+            const unsigned char* bb = bres + (TAP) * B_TAP;                                                \
+            const unsigned am = (tapmask >> (TAP)) & 1u ? 0xffffffffu : 0u;                                \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                \
+                const int ao = ((2 * s + (lane >> 5)) ^ aswz) * 16;                                        \
+                u32x4_t ah = *reinterpret_cast<const u32x4_t*>(ap + ao);                                   \
+                u32x4_t al = *reinterpret_cast<const u32x4_t*>(ap + win_plane + ao);                       \
+                ah &= am; al &= am;                                                                        \
+                fa_[BUF][s][0] = __builtin_bit_cast(half8_t, ah);                                          \
+                fa_[BUF][s][1] = __builtin_bit_cast(half8_t, al);                                          \
+                const unsigned char* bp = bb + (s ? fb1 : fb0);                                            \
+                fb_[BUF][s][0] = *reinterpret_cast<const half8_t*>(bp);                                    \
+                fb_[BUF][s][1] = *reinterpret_cast<const half8_t*>(bp + B_PLANE);                          \
+            }                                                                                              \
+        }
+#define W32_MFMAS(BUF)                                                                                    \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
+            acc_corr = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[BUF][s][1], fa_[BUF][s][0], acc_corr, 0, 0, 0); \
+            acc_main = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[BUF][s][0], fa_[BUF][s][0], acc_main, 0, 0, 0); \
+            acc_corr = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[BUF][s][0], fa_[BUF][s][1], acc_corr, 0, 0, 0); \
+        }
+        if (!(p.nseg & 0x200)) {
+        W32_READS(0, 0)
+#pragma unroll
+        for (int tap = 0; tap < ntaps; ++tap) {
+            if (tap + 1 < ntaps) {
+                if ((tap + 1) & 1) { W32_READS(tap + 1, 1) } else { W32_READS(tap + 1, 0) }
+            }
+            if (tap & 1) { W32_MFMAS(1) } else { W32_MFMAS(0) }
+        }
+        }
+        // hand the combined accumulator over: value j of lane l -> float4 slot (j >> 2) * 64 + l
+        unsigned char* hb = hand + (it & 1) * 4 * HAND + wave * HAND;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            conv_epi::float4_t v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = acc_main[4 * g + k] + acc_corr[4 * g + k] * (1.0f / 2048.0f);
+            *reinterpret_cast<conv_epi::float4_t*>(hb + (g * 64 + lane) * 16) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                      // X(it)
+        asm volatile("" ::: "memory");
+    }
+}
+
+int launch_win32(const ConvArgs* a, hipStream_t st) {
+    if (a->Cin != 32 || a->SH != 1 || a->SW != 1 || a->KH != 3 || a->KW != 3 || a->Kpad != 9 * 32 || a->W < 8 ||
+        (long long)a->N * a->H * a->W >= 0x7fffff00LL)
+        return TISE_ERR_INVALID_ARG;
+    const int R = 128 + 2 * a->W + 2;
+    const int R16 = (R + 15) & ~15;
+    const size_t lds = 9 * 32 * 128 + (size_t)(R16 + 256) * 128 + 2048 + 8 * (size_t)conv_epi::Staging<1>::BYTES;
+    if (lds > 160 * 1024) return TISE_ERR_UNSUPPORTED;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win32_kernel<3, 3>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_lds = lds;
+    }
+    const long long mg = (long long)a->N * a->H * a->W;
+    const long long ntiles = (mg + 127) / 128;
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        TISE_HIP_CHECK(hipGetDevice(&dev));
+        TISE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long grid = ntiles < ncu ? ntiles : ncu;
+    for (int n0 = 0; n0 < a->Cout; n0 += 32) {            // 32 couts per launch (the weights of 9 taps x 32 couts stay in LDS)
+        hipLaunchKernelGGL((conv_win32_kernel<3, 3>), dim3((unsigned)grid), dim3(512), lds, st, *a, R16, ntiles, n0);
+    }
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
 }  // namespace
 
 // cfg: tile width / wave layout / schedule.  Ping-pong schedule: 0: 128 couts (4x2 waves of 64x64)  1: 96 (8x1 of
 // 32x96)  2: 64 (8x1 of 32x64)  4: 64 (4x2 of 64x32)  5: 32 (8x1 of 32x32).  Lockstep schedule (all waves in
 // the same phase): 8, 9, 10 = the layouts of 0, 1, 2;  3: 160 (8x1 of 32x160)  6: 128 (8x1 of 32x128).
+// Resident-weights sliding-window kernel for Cin = 32, 3x3, stride 1: 33 (32 couts per launch).
 // Window kernel (stride 1, more than one tap): 11, 12, 13, 14 = 128, 96, 64, 32 couts (ping-pong);
 // 7, 15 = 128, 96 couts lockstep.
 int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream) {
@@ -706,6 +942,7 @@ int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream) {
         case 9: return launch_cfg<1, 1, 3, false>(a, st);
         case 10: return launch_cfg<1, 1, 2, false>(a, st);
         case 3: return launch_cfg<1, 1, 5, false>(a, st);
+        case 33: return launch_win32(a, st);
         case 7: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<2, 2, 2, false>(a, st);
         case 15: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<1, 1, 3, false>(a, st);
         case 11: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<2, 2, 2, true>(a, st);

@@ -1021,7 +1021,7 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
             return TISE_ERR_INVALID_ARG;
     }
     if (args->seg[0].c0 != 0) return TISE_ERR_INVALID_ARG;
-    if (tn & 512) return tise_conv_pipe_launch(args, tn & 15, stream);   // persistent 3-stage kernel, weights [tap][Cin_pad]
+    if (tn & 512) return tise_conv_pipe_launch(args, tn & 255, stream);   // persistent 3-stage kernel, weights [tap][Cin_pad]
     const bool glds = (tn & (16 | 128)) != 0, glds3 = (tn & 32) != 0, gldsb = (tn & 64) != 0;
     // fast path: K order (tap, full 32-channel block) then paired 16-channel tails (see the kernel); Kpad says which
     const int fast_kpad = (args->KH * args->KW * (args->Cin / 32) + ((args->Cin & 16) ? (args->KH * args->KW + 1) / 2 : 0)) * 32;
