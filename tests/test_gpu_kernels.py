@@ -538,6 +538,44 @@ def test_conv_pipe_many_tiles_per_workgroup(dev):
         assert d <= 2e-6 * merge(outs[0]).abs().max().item(), d
 
 
+@pytest.mark.parametrize("case", [(17, 17, 160, 160, 1, 7, 1, (0, 3), 40), (35, 35, 64, 96, 3, 3, 1, (1, 1), 41),
+                                  (35, 35, 288, 384, 3, 3, 2, (0, 0), 43), (8, 8, 320, 1344, 1, 1, 1, (0, 0), 40),
+                                  (9, 9, 64, 80, 1, 1, 1, (0, 0), 42), (13, 13, 96, 208, 1, 1, 1, (0, 0), 44),
+                                  (11, 7, 32, 48, 3, 3, 1, (1, 1), 42)])
+def test_conv_spec_kernels_match_fp64_conv(dev, case):
+    """conv_pipe.hip wave-specialised kernel (four compute waves, four DMA / descriptor waves, one barrier per K-step):
+    every configuration against fp64, including 1- and 2-step tiles (the service waves then run up to three tiles
+    ahead of the epilogues that read their descriptors), M and Cout tails, three segments, repeatability."""
+    from tise_toolbox_amd.conv_split import SplitConv, merge, split
+    H, W, Cin, Cout, kh, kw, st, pad, cfg = case
+    g = torch.Generator(device="cpu").manual_seed(Cin + Cout + kh + cfg)
+    n = 41
+    x = (torch.rand((n, H, W, Cin), generator=g) * 3.0).to(dev)
+    w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+    conv = SplitConv(w, b, (st, st), pad, dev, variant="pipe", pipe_cfg=cfg)
+    oh, ow = conv.out_hw(H, W)
+    ref_lin = torch.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, st, pad).permute(0, 2, 3, 1)
+    ref = torch.relu(ref_lin + b.double())
+    scale = ref.abs().max().item()
+    first = None
+    for rep in range(3):
+        out = torch.zeros((2, n, oh, ow, Cout + 32), dtype=torch.float16, device=dev)
+        raw = torch.zeros((n, oh, ow, 16), dtype=torch.float32, device=dev)
+        segs = [(0, 16, out, 16, 0), (16, 32, raw, 0, 1)] + ([(32, Cout, out, 64, 0)] if Cout > 32 else [])
+        conv(split(x), segs)
+        got = merge(out)
+        assert (got[..., 16:32].double() - ref[..., 0:16]).abs().max().item() <= 4e-6 * scale
+        if Cout > 32:
+            assert (got[..., 64:].double() - ref[..., 32:]).abs().max().item() <= 4e-6 * scale
+        assert (raw.double() - ref_lin[..., 16:32]).abs().max().item() <= 4e-6 * scale
+        assert got[..., :16].abs().max().item() == 0 and got[..., 32:64].abs().max().item() == 0
+        if first is None:
+            first = (out.clone(), raw.clone())
+        else:
+            assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
+
+
 def test_split_trunk_batch_sizes_and_determinism(dev):
     """pool3 features must not depend on how images are batched, and must repeat bit for bit."""
     from tise_toolbox_amd.inception import InceptionV3

@@ -60,7 +60,7 @@ def pick_tn(cout):
 
 # conv_pipe.hip tile widths by configuration index, and the configuration for a given Cout: least padded work,
 # ties to the wider tile
-PIPE_BN = {0: 128, 1: 96, 2: 64, 3: 160, 4: 64, 5: 32, 6: 128, 8: 128, 9: 96, 10: 64, 11: 128, 12: 96, 13: 64, 14: 32, 7: 128, 15: 96, 33: 32}
+PIPE_BN = {0: 128, 1: 96, 2: 64, 3: 160, 4: 64, 5: 32, 6: 128, 8: 128, 9: 96, 10: 64, 11: 128, 12: 96, 13: 64, 14: 32, 7: 128, 15: 96, 33: 32, 40: 128, 41: 96, 42: 64, 43: 128, 44: 160}
 
 
 def pick_pipe_cfg(cout):

@@ -171,8 +171,9 @@ struct EpiArea {
 // all threads of the workgroup; area = LDS behind the staging tiles.  sc_pre / bs_pre: scale / bias of couts
 // n0 + 4*tid .. +3 held by threads tid < BN / 4.  Caller issues __syncthreads() afterwards.
 template <int BN>
-__device__ __forceinline__ void prepare(const tise_conv_args& p, unsigned char* area, int n0, float4_t sc_pre, float4_t bs_pre) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void prepare(const tise_conv_args& p, unsigned char* area, int n0, float4_t sc_pre, float4_t bs_pre,
+                                        int tid = -1) {
+    if (tid < 0) tid = threadIdx.x;
     const int nseg = p.nseg & 0xff;
     if (tid < BN / 4) {
         *reinterpret_cast<float4_t*>(area + EpiArea<BN>::SCALE + tid * 16) = sc_pre;
@@ -195,11 +196,13 @@ __device__ __forceinline__ void prepare(const tise_conv_args& p, unsigned char* 
 // acc[0][t]: tile rows m0w .. m0w+31 (this wave), couts n0 + 32*t .. +31.  tw: the wave's staging bytes.
 // GRID = true (window kernels): tile rows are pixels of the input grid; the (n, y, x) of a lane's first row comes
 // from two 32-bit divisions and is stepped forward per pass (grid pixel counts < 2^31: launcher).
-template <int TNW, int TW, bool GRID = false>
+// BN_AREA: tile width the descriptor area was prepared for (default: this wave's TNW tiles are the whole tile);
+// chunk0: first 8-cout chunk of this wave inside the tile (wave layouts with more than one wave along the couts).
+template <int TNW, int TW, bool GRID = false, int BN_AREA = 32 * TNW>
 __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float16_t (&acc_main)[1][TNW],
                                                  float16_t (&acc_corr)[1][TNW], unsigned char* tw,
-                                                 const unsigned char* area, long long m0w) {
-    constexpr int BN = 32 * TNW;
+                                                 const unsigned char* area, long long m0w, int chunk0 = 0) {
+    constexpr int BN = BN_AREA;
     constexpr int PITCH = Staging<TW>::PITCH;
     const int lane = threadIdx.x & 63;
     const long long left = (GRID ? (long long)p.N * p.H * p.W : p.M) - m0w;   // rows of this tile that exist (wave-uniform)
@@ -214,7 +217,7 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float1
             const int t = t0 + u;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int chunk = t * 4 + g;
+                const int chunk = chunk0 + t * 4 + g;
                 const int mode = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(area + EpiArea<BN>::DESC + chunk * 32 + 24));
                 const int ch = chunk * 8 + 4 * (lane >> 5);
                 const float4_t sc = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::SCALE + ch * 4);
@@ -242,7 +245,7 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float1
         const int lpr = 8 * nt;                               // lanes per pixel row: 8 or 16
         const int rows_per_pass = 64 / lpr;
         const int row0 = lane / lpr, q = lane % lpr;
-        const ChunkDesc cd = *reinterpret_cast<const ChunkDesc*>(area + EpiArea<BN>::DESC + (t0 * 4 + (q >> 1)) * 32);
+        const ChunkDesc cd = *reinterpret_cast<const ChunkDesc*>(area + EpiArea<BN>::DESC + (chunk0 + t0 * 4 + (q >> 1)) * 32);
         const unsigned char* src = tw + row0 * PITCH + q * 16;
         if (!GRID) {
             unsigned char* d = reinterpret_cast<unsigned char*>(cd.base + (m0w + row0) * cd.row_stride + ((q & 1) ? cd.second : 0));

@@ -921,12 +921,241 @@ int launch_win32(const ConvArgs* a, hipStream_t st) {
     return TISE_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised persistent kernel.  What made conv_win32_kernel pay is taken to the general case (Cin % 32 == 0):
+// the ablations show DMA-only time ~= MFMA-only time ~= 55-65 % of a launch of the 2-stage kernel and the two
+// adding up, because every wave does both -- an LDS-DMA instruction holds its wave ~125 cycles once the queue is
+// full, and that is on the critical path of the wave's MFMAs.  Here a persistent workgroup of 8 waves splits:
+//   waves 0-3 (one per SIMD): fragment reads + MFMAs of a 128-pixel x BN-cout tile, then the tile's epilogue from
+//              their own staging area (conv_epilogue.h, descriptors written by the service waves);
+//   waves 4-7: the DMA cursor, two K-steps ahead across tile boundaries (three LDS stages), one counted vmcnt and
+//              one barrier per K-step; at a tile boundary they also stage scale / bias / destination descriptors
+//              of the tile they are entering (double-buffered: the compute waves are two steps behind).
+// Ordering per K-step g:  service: vmcnt(L) [stage g landed: loads return in order, only the L pieces of step g+1 are
+// younger] -> barrier X(g) -> DMA of step g+2 into stage (g+2) % 3 = (g-1) % 3 (read in step g-1, which every compute
+// wave finished before X(g)).  compute: barrier X(g) -> reads + MFMAs of stage g % 3.
+template <int WN, int TMW, int TNW>
+__global__ __launch_bounds__(512, 1) void conv_spec_kernel(const ConvArgs p, const int tiles_n, const long long ntiles) {
+    constexpr int WM = 4 / WN;
+    constexpr int BM = 32 * TMW * WM;
+    static_assert(BM == 128, "tile is 128 pixels");
+    constexpr int BN = 32 * TNW * WN;
+    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
+    constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
+    constexpr int NBP = BN / 32;                          // weight DMA pieces per service wave and stage
+    constexpr int L = 4 + NBP;
+    constexpr int ETW = (TNW > 1) ? 2 : 1;
+    constexpr int EPI = 2048;                             // bytes of one descriptor / scale / bias area
+    static_assert(conv_epi::EpiArea<BN>::BYTES <= EPI, "epilogue area");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char* epi_area = lds + 3 * STAGE;            // four areas (tile index & 3): the service waves run up to three tiles ahead
+    unsigned char* staging = epi_area + 4 * EPI;          // 4 compute waves x Staging<ETW>::BYTES
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long long G = (long long)gridDim.x;
+    long long slot = blockIdx.x;
+    {
+        const long long q = G >> 3, r = G & 7, xcd = slot & 7, idx = slot >> 3;
+        slot = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ncb = p.Cin / CP_BK;
+    const int nsteps = p.KH * p.KW * ncb;
+    const long long my_tiles = slot < ntiles ? (ntiles - slot + G - 1) / G : 0;
+    const long long total = my_tiles * nsteps;
+    if (total == 0) return;
+
+    if (wave >= 4) {
+        // ================================ service waves: DMA cursor ======================================
+        const int sw = wave - 4;
+        const int stid = tid - 256;
+        const int cl = (lane & 3) ^ ((lane >> 4) & 3);
+        const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
+        const _Float16* wgt = reinterpret_cast<const _Float16*>(p.w);
+        const _Float16* zp = reinterpret_cast<const _Float16*>(g_pipe_zero_page);
+        const unsigned ohw = (unsigned)(p.OH * p.OW), M32 = (unsigned)p.M;
+        long long is_v = slot;
+        int kh = 0, kw = 0, cb = 0, is_stage = 0, tile_par = 0;
+        long long issued = 0;
+        int ih0[2], iw0[2];
+        const _Float16* img[2];
+        bool rok[2];
+        const unsigned char* pa_hi[2];
+        const unsigned char* pa_lo[2];
+        long long pa_inc[2];
+        const _Float16* pb[NBP];
+        int pb_off[NBP];
+        long long pb_row[NBP];
+#pragma unroll
+        for (int i = 0; i < NBP; ++i) {
+            const int q = sw * NBP + i;                   // 4 * NBP = BN / 8 pieces: 2 planes x BN / 16 row blocks
+            const int plane = q >= BN / 16 ? 1 : 0;
+            const int rb = q - plane * (BN / 16);
+            pb_row[i] = (plane ? p.w_plane : 0) + (long long)(rb * 16 + (lane >> 2)) * p.Kpad + cl * 8;
+            pb_off[i] = 2 * A_PLANE + plane * B_PLANE + rb * 1024;
+        }
+#define CS_TAP()                                                                                          \
+        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                 \
+            const int ih = ih0[jj] + kh, iw = iw0[jj] + kw;                                                \
+            const bool ok = rok[jj] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                         \
+            const _Float16* src = img[jj] + ((long long)ih * p.W + iw) * p.Cin;                            \
+            pa_hi[jj] = reinterpret_cast<const unsigned char*>(ok ? src : zp);                             \
+            pa_lo[jj] = reinterpret_cast<const unsigned char*>(ok ? src + p.x_plane : zp);                 \
+            pa_inc[jj] = ok ? CP_BK * 2 : 0;                                                               \
+        }
+// enter tile is_v: pixel decode (32-bit: M < 2^31, launcher), weight pointers, and the epilogue descriptors of the tile
+#define CS_TILE()                                                                                         \
+        {                                                                                                  \
+            const unsigned tm_ = (unsigned)(is_v / tiles_n);                                               \
+            const int tn_ = (int)(is_v - (long long)tm_ * tiles_n);                                        \
+            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                             \
+                const unsigned pix = tm_ * BM + (2 * sw + jj) * 16 + (lane >> 2);                          \
+                rok[jj] = pix < M32;                                                                       \
+                const unsigned pp = rok[jj] ? pix : 0u;                                                    \
+                const unsigned n = pp / ohw;                                                               \
+                const unsigned rem = pp - n * ohw;                                                         \
+                const unsigned oh = rem / (unsigned)p.OW, ow = rem - oh * (unsigned)p.OW;                  \
+                ih0[jj] = (int)oh * p.SH - p.PH;                                                           \
+                iw0[jj] = (int)ow * p.SW - p.PW;                                                           \
+                img[jj] = xg + (long long)n * p.H * p.W * p.Cin + cl * 8;                                  \
+            }                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < NBP; ++i)                                                \
+                pb[i] = wgt + (long long)tn_ * BN * p.Kpad + pb_row[i];                                    \
+            {                                                                                              \
+                conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};           \
+                if (stid < BN / 4) {                                                                       \
+                    sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + tn_ * BN + 4 * stid);  \
+                    bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + tn_ * BN + 4 * stid);   \
+                }                                                                                          \
+                conv_epi::prepare<BN>(p, epi_area + tile_par * EPI, tn_ * BN, sc_pre, bs_pre, stid);       \
+                tile_par = (tile_par + 1) & 3;                                                             \
+            }                                                                                              \
+            kh = 0; kw = 0; cb = 0;                                                                        \
+            CS_TAP()                                                                                       \
+        }
+#define CS_ISSUE()                                                                                        \
+        {                                                                                                  \
+            unsigned char* sb_ = lds + is_stage * STAGE;                                                   \
+            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                             \
+                const unsigned char* sh = pa_hi[jj];                                                       \
+                const unsigned char* sl = pa_lo[jj];                                                       \
+                unsigned char* da_ = sb_ + (2 * sw + jj) * 1024;                                           \
+                __builtin_amdgcn_global_load_lds(sh, (lds_ptr_t)da_, 16, 0, 0);                            \
+                __builtin_amdgcn_global_load_lds(sl, (lds_ptr_t)(da_ + A_PLANE), 16, 0, 0);                \
+                pa_hi[jj] = sh + pa_inc[jj];                                                               \
+                pa_lo[jj] = sl + pa_inc[jj];                                                               \
+            }                                                                                              \
+            _Pragma("unroll") for (int i = 0; i < NBP; ++i) {                                              \
+                const _Float16* sw_ = pb[i];                                                               \
+                unsigned char* dw_ = sb_ + pb_off[i];                                                      \
+                __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)dw_, 16, 0, 0);                           \
+                pb[i] = sw_ + CP_BK;                                                                       \
+            }                                                                                              \
+            is_stage = is_stage == 2 ? 0 : is_stage + 1;                                                   \
+            ++issued;                                                                                      \
+            if (++cb == ncb) {                                                                             \
+                cb = 0;                                                                                    \
+                if (++kw == p.KW) { kw = 0; ++kh; }                                                        \
+                if (kh == p.KH) {                                                                          \
+                    is_v += G;                                                                             \
+                    if (issued < total) CS_TILE()                                                          \
+                } else {                                                                                   \
+                    CS_TAP()                                                                               \
+                }                                                                                          \
+            }                                                                                              \
+        }
+        CS_TILE()
+        CS_ISSUE()
+        if (issued < total) CS_ISSUE()
+        for (long long g = 0; g < total; ++g) {
+            if (issued > g + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // descriptor writes of CS_TILE
+            __builtin_amdgcn_s_barrier();                                 // X(g)
+            asm volatile("" ::: "memory");
+            if (issued < total) CS_ISSUE()
+        }
+        return;
+    }
+    // ==================================== compute waves ==============================================
+    const int wm = wave / WN, wn = wave - wm * WN;
+    float16_t acc_main[TMW][TNW], acc_corr[TMW][TNW];
+    CP_ZERO()
+    const int fswz = ((lane & 31) >> 2) & 3;
+    const int fo0 = (lane & 31) * 64 + (((lane >> 5)) ^ fswz) * 16;
+    const int fo1 = (lane & 31) * 64 + ((2 + (lane >> 5)) ^ fswz) * 16;
+    const int fa_off = wm * TMW * 32 * 64;
+    const int fb_off = 2 * A_PLANE + wn * TNW * 32 * 64;
+    constexpr int NREADS = 4 * (TMW + TNW), NGROUPS = 2 * TMW * TNW;
+    constexpr int NR2 = (NREADS - 4) / 2;
+    long long c_v = slot;
+    int c_step = 0, c_stage = 0, c_par = 0;
+    for (long long g = 0; g < total; ++g) {
+        __builtin_amdgcn_s_barrier();                                     // X(g)
+        asm volatile("" ::: "memory");
+        const unsigned char* sb = lds + c_stage * STAGE;
+        CP_COMPUTE(sb)
+        c_stage = c_stage == 2 ? 0 : c_stage + 1;
+        if (++c_step == nsteps) {
+            const long long tm_ = c_v / tiles_n;
+            const int tn_ = (int)(c_v - tm_ * tiles_n);
+            // a wave owns TMW row tiles: one call per row tile (store_tiles_desc handles one 32-row strip)
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                float16_t am[1][TNW], ac[1][TNW];
+#pragma unroll
+                for (int t = 0; t < TNW; ++t) { am[0][t] = acc_main[i][t]; ac[0][t] = acc_corr[i][t]; }
+                conv_epi::store_tiles_desc<TNW, ETW, false, BN>(p, am, ac, staging + wave * conv_epi::Staging<ETW>::BYTES,
+                                                                epi_area + c_par * EPI, tm_ * BM + (wm * TMW + i) * 32, wn * TNW * 4);
+            }
+            (void)tn_;
+            CP_ZERO()
+            c_step = 0;
+            c_v += G;
+            c_par = (c_par + 1) & 3;
+        }
+    }
+}
+
+template <int WN, int TMW, int TNW>
+int launch_spec(const ConvArgs* a, hipStream_t st) {
+    constexpr int BN = 32 * TNW * WN;
+    constexpr int STAGE = 2 * 128 * 64 + 2 * BN * 64;
+    constexpr int ETW = (TNW > 1) ? 2 : 1;
+    constexpr int LDS = 3 * STAGE + 4 * 2048 + 4 * conv_epi::Staging<ETW>::BYTES;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    if (a->Cin % 32 != 0 || a->Kpad != a->KH * a->KW * a->Cin || a->M >= 0x7fffff00LL) return TISE_ERR_INVALID_ARG;
+    static bool attr_set = false;
+    if (!attr_set) {
+        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_spec_kernel<WN, TMW, TNW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int tiles_n = (a->Cout + BN - 1) / BN;
+    const long long ntiles = ((a->M + 127) / 128) * tiles_n;
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        TISE_HIP_CHECK(hipGetDevice(&dev));
+        TISE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long grid = ntiles < ncu ? ntiles : ncu;
+    hipLaunchKernelGGL((conv_spec_kernel<WN, TMW, TNW>), dim3((unsigned)grid), dim3(512), LDS, st, *a, tiles_n, ntiles);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
 }  // namespace
 
 // cfg: tile width / wave layout / schedule.  Ping-pong schedule: 0: 128 couts (4x2 waves of 64x64)  1: 96 (8x1 of
 // 32x96)  2: 64 (8x1 of 32x64)  4: 64 (4x2 of 64x32)  5: 32 (8x1 of 32x32).  Lockstep schedule (all waves in
 // the same phase): 8, 9, 10 = the layouts of 0, 1, 2;  3: 160 (8x1 of 32x160)  6: 128 (8x1 of 32x128).
 // Resident-weights sliding-window kernel for Cin = 32, 3x3, stride 1: 33 (32 couts per launch).
+// Wave-specialised persistent kernel (Cin % 32 == 0), 128-pixel tiles: 40 (128 couts, 2x2 compute waves), 41 (96), 42 (64),
+// 43 (128, 4x1), 44 (160).
 // Window kernel (stride 1, more than one tap): 11, 12, 13, 14 = 128, 96, 64, 32 couts (ping-pong);
 // 7, 15 = 128, 96 couts lockstep.
 int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream) {
@@ -943,6 +1172,11 @@ int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream) {
         case 10: return launch_cfg<1, 1, 2, false>(a, st);
         case 3: return launch_cfg<1, 1, 5, false>(a, st);
         case 33: return launch_win32(a, st);
+        case 40: return launch_spec<2, 2, 2>(a, st);       // 128 couts, compute waves 2 x 2 of 64 x 64
+        case 41: return launch_spec<1, 1, 3>(a, st);       // 96 couts, compute waves 4 x 1 of 32 x 96
+        case 42: return launch_spec<1, 1, 2>(a, st);       // 64
+        case 43: return launch_spec<1, 1, 4>(a, st);       // 128, 4 x 1 of 32 x 128
+        case 44: return launch_spec<1, 1, 5>(a, st);       // 160
         case 7: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<2, 2, 2, false>(a, st);
         case 15: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<1, 1, 3, false>(a, st);
         case 11: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<2, 2, 2, true>(a, st);

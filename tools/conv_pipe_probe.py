@@ -37,7 +37,9 @@ for li, (H, Cin, Cout, kh, kw, st, pad, cnt) in enumerate(LAYERS):
     for var, cfg in [("fast", None)] + [("pipe", c) for c in cfgs]:
         if cfg is not None and PIPE_BN[cfg] >= 2 * max(32, Cout):
             continue
-        if cfg is not None and (cfg >= 11 or cfg == 7) and (st != 1 or kh * kw == 1):
+        if cfg is not None and ((cfg >= 11 and cfg < 33) or cfg == 7) and (st != 1 or kh * kw == 1):
+            continue
+        if cfg is not None and cfg >= 40 and Cin % 32 != 0:
             continue
         conv = SplitConv(w, b, (st, st), pad, dev, variant=var, pipe_cfg=cfg)
         oh, ow = conv.out_hw(H, H)
