@@ -541,7 +541,10 @@ def test_conv_pipe_many_tiles_per_workgroup(dev):
 @pytest.mark.parametrize("case", [(17, 17, 160, 160, 1, 7, 1, (0, 3), 40), (35, 35, 64, 96, 3, 3, 1, (1, 1), 41),
                                   (35, 35, 288, 384, 3, 3, 2, (0, 0), 43), (8, 8, 320, 1344, 1, 1, 1, (0, 0), 40),
                                   (9, 9, 64, 80, 1, 1, 1, (0, 0), 42), (13, 13, 96, 208, 1, 1, 1, (0, 0), 44),
-                                  (11, 7, 32, 48, 3, 3, 1, (1, 1), 42)])
+                                  (11, 7, 32, 48, 3, 3, 1, (1, 1), 42), (17, 17, 160, 160, 1, 7, 1, (0, 3), 45),
+                                  (35, 35, 288, 384, 3, 3, 2, (0, 0), 45), (9, 9, 64, 80, 1, 1, 1, (0, 0), 46),
+                                  (8, 8, 320, 1344, 1, 1, 1, (0, 0), 47), (13, 13, 96, 208, 1, 1, 1, (0, 0), 47),
+                                  (11, 7, 32, 48, 3, 3, 1, (1, 1), 46)])
 def test_conv_spec_kernels_match_fp64_conv(dev, case):
     """conv_pipe.hip wave-specialised kernel (four compute waves, four DMA / descriptor waves, one barrier per K-step):
     every configuration against fp64, including 1- and 2-step tiles (the service waves then run up to three tiles
@@ -574,6 +577,27 @@ def test_conv_spec_kernels_match_fp64_conv(dev, case):
             first = (out.clone(), raw.clone())
         else:
             assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
+
+
+def test_conv_spec_many_tiles_bitwise_vs_default(dev):
+    """More tiles than compute units through the wave-specialised kernels (the DMA cursor crosses tile boundaries two
+    K-steps ahead of the MFMAs; 256-pixel tiles stage their epilogue in the stage the last step consumed): same K
+    order as the default kernel, so the outputs must be bit-identical, run after run."""
+    from tise_toolbox_amd.conv_split import SplitConv, split
+    g = torch.Generator(device="cpu").manual_seed(13)
+    for (n, H, Cin, Cout, kh, cfg) in [(500, 17, 128, 128, 1, 45), (500, 17, 96, 160, 1, 47), (300, 9, 64, 64, 3, 46),
+                                        (300, 17, 128, 128, 1, 40), (64, 35, 32, 64, 1, 42), (500, 8, 256, 240, 1, 45)]:
+        x = (torch.rand((n, H, H, Cin), generator=g) * 2.0).to(dev)
+        w = (torch.randn((Cout, Cin, kh, kh), generator=g) * (2.0 / (Cin * kh * kh)) ** 0.5).to(dev)
+        b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+        xs = split(x)
+        ref = torch.zeros((2, n, H, H, Cout), dtype=torch.float16, device=dev)
+        SplitConv(w, b, (1, 1), (kh // 2, kh // 2), dev, variant="fast")(xs, [(0, Cout, ref, 0, 0)])
+        conv = SplitConv(w, b, (1, 1), (kh // 2, kh // 2), dev, variant="pipe", pipe_cfg=cfg)
+        for rep in range(3):
+            out = torch.full_like(ref, 3.0)
+            conv(xs, [(0, Cout, out, 0, 0)])
+            assert torch.equal(out, ref), (cfg, rep)
 
 
 def test_split_trunk_batch_sizes_and_determinism(dev):

@@ -60,7 +60,7 @@ def pick_tn(cout):
 
 # conv_pipe.hip tile widths by configuration index, and the configuration for a given Cout: least padded work,
 # ties to the wider tile
-PIPE_BN = {0: 128, 1: 96, 2: 64, 3: 160, 4: 64, 5: 32, 6: 128, 8: 128, 9: 96, 10: 64, 11: 128, 12: 96, 13: 64, 14: 32, 7: 128, 15: 96, 33: 32, 40: 128, 41: 96, 42: 64, 43: 128, 44: 160}
+PIPE_BN = {0: 128, 1: 96, 2: 64, 3: 160, 4: 64, 5: 32, 6: 128, 8: 128, 9: 96, 10: 64, 11: 128, 12: 96, 13: 64, 14: 32, 7: 128, 15: 96, 33: 32, 40: 128, 41: 96, 42: 64, 43: 128, 44: 160, 45: 128, 46: 96, 47: 128}
 
 
 def pick_pipe_cfg(cout):
@@ -72,6 +72,20 @@ def pick_pipe_cfg(cout):
         if best is None or key < best[0]:
             best = (key, cfg)
     return best[1]
+
+
+# Optional per-layer kernel choice (TISE_CONV_AUTO=1), from tools/conv_pipe_probe.py on the trunk's shapes at batch 500
+# (medians of three runs, profiles/r01i_conv_spec256_probe.txt): in isolation, on dense random inputs, the
+# wave-specialised 256-pixel kernel of conv_pipe.hip (configuration 45: 4 x 2 compute waves of 64 x 64; 47: 8 x 1 of
+# 32 x 128) is 5-13 % faster than the default kernel on the deep 1x1 layers and on Mixed_6a's 3x3 stride-2 conv.
+# Inside the trunk (ReLU-sparse activations, kernels back to back) the gain shrinks to 1-3 % per layer and the bench
+# shows none (25.73 vs 25.69 ms/step over three alternating runs), so it is OFF by default.
+# Key: (Cin, Cout, KH, KW, stride).  Results are bit-identical either way (same K order).
+AUTO_PIPE_CFG = {
+    (768, 704, 1, 1, 1): 45, (768, 768, 1, 1, 1): 45, (768, 640, 1, 1, 1): 47, (768, 384, 1, 1, 1): 45,
+    (288, 240, 1, 1, 1): 45, (256, 240, 1, 1, 1): 47, (192, 208, 1, 1, 1): 45,
+    (2048, 1344, 1, 1, 1): 47, (1280, 1344, 1, 1, 1): 47, (288, 384, 3, 3, 2): 45,
+}
 
 
 class SplitConv:
@@ -94,6 +108,10 @@ class SplitConv:
         # "fast" = glds with hoisted addressing (default), "win" = window-resident input for stride-1
         # multi-tap layers (A/B variant: measured equal to "fast" within +-3 %, profiles/r01g_conv_window_probe.txt)
         self.variant = variant or os.environ.get("TISE_CONV_VARIANT", "fast")
+        if variant is None and self.variant == "fast" and os.environ.get("TISE_CONV_AUTO", "0") == "1":
+            auto = AUTO_PIPE_CFG.get((cin, cout, kh, kw, self.stride[0]))
+            if auto is not None and self.stride[0] == self.stride[1]:
+                self.variant, pipe_cfg = "pipe", auto
         bn = 32 * self.tn
         if self.variant == "pipe":                              # persistent 3-stage kernel (conv_pipe.hip)
             self.pipe_cfg = pick_pipe_cfg(cout) if pipe_cfg is None else pipe_cfg

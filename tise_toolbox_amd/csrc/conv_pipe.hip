@@ -935,17 +935,22 @@ int launch_win32(const ConvArgs* a, hipStream_t st) {
 // Ordering per K-step g:  service: vmcnt(L) [stage g landed: loads return in order, only the L pieces of step g+1 are
 // younger] -> barrier X(g) -> DMA of step g+2 into stage (g+2) % 3 = (g-1) % 3 (read in step g-1, which every compute
 // wave finished before X(g)).  compute: barrier X(g) -> reads + MFMAs of stage g % 3.
-template <int WN, int TMW, int TNW>
-__global__ __launch_bounds__(512, 1) void conv_spec_kernel(const ConvArgs p, const int tiles_n, const long long ntiles) {
-    constexpr int WM = 4 / WN;
+template <int WN, int TMW, int TNW, int CW>
+__global__ __launch_bounds__(64 * (CW + 4), 1) void conv_spec_kernel(const ConvArgs p, const int tiles_n, const long long ntiles) {
+    // CW compute waves (4: one per SIMD, 128-pixel tiles; 8: two per SIMD, 256-pixel tiles) + 4 service waves
+    constexpr int WM = CW / WN;
     constexpr int BM = 32 * TMW * WM;
-    static_assert(BM == 128, "tile is 128 pixels");
+    static_assert(BM == 32 * CW, "128 pixels per four compute waves");
+    constexpr int NJ = BM / 64;                           // pixel rows per service-wave lane
     constexpr int BN = 32 * TNW * WN;
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
     constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
     constexpr int NBP = BN / 32;                          // weight DMA pieces per service wave and stage
-    constexpr int L = 4 + NBP;
-    constexpr int ETW = (TNW > 1) ? 2 : 1;
+    constexpr int L = 2 * NJ + NBP;
+    // epilogue staging: CW = 4: a dedicated area (two tiles wide); CW = 8: the stage the tile's last step consumed
+    // (the service waves refill it only after the barrier the compute waves reach after their epilogue)
+    constexpr int ETW = (CW == 4 && TNW > 1) ? 2 : 1;
+    static_assert(CW == 4 || CW * conv_epi::Staging<1>::BYTES <= STAGE, "staging must fit a stage");
     constexpr int EPI = 2048;                             // bytes of one descriptor / scale / bias area
     static_assert(conv_epi::EpiArea<BN>::BYTES <= EPI, "epilogue area");
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -966,10 +971,10 @@ __global__ __launch_bounds__(512, 1) void conv_spec_kernel(const ConvArgs p, con
     const long long total = my_tiles * nsteps;
     if (total == 0) return;
 
-    if (wave >= 4) {
+    if (wave >= CW) {
         // ================================ service waves: DMA cursor ======================================
-        const int sw = wave - 4;
-        const int stid = tid - 256;
+        const int sw = wave - CW;
+        const int stid = tid - 64 * CW;
         const int cl = (lane & 3) ^ ((lane >> 4) & 3);
         const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
         const _Float16* wgt = reinterpret_cast<const _Float16*>(p.w);
@@ -978,12 +983,12 @@ __global__ __launch_bounds__(512, 1) void conv_spec_kernel(const ConvArgs p, con
         long long is_v = slot;
         int kh = 0, kw = 0, cb = 0, is_stage = 0, tile_par = 0;
         long long issued = 0;
-        int ih0[2], iw0[2];
-        const _Float16* img[2];
-        bool rok[2];
-        const unsigned char* pa_hi[2];
-        const unsigned char* pa_lo[2];
-        long long pa_inc[2];
+        int ih0[NJ], iw0[NJ];
+        const _Float16* img[NJ];
+        bool rok[NJ];
+        const unsigned char* pa_hi[NJ];
+        const unsigned char* pa_lo[NJ];
+        long long pa_inc[NJ];
         const _Float16* pb[NBP];
         int pb_off[NBP];
         long long pb_row[NBP];
@@ -996,7 +1001,7 @@ __global__ __launch_bounds__(512, 1) void conv_spec_kernel(const ConvArgs p, con
             pb_off[i] = 2 * A_PLANE + plane * B_PLANE + rb * 1024;
         }
 #define CS_TAP()                                                                                          \
-        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                 \
+        _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                                \
             const int ih = ih0[jj] + kh, iw = iw0[jj] + kw;                                                \
             const bool ok = rok[jj] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                         \
             const _Float16* src = img[jj] + ((long long)ih * p.W + iw) * p.Cin;                            \
@@ -1009,8 +1014,8 @@ __global__ __launch_bounds__(512, 1) void conv_spec_kernel(const ConvArgs p, con
         {                                                                                                  \
             const unsigned tm_ = (unsigned)(is_v / tiles_n);                                               \
             const int tn_ = (int)(is_v - (long long)tm_ * tiles_n);                                        \
-            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                             \
-                const unsigned pix = tm_ * BM + (2 * sw + jj) * 16 + (lane >> 2);                          \
+            _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                            \
+                const unsigned pix = tm_ * BM + (NJ * sw + jj) * 16 + (lane >> 2);                         \
                 rok[jj] = pix < M32;                                                                       \
                 const unsigned pp = rok[jj] ? pix : 0u;                                                    \
                 const unsigned n = pp / ohw;                                                               \
@@ -1037,10 +1042,10 @@ __global__ __launch_bounds__(512, 1) void conv_spec_kernel(const ConvArgs p, con
 #define CS_ISSUE()                                                                                        \
         {                                                                                                  \
             unsigned char* sb_ = lds + is_stage * STAGE;                                                   \
-            _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                             \
+            _Pragma("unroll") for (int jj = 0; jj < NJ; ++jj) {                                            \
                 const unsigned char* sh = pa_hi[jj];                                                       \
                 const unsigned char* sl = pa_lo[jj];                                                       \
-                unsigned char* da_ = sb_ + (2 * sw + jj) * 1024;                                           \
+                unsigned char* da_ = sb_ + (NJ * sw + jj) * 1024;                                          \
                 __builtin_amdgcn_global_load_lds(sh, (lds_ptr_t)da_, 16, 0, 0);                            \
                 __builtin_amdgcn_global_load_lds(sl, (lds_ptr_t)(da_ + A_PLANE), 16, 0, 0);                \
                 pa_hi[jj] = sh + pa_inc[jj];                                                               \
@@ -1075,6 +1080,10 @@ __global__ __launch_bounds__(512, 1) void conv_spec_kernel(const ConvArgs p, con
             __builtin_amdgcn_s_barrier();                                 // X(g)
             asm volatile("" ::: "memory");
             if (issued < total) CS_ISSUE()
+            if (CW == 8 && (g + 1) % nsteps == 0) {                       // E: see the compute waves' tile end
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
         }
         return;
     }
@@ -1098,6 +1107,10 @@ __global__ __launch_bounds__(512, 1) void conv_spec_kernel(const ConvArgs p, con
         CP_COMPUTE(sb)
         c_stage = c_stage == 2 ? 0 : c_stage + 1;
         if (++c_step == nsteps) {
+            if (CW == 8) {                                                // E: every compute wave has read its last fragments
+                __builtin_amdgcn_s_barrier();                             // before the consumed stage becomes staging
+                asm volatile("" ::: "memory");
+            }
             const long long tm_ = c_v / tiles_n;
             const int tn_ = (int)(c_v - tm_ * tiles_n);
             // a wave owns TMW row tiles: one call per row tile (store_tiles_desc handles one 32-row strip)
@@ -1106,7 +1119,9 @@ __global__ __launch_bounds__(512, 1) void conv_spec_kernel(const ConvArgs p, con
                 float16_t am[1][TNW], ac[1][TNW];
 #pragma unroll
                 for (int t = 0; t < TNW; ++t) { am[0][t] = acc_main[i][t]; ac[0][t] = acc_corr[i][t]; }
-                conv_epi::store_tiles_desc<TNW, ETW, false, BN>(p, am, ac, staging + wave * conv_epi::Staging<ETW>::BYTES,
+                unsigned char* stg = CW == 4 ? staging + wave * conv_epi::Staging<ETW>::BYTES
+                                             : lds + (c_stage == 0 ? 2 : c_stage - 1) * STAGE + wave * conv_epi::Staging<ETW>::BYTES;
+                conv_epi::store_tiles_desc<TNW, ETW, false, BN>(p, am, ac, stg,
                                                                 epi_area + c_par * EPI, tm_ * BM + (wm * TMW + i) * 32, wn * TNW * 4);
             }
             (void)tn_;
@@ -1118,22 +1133,23 @@ __global__ __launch_bounds__(512, 1) void conv_spec_kernel(const ConvArgs p, con
     }
 }
 
-template <int WN, int TMW, int TNW>
+template <int WN, int TMW, int TNW, int CW>
 int launch_spec(const ConvArgs* a, hipStream_t st) {
     constexpr int BN = 32 * TNW * WN;
-    constexpr int STAGE = 2 * 128 * 64 + 2 * BN * 64;
-    constexpr int ETW = (TNW > 1) ? 2 : 1;
-    constexpr int LDS = 3 * STAGE + 4 * 2048 + 4 * conv_epi::Staging<ETW>::BYTES;
+    constexpr int BM = 32 * CW;
+    constexpr int STAGE = 2 * BM * 64 + 2 * BN * 64;
+    constexpr int ETW = (CW == 4 && TNW > 1) ? 2 : 1;
+    constexpr int LDS = 3 * STAGE + 4 * 2048 + (CW == 4 ? 4 * conv_epi::Staging<ETW>::BYTES : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     if (a->Cin % 32 != 0 || a->Kpad != a->KH * a->KW * a->Cin || a->M >= 0x7fffff00LL) return TISE_ERR_INVALID_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_spec_kernel<WN, TMW, TNW>),
+        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_spec_kernel<WN, TMW, TNW, CW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
     }
     const int tiles_n = (a->Cout + BN - 1) / BN;
-    const long long ntiles = ((a->M + 127) / 128) * tiles_n;
+    const long long ntiles = ((a->M + BM - 1) / BM) * tiles_n;
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
@@ -1143,7 +1159,7 @@ int launch_spec(const ConvArgs* a, hipStream_t st) {
         ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const long long grid = ntiles < ncu ? ntiles : ncu;
-    hipLaunchKernelGGL((conv_spec_kernel<WN, TMW, TNW>), dim3((unsigned)grid), dim3(512), LDS, st, *a, tiles_n, ntiles);
+    hipLaunchKernelGGL((conv_spec_kernel<WN, TMW, TNW, CW>), dim3((unsigned)grid), dim3(64 * (CW + 4)), LDS, st, *a, tiles_n, ntiles);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
@@ -1172,11 +1188,14 @@ int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream) {
         case 10: return launch_cfg<1, 1, 2, false>(a, st);
         case 3: return launch_cfg<1, 1, 5, false>(a, st);
         case 33: return launch_win32(a, st);
-        case 40: return launch_spec<2, 2, 2>(a, st);       // 128 couts, compute waves 2 x 2 of 64 x 64
-        case 41: return launch_spec<1, 1, 3>(a, st);       // 96 couts, compute waves 4 x 1 of 32 x 96
-        case 42: return launch_spec<1, 1, 2>(a, st);       // 64
-        case 43: return launch_spec<1, 1, 4>(a, st);       // 128, 4 x 1 of 32 x 128
-        case 44: return launch_spec<1, 1, 5>(a, st);       // 160
+        case 40: return launch_spec<2, 2, 2, 4>(a, st);       // 128 couts, compute waves 2 x 2 of 64 x 64
+        case 41: return launch_spec<1, 1, 3, 4>(a, st);       // 96 couts, compute waves 4 x 1 of 32 x 96
+        case 42: return launch_spec<1, 1, 2, 4>(a, st);       // 64
+        case 43: return launch_spec<1, 1, 4, 4>(a, st);       // 128, 4 x 1 of 32 x 128
+        case 44: return launch_spec<1, 1, 5, 4>(a, st);       // 160
+        case 45: return launch_spec<2, 2, 2, 8>(a, st);       // 256 pixels x 128 couts: 8 compute waves 4 x 2 of 64 x 64
+        case 46: return launch_spec<1, 1, 3, 8>(a, st);       // 256 x 96: 8 x 1 of 32 x 96
+        case 47: return launch_spec<1, 1, 4, 8>(a, st);       // 256 x 128: 8 x 1 of 32 x 128
         case 7: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<2, 2, 2, false>(a, st);
         case 15: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<1, 1, 3, false>(a, st);
         case 11: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<2, 2, 2, true>(a, st);
