@@ -47,7 +47,7 @@ int tise_device_info(int* cu_count, int* gcn_arch_is_gfx950, size_t* total_mem);
  * vertical pass -> u8) and the per-channel affine of image_realism/FID/inception.py:120-124.
  *
  *   src_dev   n images, HWC uint8, contiguous (n, h, w, 3)
- *   dst_dev   fp32, (n, 3, oh, ow) when nhwc == 0, (n, oh, ow, 3) when nhwc != 0
+ *   dst_dev   fp32, (n, 3, oh, ow) when nhwc == 0, (n, oh, ow, 3) when nhwc != 0; NULL: only u8_out_dev is produced
  *             (the latter is torch.channels_last storage of an NCHW tensor)
  *   lut       host pointer, 3*256 floats: lut[c*256 + v] = value written for channel c and
  *             resized byte v (the shim fills it with fp32(v)/255 then the inception.py affine,
@@ -182,6 +182,11 @@ int tise_maxpool3s2_split_nhwc(const void* x_dev, int64_t x_ld, int x_off, int64
  * ReLU + fp16 split fused: out planes (n, oh, ow, 32).  w_dev: [kh][kw][cin][cout] fp32 (27 x 32). */
 int tise_stem_conv3x3s2_split(const float* x_dev, int n, int h, int w, const float* w_dev, const float* bias_dev,
                               void* out_dev, int64_t out_plane, void* stream);
+/* The same layer from the uint8 NHWC result of tise_resize_bilinear_u8 (called with dst_dev = NULL and u8_out_dev set):
+ * lut_dev is the 3 x 256 fp32 table (device copy) that ToTensor + the inception.py:120-124 affine tabulate, applied
+ * while loading; bit-identical to the fp32 entry point on the table's values. */
+int tise_stem_conv3x3s2_split_u8(const uint8_t* x_dev, const float* lut_dev, int n, int h, int w, const float* w_dev,
+                                 const float* bias_dev, void* out_dev, int64_t out_plane, void* stream);
 /* Global average of split planes (n, hw, C) -> fp32 (n, C): AdaptiveAvgPool2d((1,1)) of the last block. */
 int tise_split_mean_nhwc(const void* x_dev, int64_t x_plane, int n, int hw, int C, float* out_dev, void* stream);
 

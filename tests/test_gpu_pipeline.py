@@ -217,3 +217,18 @@ def test_hipgraph_replay_matches_eager(cuda_device, monkeypatch):
             f1, l1 = graphed.features_from_u8(batch)
             assert torch.equal(f0, f1) and torch.equal(l0, l1), (rep, lo)
     assert sum(1 for k in graphed._graphs if not (isinstance(k[0], str))) == 2
+
+
+def test_u8_stem_path_bit_identical_to_fp32_input_path(cuda_device, monkeypatch):
+    """TISE_U8_STEM (default on for the all-HIP trunk): resize writes uint8 only and the stem conv applies the input
+    table; features and logits must equal the fp32-input path bit for bit."""
+    from tise_toolbox_amd.engine import RealismEngine
+    imgs = torch.from_numpy(_cases.smooth_images(24, 256, 256, seed=33)).to(cuda_device)
+    monkeypatch.setenv("TISE_U8_STEM", "0")
+    a = RealismEngine(dims=2048, seed=0, with_logits=True)
+    monkeypatch.setenv("TISE_U8_STEM", "1")
+    b = RealismEngine(dims=2048, seed=0, with_logits=True)
+    assert b._u8_stem and not a._u8_stem
+    fa, la = a.features_from_u8(imgs)
+    fb, lb = b.features_from_u8(imgs)
+    assert torch.equal(fa, fb) and torch.equal(la, lb)

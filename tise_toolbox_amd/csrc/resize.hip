@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
         int k0 = 0, k1 = 0, k2 = 0;
         if (h != oh && cnt <= 3) { k0 = k[0]; k1 = cnt > 1 ? k[1] : 0; k2 = cnt > 2 ? k[2] : 0; }
         const int p1 = cnt > 1 ? tmp_pitch : 0, p2 = cnt > 2 ? 2 * tmp_pitch : 0;
-        float* drow_nhwc = dst + ((size_t)img * oh + y) * (size_t)rowlen;
+        float* drow_nhwc = dst ? dst + ((size_t)img * oh + y) * (size_t)rowlen : nullptr;
         uint8_t* urow = u8_out ? u8_out + ((size_t)img * oh + y) * (size_t)rowlen : nullptr;
 #pragma unroll
         for (int j = 0; j < RS_MAXE; ++j) {
@@ -301,9 +301,11 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
                 for (int yy = 0; yy < cnt; ++yy) ss += (int)tp[(size_t)yy * tmp_pitch] * k[yy];
                 v = clip8(ss);
             }
-            const float f = lut_s[e_lut[j] + v];
-            if (nhwc) drow_nhwc[e] = f;
-            else dst[(((size_t)img * 3 + (e_lut[j] >> 8)) * oh + y) * ow + e_dst[j]] = f;
+            if (dst) {                                      // dst == nullptr: uint8 result only (the stem conv applies the table)
+                const float f = lut_s[e_lut[j] + v];
+                if (nhwc) drow_nhwc[e] = f;
+                else dst[(((size_t)img * 3 + (e_lut[j] >> 8)) * oh + y) * ow + e_dst[j]] = f;
+            }
             if (urow) urow[e] = v;
         }
     }
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
 
 extern "C" int tise_resize_bilinear_u8(const uint8_t* src_dev, int n, int h, int w, float* dst_dev, int oh, int ow,
                                        int nhwc, const float* lut, uint8_t* u8_out_dev, void* stream) {
-    if (n < 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || !lut || (n > 0 && (!src_dev || !dst_dev)))
+    if (n < 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || !lut || (n > 0 && (!src_dev || (!dst_dev && !u8_out_dev))))
         return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
     if (n > 65535) return TISE_ERR_UNSUPPORTED;

@@ -251,6 +251,53 @@ __global__ __launch_bounds__(256) void stem_conv3x3s2_split_kernel(const float* 
     }
 }
 
+// The same convolution reading the Pillow-exact uint8 pixels (resize kernel, float output switched off) and applying
+// the 3 x 256 input table itself: 134 MB instead of 536 MB of network input written and read per 500 images.
+__global__ __launch_bounds__(256) void stem_conv3x3s2_split_u8_kernel(const uint8_t* __restrict__ x, const float* __restrict__ lut, int N, int H, int W,
+                                                                   const float* __restrict__ wt,   // [27][32]
+                                                                   const float* __restrict__ bias, // [32]
+                                                                   _Float16* __restrict__ out, int64_t out_plane) {
+    __shared__ float ws[27 * 32];
+    __shared__ float lut_s[3 * 256];                         // byte -> network input value per channel (device.make_lut)
+    for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = wt[i];
+    for (int i = threadIdx.x; i < 3 * 256; i += 256) lut_s[i] = lut[i];
+    __syncthreads();
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+    const int64_t total = (int64_t)N * OH * OW * 4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = e >> 2;
+        const int cg = (int)(e & 3) * 8;
+        const int ow = (int)(p % OW);
+        const int oh = (int)((p / OW) % OH);
+        const int64_t n = p / ((int64_t)OW * OH);
+        const uint8_t* xp = x + ((n * H + 2 * oh) * W + 2 * ow) * 3;
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const uint8_t* xr = xp + (int64_t)kh * W * 3;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {                    // (kw, cin) = 9 contiguous floats of the input row
+                const float v = lut_s[(t % 3) * 256 + xr[t]];   // same value the fp32 path reads: results are bit-identical
+                const float* wr = ws + (kh * 9 + t) * 32 + cg;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
+            }
+        }
+        half8v h, l;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float v = fmaxf(acc[c] + bias[cg + c], 0.f);
+            h[c] = (_Float16)v;
+            l[c] = (_Float16)((v - (float)h[c]) * 2048.f);
+        }
+        _Float16* d = out + p * 32 + cg;
+        *reinterpret_cast<half8v*>(d) = h;
+        *reinterpret_cast<half8v*>(d + out_plane) = l;
+    }
+}
+
 // split planes (N, HW, C) -> fp32 (N, C) mean over the HW positions (AdaptiveAvgPool2d((1,1)) of the last
 // block): thread = (image, 8 channels), fixed summation order.
 __global__ __launch_bounds__(256) void split_mean_kernel(const _Float16* __restrict__ x, int64_t x_plane, int N, int HW,
@@ -378,6 +425,17 @@ int tise_stem_conv3x3s2_split(const float* x_dev, int n, int h, int w, const flo
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
     hipLaunchKernelGGL(stem_conv3x3s2_split_kernel, dim3(grid_for((int64_t)n * oh * ow * 4)), dim3(256), 0,
                        (hipStream_t)stream, x_dev, n, h, w, w_dev, bias_dev, reinterpret_cast<_Float16*>(out_dev), out_plane);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+int tise_stem_conv3x3s2_split_u8(const uint8_t* x_dev, const float* lut_dev, int n, int h, int w, const float* w_dev,
+                                 const float* bias_dev, void* out_dev, int64_t out_plane, void* stream) {
+    if (!x_dev || !lut_dev || !w_dev || !bias_dev || !out_dev || n < 0 || h < 3 || w < 3) return TISE_ERR_INVALID_ARG;
+    if (n == 0) return TISE_OK;
+    const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
+    hipLaunchKernelGGL(stem_conv3x3s2_split_u8_kernel, dim3(grid_for((int64_t)n * oh * ow * 4)), dim3(256), 0,
+                       (hipStream_t)stream, x_dev, lut_dev, n, h, w, w_dev, bias_dev, reinterpret_cast<_Float16*>(out_dev), out_plane);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }

@@ -79,6 +79,22 @@ def resize_bilinear_u8(src_u8, out_hw=(299, 299), lut=None, channels_last=True, 
     return (out, u8) if return_u8 else out
 
 
+def resize_u8_only(src_u8, out_hw=(299, 299)):
+    """(N,H,W,3) uint8 CUDA tensor -> the Pillow-exact resized uint8 image (N,oh,ow,3); no float output (the stem
+    convolution applies the input table itself: SplitTrunk.forward_u8)."""
+    _require_cuda(src_u8)
+    if src_u8.dtype != torch.uint8 or src_u8.dim() != 4 or src_u8.shape[3] != 3:
+        raise ValueError("src_u8 must be (N,H,W,3) uint8")
+    src_u8 = src_u8.contiguous()
+    n, h, w, _ = src_u8.shape
+    oh, ow = out_hw
+    u8 = torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=src_u8.device)
+    lut = np.ascontiguousarray(make_lut(True), dtype=np.float32)          # unused by the kernel when dst is NULL
+    _lib.call("tise_resize_bilinear_u8", _ptr(src_u8), n, h, w, None, oh, ow, 1,
+              lut.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _ptr(u8), _stream())
+    return u8
+
+
 class StatsAccumulator:
     """fp64 running {n, sum x, sum x x^T} on the device (tise_stats_* in include/tise_hip.h)."""
 

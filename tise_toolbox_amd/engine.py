@@ -91,12 +91,24 @@ class RealismEngine:
         # host is the slower side (small batches).  Only for the all-HIP trunk (MIOpen picks solvers at run time).
         from .trunk import SplitTrunk as _ST
         self._graph_ok = isinstance(self.fused, _ST) and os.environ.get("TISE_GRAPH", "0") == "1"
+        self._u8_stem = isinstance(self.fused, _ST) and os.environ.get("TISE_U8_STEM", "1") != "0"
+        self.lut_dev = torch.from_numpy(np.ascontiguousarray(self.lut, dtype=np.float32).reshape(-1)).to(self.device)
         self._graphs = {}
 
     # ---- per-batch device work -----------------------------------------------------------------
     def _features_from_u8_eager(self, batch_u8):
+        if self._u8_stem:
+            # all-HIP trunk: the resize kernel writes the Pillow-exact uint8 image only and the stem convolution
+            # applies the input table (134 MB instead of 536 MB of network input per 500 images; same features)
+            return self._trunk_u8(device.resize_u8_only(batch_u8, (299, 299)))
         x = device.resize_bilinear_u8(batch_u8, (299, 299), self.lut, channels_last=self.channels_last)
         return self._trunk(x, prenormalized=True)
+
+    def _trunk_u8(self, u8):
+        pred = self.fused.forward_u8(u8, self.lut_dev)
+        feats = pred.reshape(pred.shape[0], -1)
+        logits = self.model.logits(feats) if self.with_logits else None
+        return feats, logits
 
     @torch.no_grad()
     def features_from_u8(self, batch_u8):

@@ -380,6 +380,22 @@ class SplitTrunk(FusedTrunk):
         a = self._new(n, oh, ow, 32, x.device)
         _lib.call("tise_stem_conv3x3s2_split", _p(x), n, h, w, _p(self.stem_w), _p(self.c1a.b), _p(a), a.stride(0),
                   _stream())
+        return self._after_stem(a)
+
+    @torch.no_grad()
+    def forward_u8(self, u8_nhwc, lut_dev):
+        """The same forward from the resized uint8 image (N,299,299,3) and the 3x256 input table on the device: the
+        stem conv looks the network input values up itself (bit-identical features, 4x less input traffic)."""
+        assert u8_nhwc.dtype == torch.uint8 and u8_nhwc.is_contiguous() and u8_nhwc.shape[3] == 3
+        assert lut_dev.dtype == torch.float32 and lut_dev.numel() == 768 and lut_dev.is_contiguous()
+        n, h, w, _ = u8_nhwc.shape
+        oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+        a = self._new(n, oh, ow, 32, u8_nhwc.device)
+        _lib.call("tise_stem_conv3x3s2_split_u8", _p(u8_nhwc), _p(lut_dev), n, h, w, _p(self.stem_w), _p(self.c1a.b), _p(a),
+                  a.stride(0), _stream())
+        return self._after_stem(a)
+
+    def _after_stem(self, a):
         a = self._sconv(self.s2a, a)
         a = self._maxpool_split(self._sconv(self.s2b, a))
         a = self._sconv(self.s3b, a)
