@@ -271,7 +271,7 @@ def main():
             # algorithmic flop (hi*hi, hi*lo, lo*hi), so its ceiling is the dense fp16 MFMA peak / 3.
             kern["conv_split_fast_kernel"] = {
                 "instances": "conv_split_fast_kernel<TN=1..5> (64 launches) + conv_win32_kernel (Conv2d_2a): all 65 conv launches of a step, as rocprofv3 lists them "
-                             "(profiles/r01j_bench_steps10_kernel_stats.md)",
+                             "(profiles/r01k_bench_steps10_kernel_stats.md)",
                 "clock_note": "in-kernel stamps (profiles/r01g_conv_pipe_stamps.txt): 1.49 GHz while the MFMAs are busy, i.e. "
                               "~1550 TFLOP/s fp16 actually available; peak below is the 2.4 GHz datasheet figure / 3",
                 "bound": "mfma", "achieved": conv_flop / (conv_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3.0,
