@@ -1,8 +1,12 @@
 """CPU restatement of the reference IS* reductions (test infrastructure).
 
-The three reference modules cannot be imported (TensorFlow, or they run the
-whole evaluation at import), so each function below follows the cited lines
-statement by statement.  Inputs are LOGITS; the temperature/softmax the
+The three reference modules cannot be imported as they are (TensorFlow, or they
+run the whole evaluation at import), so each function below follows the cited
+lines statement by statement.  PINNED: tests/golden/make_golden_is.py runs the
+three reference scripts by path under stub tensorflow / torchvision modules and
+stores logits + the scores/text the reference computed (is_ref_*.npz);
+tests/test_oracle_golden.py::test_is_oracle_matches_reference_script_run checks
+this file against them.  Inputs are LOGITS; the temperature/softmax the
 reference applies inside its graph is restated in ``softmax_with_temperature``.
 """
 import numpy as np
@@ -11,6 +15,21 @@ from scipy.stats import entropy
 T_COCO = 0.9091363549232483   # image_realism/IS/coco/inception_score_star_coco.py:107
 T_BIRD = 0.5980541706085205   # image_realism/IS/bird/inception_score_star_bird.py:192
 T_OIS = 2.1737587451934814    # object_fidelity/O-IS/object_centric_inception_score.py:55
+
+
+def coco_text(mean, std):
+    """inception_score_star_coco.py:153-154 result-file text."""
+    return "[Inception Score] mean: {:.5f} std: {:.5f}".format(mean, std)
+
+
+def bird_text(mean, std):
+    """inception_score_star_bird.py:208-209."""
+    return f"IS = {mean}  +-  {std}"
+
+
+def ois_text(mean, std):
+    """object_centric_inception_score.py:126-127."""
+    return f"O-IS: {mean} +-  {std}"
 
 
 def softmax_with_temperature(logits, temperature, dtype=np.float32, drop_first_class=False):

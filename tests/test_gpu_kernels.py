@@ -265,6 +265,20 @@ def test_is_golden(dev, golden_dir, name):
     assert np.all(scores >= 1.0 - 1e-12) and np.all(scores <= g["logits"].shape[1])    # 1 <= IS <= C
 
 
+@pytest.mark.parametrize("name", ["is_ref_coco_57.npz", "is_ref_coco_130.npz", "is_ref_bird_150.npz", "is_ref_ois_97.npz"])
+def test_is_matches_reference_script_run(dev, golden_dir, name):
+    """is_score.hip against what the REFERENCE scripts computed from the same logits when run by path under
+    stub tensorflow / torchvision (tests/golden/make_golden_is.py).  |dIS| <= 1e-4 (north_star)."""
+    from tise_toolbox_amd import inception_score as isc
+    g = np.load(os.path.join(golden_dir, name))
+    rule, drop = str(g["rule"]), bool(g["drop_first"])
+    T = is_oracle.T_OIS if rule == "ois" else float(g["temperature"])
+    mean, std = isc.inception_score_from_logits(g["logits"], T, int(g["splits"]), rule, drop)
+    assert abs(mean - float(g["mean"])) <= 1e-4 and abs(std - float(g["std"])) <= 1e-4, (mean, std, g["mean"], g["std"])
+    if rule == "coco" and not drop:
+        assert "[Inception Score] mean: {:.5f} std: {:.5f}".format(mean, std) == str(g["expected_text"])
+
+
 @pytest.mark.parametrize("n,c,splits,rule", [(1000, 1000, 10, "coco"), (997, 80, 10, "ois"), (23, 51, 10, "coco"),
                                              (10, 7, 10, "coco"), (64, 1008, 3, "coco")])
 def test_is_sharded_updates_match_oracle(dev, n, c, splits, rule):

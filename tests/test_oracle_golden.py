@@ -84,6 +84,34 @@ def test_is_reduction_vectors(golden_dir, name):
     assert m == pytest.approx(m64, abs=1e-10) and s == pytest.approx(s64, abs=1e-10)
 
 
+REF_IS = ["is_ref_coco_57.npz", "is_ref_coco_130.npz", "is_ref_bird_150.npz", "is_ref_ois_97.npz"]
+
+
+@pytest.mark.parametrize("name", REF_IS)
+def test_is_oracle_matches_reference_script_run(golden_dir, name):
+    """Fixture = what the reference IS* scripts themselves computed/wrote when run by path under stub
+    tensorflow / torchvision (tests/golden/make_golden_is.py): logits in, (mean, std, text) out."""
+    g = np.load(os.path.join(golden_dir, name))
+    rule, drop = str(g["rule"]), bool(g["drop_first"])
+    if rule == "ois":
+        T, dtype = is_oracle.T_OIS, np.float32           # softmax in fp32 (torch), preds widened to fp64 (:60)
+        p32 = is_oracle.softmax_with_temperature(g["logits"], T, np.float32)
+        m, s = is_oracle.inception_score_ois(p32, int(g["splits"]))
+        assert abs(m - float(g["mean"])) <= 1e-6 and abs(s - float(g["std"])) <= 1e-6
+        assert is_oracle.ois_text(m, s)[:12] == str(g["expected_text"])[:12]
+    else:
+        T = float(g["temperature"])
+        assert T == (is_oracle.T_BIRD if drop else is_oracle.T_COCO)     # constant the reference's graph recorded
+        m, s = is_oracle.inception_score_from_logits(g["logits"], T, int(g["splits"]), rule, drop, dtype=np.float32)
+        # same fp32 statements; numpy's exp/log vs themselves: agreement at fp32 rounding of an O(10) score
+        assert abs(m - float(g["mean"])) <= 2e-6 * float(g["mean"]) and abs(s - float(g["std"])) <= 2e-5
+        if not drop:
+            assert is_oracle.coco_text(m, s) == str(g["expected_text"])
+    # exact-arithmetic (fp64) reading, which the device kernel is compared with, is inside the 1e-4 budget
+    m64, s64 = is_oracle.inception_score_from_logits(g["logits"], T, int(g["splits"]), rule, drop, dtype=np.float64)
+    assert abs(m64 - float(g["mean"])) <= 1e-4 and abs(s64 - float(g["std"])) <= 1e-4
+
+
 def test_ois_form_equals_coco_form_when_divisible():
     rng = np.random.default_rng(0)
     logits = rng.standard_normal((200, 40)).astype(np.float32)
