@@ -1,30 +1,40 @@
 #!/usr/bin/env python3
-"""Headline benchmark: images/sec through InceptionV3 + FID (+ IS*) on 256x256 images, MI355X.
+"""Headline benchmark: images/sec through InceptionV3 + FID (+ IS*) on 30k 256x256 images, MI355X.
 
     python bench.py --gpus 1 --steps 60 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A STEP is one pass of the hot path over one batch of `--batch` (default 500) synthetic uint8
-256x256x3 images that are already resident in HBM:
-    resize 256->299 (PIL-exact, csrc/resize.hip) -> InceptionV3 trunk + fc (PyTorch-ROCm, fp32)
-    -> fp64 covariance/mean accumulation (csrc/stats.hip) -> IS* split sums (csrc/is_score.hip).
-After the K steps the timed region also contains, once: the all-reduce of the sufficient
-statistics over RCCL (world > 1), the finalisation of (mu, sigma), the Frechet distance against
-pre-computed reference statistics (csrc/frechet.hip) and the IS* finalisation -- i.e. the whole job
-"IS* + FID on K*batch images per GPU" (BASELINE.json configs[1] at the default K*batch = 30 000).
-Each rank processes its own K*batch images (weak scaling); value = world * K * batch / seconds.
+The JOB is BASELINE.json's metric: IS* + FID of ONE set of K*500 synthetic uint8 256x256x3 images (30 000 at the
+default K = 60) that are already resident in HBM, against pre-computed reference statistics.  A STEP is 1/K of the
+job = one pass of the hot path over 500 images:
+    resize 256->299 (PIL-exact, csrc/resize.hip) -> InceptionV3 trunk (hand-written split-fp16 MFMA convolutions,
+    csrc/conv_split.hip / conv_pipe.hip / trunk_ops.hip) + fc -> fp64 covariance/mean accumulation (csrc/stats.hip)
+    -> IS* split sums (csrc/is_score.hip).
+With N GPUs the SAME job is sharded (STRONG scaling, SURVEY.md section 8(d) "Config 3"): rank r takes the
+contiguous index range dist.shard_range(K*500, r, N) (3 750 images at N = 8) and runs it in device batches that
+divide its range (500 / 500 / 500 / 750 at N = 1 / 2 / 4 / 8).  After the loop the timed region contains, once: the
+all-reduce of the sufficient statistics over RCCL, the finalisation of (mu, sigma), the Frechet distance
+(csrc/frechet.hip, solved redundantly on every rank) and the IS* finalisation.  value = K*500 / max-over-ranks
+seconds; `allreduce_ms` and `finalize_ms` are reported separately.  `--scaling weak` gives every rank its own
+K*500 images instead (round-1 behaviour).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the dominant hand-written kernel of the step loop, timed with HIP events inside the
-                timed region, against its gfx950 bound (see DESIGN.md "Measurement")
-  cpu_baseline  the CPU oracle (oracle/, numpy/scipy/torch-CPU restatement of the reference) timed
-                on this host on a bounded sample of the same workload (rank 0, N = 1 only)
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
+  roofline      the dominant hand-written kernel of the step loop, timed with HIP events inside the timed region,
+                against its gfx950 bound (DESIGN.md "Measurement")
+  parity        |dFID|, |dIS| of the device path against the CPU oracle on the first images of the timed set
+                (outside the timed region; N = 1 only)
+  cross_check   the whole timed set again through exact-fp32 MIOpen convolutions: |dFID|, |dIS|, max feature error
+                of the split-fp16 trunk at the job's full size (N = 1 only)
+  cpu_baseline  the CPU oracle (oracle/: numpy/scipy/torch-CPU restatement of the reference) timed on this host on
+                a bounded sample of the same workload (rank 0, N = 1 only)
 """
 import argparse
 import json
 import os
+import statistics
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -41,6 +51,7 @@ if ROOT not in sys.path:
 PEAK_HBM_GBS = 8000.0
 PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: "Peak BF16/FP16 MFMA ~2.5 PF dense"
+GLOBAL_STEP_IMAGES = 500
 
 
 def synth_images_device(lo, hi, device, seed=0, shift=0.0, hw=256):
@@ -77,48 +88,129 @@ def synth_images_device(lo, hi, device, seed=0, shift=0.0, hw=256):
     return out
 
 
-def cpu_baseline(sample_u8, n_job, dims=2048):
-    """Time the CPU oracle on a bounded sample (rank 0, N=1): resize + InceptionV3 forward on
-    `sample` images, np.mean/np.cov on 3000x2048 fp64, the reference-form Frechet distance
-    (scipy sqrtm) at d=2048, IS* reduction; combine to images/s for an n_job-image job."""
+def rank_batch(n_rank, preferred=GLOBAL_STEP_IMAGES, cap=750):
+    """Device batch of a rank: `preferred` when it divides the rank's image count, otherwise the largest divisor
+    <= cap (3 750 images at 8 GPUs -> 750); a count without a usable divisor runs `preferred` with a short tail."""
+    if n_rank <= 0:
+        return preferred
+    if n_rank % preferred == 0 or n_rank < preferred:
+        return min(preferred, n_rank)
+    for b in range(min(cap, n_rank), 127, -1):
+        if n_rank % b == 0:
+            return b
+    return preferred
+
+
+def _median_time(fn, repeats=3, warmup=1, budget_s=None):
+    """median wall time of fn() over `repeats` runs after `warmup` untimed runs; stops repeating once `budget_s`
+    seconds have been spent (at least one timed run)."""
+    for _ in range(warmup):
+        fn()
+    ts, spent = [], 0.0
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+        spent += ts[-1]
+        if budget_s is not None and spent > budget_s:
+            break
+    return statistics.median(ts), len(ts)
+
+
+def cpu_reference_pass(gen_u8, ref_u8, n_job, dims=2048, workers=8):
+    """The CPU oracle on THIS host (rank 0, N = 1), doing what the reference's CPU path does, stage by stage:
+
+      decode+resize  PNG files -> PIL decode -> PIL bilinear 299x299 -> ToTensor, DataLoader(batch 50, 8 workers) as
+                     fid_score.py:208-217 (Pillow is what the reference itself uses; resize_oracle is its restatement)
+      forward        oracle/inception_oracle.py fp32 InceptionV3 (torch CPU, all threads) at batch 50
+      cov            np.mean / np.cov(rowvar=False) on (n_job, 2048) float64            (fid_score.py:194-195)
+      frechet        scipy.linalg.sqrtm form, d = 2048                                   (fid_score.py:121-171)
+      is             the IS* reduction on (n_job, 1000) fp32 logits                      (inception_score_star_coco.py:52-60)
+
+    1 warm-up + 3 repeats (median) for the per-image stages on len(gen_u8) images; cov / sqrtm once at the job's
+    size.  Returns (cpu_baseline dict, oracle features/logits of gen and ref for the parity figures)."""
+    import torch.utils.data as tud
+    from PIL import Image
     from oracle import fid_oracle, inception_oracle, is_oracle, resize_oracle
     from tise_toolbox_amd.inception import build_inception3
     from tests import _cases
     threads = torch.get_num_threads()
     sd = {k: v.float() for k, v in build_inception3(seed=0).state_dict().items()}
-    n = sample_u8.shape[0]
-    t0 = time.perf_counter()
-    xs = np.stack([resize_oracle.to_tensor(resize_oracle.resize_bilinear_u8(im, 299, 299)) for im in sample_u8])
-    t_resize = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    feats, logits = [], []
-    for i in range(0, n, 16):
-        o = inception_oracle.inception_forward(sd, torch.from_numpy(xs[i:i + 16]))[3]
-        feats.append(o.flatten(1).numpy())
-        logits.append(inception_oracle.logits_from_pool3(sd, o).numpy())
-    t_fwd = time.perf_counter() - t0
-    x = _cases.pool3_like_features(3000, dims, 42)
-    y = _cases.pool3_like_features(2600, dims, 43, shift=0.1)
+    n = gen_u8.shape[0]
+    bs = 50
+
+    # ---- stage 1: PNG decode + PIL resize + ToTensor on 8 DataLoader workers (the reference's loader) ----
+    class _Files(tud.Dataset):
+        def __init__(self, files):
+            self.files = files
+
+        def __len__(self):
+            return len(self.files)
+
+        def __getitem__(self, i):
+            img = Image.open(self.files[i]).convert("RGB").resize((299, 299), Image.BILINEAR)
+            return torch.from_numpy(np.asarray(img, dtype=np.uint8).transpose(2, 0, 1).copy()).float().div_(255.0)
+
+    with tempfile.TemporaryDirectory(prefix="tise_bench_png_") as tmp:
+        files = []
+        for i in range(n):
+            p = os.path.join(tmp, f"{i:05d}.png")
+            Image.fromarray(gen_u8[i]).save(p)
+            files.append(p)
+        loader = tud.DataLoader(_Files(files), batch_size=bs, shuffle=False, drop_last=True, num_workers=workers)
+
+        def decode_pass():
+            for _ in loader:
+                pass
+        t_dec, r_dec = _median_time(decode_pass, repeats=3, warmup=1, budget_s=20.0)
+
+    # ---- stage 2: CPU fp32 forward (batch 50) ----
+    def to_input(u8):
+        return np.stack([resize_oracle.to_tensor(resize_oracle.resize_bilinear_u8(im, 299, 299)) for im in u8])
+
+    x_gen = to_input(gen_u8)
+    out = {}
+
+    def forward_pass(x=x_gen, key="gen"):
+        feats, logits = [], []
+        for i in range(0, x.shape[0], bs):
+            o = inception_oracle.inception_forward(sd, torch.from_numpy(x[i:i + bs]))[3]
+            feats.append(o.flatten(1).numpy())
+            logits.append(inception_oracle.logits_from_pool3(sd, o).numpy())
+        out[key] = (np.concatenate(feats), np.concatenate(logits))
+
+    inception_oracle.inception_forward(sd, torch.from_numpy(x_gen[:bs]))          # warm-up: oneDNN primitive creation
+    t_fwd, r_fwd = _median_time(forward_pass, repeats=3, warmup=0, budget_s=45.0)
+    forward_pass(to_input(ref_u8), "ref")                                         # parity partner set (untimed)
+
+    # ---- stages 3-5 at the job's size ----
+    x = _cases.pool3_like_features(n_job, dims, 42)
     t0 = time.perf_counter()
     m1, s1 = fid_oracle.calculate_activation_statistics(x)
     t_cov = time.perf_counter() - t0
-    m2, s2 = fid_oracle.calculate_activation_statistics(y)
+    m2, s2 = fid_oracle.calculate_activation_statistics(_cases.pool3_like_features(3000, dims, 43, shift=0.1))
     t0 = time.perf_counter()
     fid_oracle.calculate_frechet_distance(m1, s1, m2, s2)
     t_fd = time.perf_counter() - t0
     lg = np.random.default_rng(0).standard_normal((n_job, 1000)).astype(np.float32)
-    t0 = time.perf_counter()
-    is_oracle.inception_score_from_logits(lg, is_oracle.T_COCO, 10, "coco", dtype=np.float32)
-    t_is = time.perf_counter() - t0
-    per_img = (t_resize + t_fwd) / n + t_cov / 3000.0 + (t_fd + t_is) / n_job
-    return {
-        "value": 1.0 / per_img, "unit": "images/sec", "cores": threads, "kind": "port",
-        "sample": (f"oracle/: PIL-exact resize + InceptionV3 fp32 (torch CPU, {threads} threads) on {n} images "
-                   f"[{t_resize:.2f}s + {t_fwd:.2f}s], np.mean/np.cov on 3000x{dims} fp64 [{t_cov:.2f}s], reference-form "
-                   f"Frechet distance (scipy sqrtm) d={dims} [{t_fd:.2f}s], IS* reduction {n_job}x1000 [{t_is:.2f}s]; "
-                   f"per-image costs extrapolated linearly to a {n_job}-image job"),
-        "host_cpus": os.cpu_count(),
+    t_is, _ = _median_time(lambda: is_oracle.inception_score_from_logits(lg, is_oracle.T_COCO, 10, "coco", dtype=np.float32),
+                           repeats=3, warmup=1)
+    n_used = (n // bs) * bs
+    per_img_dec, per_img_fwd = t_dec / n_used, t_fwd / n
+    # the reference overlaps the loader workers with the forward pass: per image the slower of the two stages
+    job_s = n_job * max(per_img_dec, per_img_fwd) + t_cov + t_fd + t_is
+    base = {
+        "value": n_job / job_s, "unit": "images/sec", "cores": threads, "kind": "port",
+        "sample": (f"oracle/ on {n} images of the timed set, batch {bs}, 1 warm-up + median of {r_fwd} repeats: PNG decode + PIL "
+                   f"resize + ToTensor on {workers} DataLoader workers {per_img_dec * 1e3:.2f} ms/img, InceptionV3 fp32 forward "
+                   f"(torch CPU, {threads} threads) {per_img_fwd * 1e3:.2f} ms/img; at the job's size ({n_job} x {dims}): "
+                   f"np.mean/np.cov {t_cov:.2f} s, reference-form Frechet distance (scipy sqrtm) {t_fd:.2f} s, IS* reduction "
+                   f"{t_is:.3f} s; job time = N x max(decode, forward) + cov + sqrtm + IS (loader overlapped as in the reference)"),
+        "stages": {"decode_resize_ms_per_img": per_img_dec * 1e3, "forward_ms_per_img": per_img_fwd * 1e3,
+                   "cov_s": t_cov, "frechet_s": t_fd, "is_reduce_s": t_is, "repeats": {"decode": r_dec, "forward": r_fwd}},
+        "host_cpus": os.cpu_count(), "loader_workers": workers,
     }
+    return base, out
 
 
 def main():
@@ -126,14 +218,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=500)
+    ap.add_argument("--batch", type=int, default=GLOBAL_STEP_IMAGES, help="images per step (job = steps x batch images)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--ref-images", type=int, default=3000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=48)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline AND parity (both need the CPU oracle)")
+    ap.add_argument("--cpu-sample", type=int, default=250, help="images of the timed set the CPU oracle processes")
+    ap.add_argument("--no-cross-check", action="store_true")
     ap.add_argument("--channels-last", type=int, default=-1)
     args = ap.parse_args()
 
-    from tise_toolbox_amd import _lib, device, dist as tdist
+    from tise_toolbox_amd import _lib, device, dist as tdist, fid_score
     from tise_toolbox_amd.engine import RealismEngine, T_COCO, frechet_solver
     rank, world, local_rank = tdist.init_from_env()
     if world != args.gpus and rank == 0:
@@ -145,9 +239,15 @@ def main():
     cl = None if args.channels_last < 0 else bool(args.channels_last)
     eng = RealismEngine(dims=2048, device_index=local_rank, seed=0, with_logits=True, channels_last=cl)
     B, K, W = args.batch, args.steps, args.warmup
-    n_rank = K * B
-    n_total = n_rank * world
-    lo = rank * n_rank
+    if args.scaling == "strong":
+        n_total = K * B
+        lo, hi = tdist.shard_range(n_total, rank, world)
+    else:
+        n_total = K * B * world
+        lo, hi = rank * K * B, (rank + 1) * K * B
+    n_rank = hi - lo
+    rb = rank_batch(n_rank, B)
+    chunks = [(a, min(a + rb, n_rank)) for a in range(0, n_rank, rb)]
 
     # ---- inputs resident in HBM before the timed region ------------------------------------------
     data = torch.empty((n_rank, 256, 256, 3), dtype=torch.uint8, device=dev)
@@ -163,42 +263,42 @@ def main():
     solver = frechet_solver(2048, dev)
     solver.set_profiling(True)
 
-    # ---- warmup (MIOpen solver search, allocator, clocks) -----------------------------------------
-    eng.begin(n_total=max(W, 1) * B)
+    # ---- warmup (allocator, clocks, RCCL communicator) ----------------------------------------------
+    eng.begin(n_total=max(W, 1) * rb)
     for s in range(W):
-        eng.step_u8(data[(s % K) * B:(s % K + 1) * B], s * B)
+        a, b = chunks[s % len(chunks)]
+        eng.step_u8(data[a:b], s * rb)
     if W > 0:
         eng.reduce()                                # also brings up the RCCL communicator outside the timed region
         mu_w, sig_w = eng.statistics()
         solver.distance(mu_w, sig_w, mu_ref, sigma_ref)
+        eng.inception_score()
     elif world > 1:
         tdist.all_reduce_sum_(torch.zeros(1024, dtype=torch.float64, device=dev))
     torch.cuda.synchronize()
 
     # ---- timed region -------------------------------------------------------------------------------
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
+    nch = len(chunks)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(nch)]
+    ev_tail = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     from tise_toolbox_amd.conv_split import SplitConv as _SC
-    _SC.timer = []                                  # HIP events around every convolution launch of the timed steps
-    # The per-launch event pairs cost ~1.5 % of a step (130 extra records per 65 launches: measured 26.0 vs 25.6
-    # ms/step), so they bracket the conv launches of every 6th timed step only (all steps when K < 12); the rocprofv3
-    # summary of the same command is the cross-check.  TISE_BENCH_MODE=noevents | graph are experiment switches
-    # (no conv events at all / hipGraph replay through RealismEngine.step_u8).
+    # HIP events around every convolution launch cost ~1.5 % of a step (130 extra records per 65 launches), so they
+    # bracket the conv launches of every 6th device batch only (all when there are < 12); the rocprofv3 summary of
+    # the same command is the cross-check.  TISE_BENCH_MODE=noevents switches them off.
     mode = os.environ.get("TISE_BENCH_MODE", "events")
     conv_timer = [] if mode == "events" else None
-    every = 6 if K >= 12 else 1
+    every = 6 if nch >= 12 else 1
     _SC.timer = None
+    u8_stem = getattr(eng, "_u8_stem", False)
     eng.begin(n_total=n_total, temperature=T_COCO, splits=10, rule="coco")
     tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(K):
-        batch = data[s * B:(s + 1) * B]
-        if mode == "graph":
-            eng.step_u8(batch, lo + s * B)
-            continue
+    for s, (a, b) in enumerate(chunks):
+        batch = data[a:b]
         _SC.timer = conv_timer if (conv_timer is not None and s % every == 0) else None
         ev[s][0].record()
-        if getattr(eng, "_u8_stem", False):
+        if u8_stem:
             x = device.resize_u8_only(batch, (299, 299))       # uint8 out; the stem conv applies the input table
             ev[s][1].record()
             feats, logits = eng._trunk_u8(x)
@@ -210,16 +310,20 @@ def main():
         eng.stats.update_parts(feats, cov=True, col_sum=False)
         ev[s][3].record()
         eng.stats.update_parts(feats, cov=False, col_sum=True)
-        eng.is_acc.update(logits, lo + s * B)
-        if os.environ.get("TISE_BENCH_CHECKSUM"):      # debugging aid: per-batch feature / input checksums
-            print(f"[chk] rank {rank} first_index {lo + s * B} feats {feats.double().sum().item()!r} "
-                  f"imgs {batch.double().sum().item()!r} logits {logits.double().sum().item()!r}", file=sys.stderr, flush=True)
+        eng.is_acc.update(logits, lo + a)
     _SC.timer = None
+    ev_tail[0].record()
     t_loop_host = time.perf_counter()
     eng.reduce()                                             # RCCL all-reduce of {n, s, S} and the IS* sums
+    if world > 1:
+        torch.cuda.current_stream().synchronize()            # so that allreduce_ms is the collective, not the queue
+    ev_tail[1].record()
+    t_reduce_host = time.perf_counter()
     mu, sigma = eng.statistics()
+    ev_tail[2].record()
     res = solver.distance(mu, sigma, mu_ref, sigma_ref)      # one device->host read of 8 doubles
     is_mean, is_std = eng.inception_score()
+    ev_tail[3].record()
     tdist.barrier()
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -230,10 +334,8 @@ def main():
     elapsed = float(elapsed.item())
 
     from tise_toolbox_amd.trunk import SplitTrunk
-    from tise_toolbox_amd.conv_split import SplitConv
     conv_events = conv_timer or []
-    timed_steps = len(range(0, K, every)) if conv_timer is not None else 0
-    SplitConv.timer = None
+    timed_steps = len(range(0, nch, every)) if conv_timer is not None else 0
     if isinstance(eng.fused, SplitTrunk):
         # fp32-class arithmetic: every operand carried as two fp16 numbers (22 mantissa bits), three fp16 MFMAs
         # per product, fp32 accumulation; measured error vs an fp64 convolution is below MIOpen's fp32 kernels
@@ -244,21 +346,19 @@ def main():
         conv_dtype = "f32"
         trunk_desc = "PyTorch-ROCm (MIOpen) fp32 convs + HIP epilogues, BN folded, " + ("channels_last" if eng.channels_last else "NCHW")
     if rank == 0:
-        if mode == "graph":
-            resize_ms = trunk_ms = syrk_ms = 1e-9
-        else:
-            resize_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in range(K)]))
-            trunk_ms = float(np.mean([ev[s][1].elapsed_time(ev[s][2]) for s in range(K)]))
-            syrk_ms = float(np.mean([ev[s][2].elapsed_time(ev[s][3]) for s in range(K)]))
+        full = [s for s, (a, b) in enumerate(chunks) if b - a == rb]
+        resize_ms = float(np.mean([ev[s][0].elapsed_time(ev[s][1]) for s in full]))
+        trunk_ms = float(np.mean([ev[s][1].elapsed_time(ev[s][2]) for s in full]))
+        syrk_ms = float(np.mean([ev[s][2].elapsed_time(ev[s][3]) for s in full]))
         phases = solver.phase_ms()
         d = 2048
         tiles = d // 64
-        syrk_flop = 2.0 * B * 64 * 64 * (tiles * (tiles + 1) // 2)         # upper 64x64 tiles only, per launch
-        resize_bytes = B * (256 * 256 * 3 + 299 * 299 * 3 * (1 if getattr(eng, '_u8_stem', False) else 4))
+        syrk_flop = 2.0 * rb * 64 * 64 * (tiles * (tiles + 1) // 2)        # upper 64x64 tiles only, per launch
+        resize_bytes = rb * (256 * 256 * 3 + 299 * 299 * 3 * (1 if u8_stem else 4))
         kern = {
             "syrk_f32_upper_bk64_kernel": {"bound": "mfma", "achieved": syrk_flop / (syrk_ms * 1e-3) / 1e12,
-                                      "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "avg_ms": syrk_ms,
-                                      "algorithmic_flop_per_launch": syrk_flop},
+                                           "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "avg_ms": syrk_ms,
+                                           "algorithmic_flop_per_launch": syrk_flop},
             "resize_bilinear_u8_kernel": {"bound": "hbm", "achieved": resize_bytes / (resize_ms * 1e-3) / 1e9,
                                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "avg_ms": resize_ms,
                                           "algorithmic_bytes_per_launch": resize_bytes},
@@ -270,56 +370,143 @@ def main():
             # algorithmic work = the convolution's 2*M*N*K flop.  The kernel spends THREE fp16 MFMA flop per
             # algorithmic flop (hi*hi, hi*lo, lo*hi), so its ceiling is the dense fp16 MFMA peak / 3.
             kern["conv_split_fast_kernel"] = {
-                "instances": "conv_split_fast_kernel<TN=1..5> (64 launches) + conv_win32_kernel (Conv2d_2a): all 65 conv launches of a step, as rocprofv3 lists them "
-                             "(profiles/r01k_bench_steps10_kernel_stats.md)",
+                "instances": "all convolution launches of a device batch, as rocprofv3 lists them (conv_split_fast_kernel<TN> + "
+                             "conv_win32_kernel; profiles/r02*_kernel_stats.md)",
                 "clock_note": "in-kernel stamps (profiles/r01g_conv_pipe_stamps.txt): 1.49 GHz while the MFMAs are busy, i.e. "
                               "~1550 TFLOP/s fp16 actually available; peak below is the 2.4 GHz datasheet figure / 3",
                 "bound": "mfma", "achieved": conv_flop / (conv_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3.0,
                 "unit": "TFLOP/s", "avg_ms": conv_ms / timed_steps, "avg_launch_ms": conv_ms / n_launch,
-                "launches_per_step": n_launch / timed_steps, "algorithmic_flop_per_step": conv_flop / timed_steps,
-                "steps_with_events": timed_steps,
+                "launches_per_batch": n_launch / timed_steps, "algorithmic_flop_per_batch": conv_flop / timed_steps,
+                "batches_with_events": timed_steps,
                 "mfma_tflops_f16": 3.0 * conv_flop / (conv_ms * 1e-3) / 1e12, "mfma_peak_f16": PEAK_F16_MFMA_TFLOPS}
         for k in kern.values():
             k["frac"] = k["achieved"] / k["peak"]
-        traffic = None
+        traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_summary.json")
         dom = max(kern, key=lambda k: kern[k]["avg_ms"])
         if os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get(dom, {}).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc_path))
+                traffic = pj.get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_src = pj.get("_source")
             except Exception:
                 traffic = None
         roofline = {"kernel": dom, "bound": kern[dom]["bound"], "achieved": kern[dom]["achieved"],
                     "peak": kern[dom]["peak"], "unit": kern[dom]["unit"], "frac": kern[dom]["frac"],
-                    "traffic": traffic, "avg_launch_ms": kern[dom].get("avg_launch_ms", kern[dom]["avg_ms"]),
-                    "kernels": kern}
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "avg_launch_ms": kern[dom].get("avg_launch_ms", kern[dom]["avg_ms"]), "kernels": kern}
+        allreduce_ms = ev_tail[0].elapsed_time(ev_tail[1])
         out = {
             "metric": "images/sec through InceptionV3+FID on 30k 256x256 @1/2/4/8 GPU; |dFID| vs ref",
             "value": n_total / elapsed, "unit": "images/sec", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": conv_dtype, "data": "synthetic",
-            "config": {"workload": f"IS*+FID on {n_rank} synthetic 256x256 images per GPU (BASELINE configs[1]: "
-                                   f"30k images, 1xMI355X, InceptionV3 pool3 2048-d), batch {B}, seeded stand-in "
-                                   f"InceptionV3 weights, reference stats from {args.ref_images} images",
-                       "batch": B, "images_per_gpu": n_rank, "images_total": n_total, "dims": 2048,
-                       "trunk": trunk_desc,
-                       "parallelism": f"dp{world}"},
+            "config": {"workload": f"IS*+FID of ONE set of {n_total} synthetic 256x256 images (BASELINE configs[1]/[2]: 30k "
+                                   f"images, InceptionV3 pool3 2048-d) sharded over {world} GPU(s): {n_rank} images per GPU in "
+                                   f"device batches of {rb}; seeded stand-in InceptionV3 weights, reference stats from "
+                                   f"{args.ref_images} images",
+                       "step_images": B, "images_per_gpu": n_rank, "images_total": n_total, "device_batch": rb,
+                       "device_batches_per_gpu": nch, "dims": 2048, "trunk": trunk_desc, "parallelism": f"dp{world}"},
             "roofline": roofline,
-            "stage_ms_per_step": {"resize": resize_ms, "trunk_fp32": trunk_ms, "cov_syrk": syrk_ms},
-            "finalize_ms": {"host_wall_after_loop": (t1 - t_loop_host) * 1e3, **{k: v for k, v in phases.items()}},
+            "stage_ms_per_device_batch": {"resize": resize_ms, "trunk": trunk_ms, "cov_syrk": syrk_ms},
+            "allreduce_ms": allreduce_ms,
+            "finalize_ms": {"host_wall_after_loop": (t1 - t_loop_host) * 1e3,
+                            "host_wall_allreduce": (t_reduce_host - t_loop_host) * 1e3,
+                            "stats_finalize": ev_tail[1].elapsed_time(ev_tail[2]),
+                            "frechet_plus_is": ev_tail[2].elapsed_time(ev_tail[3]), **{k: v for k, v in phases.items()}},
             "scores": {"fid": float(res["fid"]), "is_mean": is_mean, "is_std": is_std, "rank": res["rank"],
                        "flags": res["flags"]},
-            "trunk_tflops": 11.42e9 * B / (trunk_ms * 1e-3) / 1e12,
+            "trunk_tflops": 11.42e9 * rb / (trunk_ms * 1e-3) / 1e12,
         }
+        out["parity"] = None
+        out["cpu_baseline"] = None
+        out["cross_check"] = None
         if world == 1 and not args.no_cpu_baseline:
-            sample = data[:args.cpu_sample].cpu().numpy()
-            out["cpu_baseline"] = cpu_baseline(sample, n_rank)
-        else:
-            out["cpu_baseline"] = None
+            # ---- CPU oracle on the first images of the timed set: the baseline AND the parity figures --------
+            n_cpu = max(50, (min(args.cpu_sample, n_rank) // 50) * 50)
+            gen_u8 = data[:n_cpu].cpu().numpy()
+            ref_dev = synth_images_device(0, n_cpu, dev, seed=1, shift=0.12)
+            base, feats_cpu = cpu_reference_pass(gen_u8, ref_dev.cpu().numpy(), n_total)
+            out["cpu_baseline"] = base
+            from oracle import fid_oracle, is_oracle
+
+            def dev_pass(u8):
+                fs, ls = [], []
+                for i in range(0, n_cpu, 50):
+                    f, l = eng.features_from_u8(u8[i:i + 50])
+                    fs.append(f); ls.append(l)
+                return torch.cat(fs), torch.cat(ls)
+            fg, lg = dev_pass(data[:n_cpu])
+            fr, _ = dev_pass(ref_dev)
+            sg, sr = device.StatsAccumulator(2048, dev), device.StatsAccumulator(2048, dev)
+            sg.update(fg); sr.update(fr)
+            fid_dev = float(fid_score.calculate_frechet_distance(*sg.finalize(), *sr.finalize()))
+            is_dev = fid_score_is(lg, dev)
+            (fg_c, lg_c), (fr_c, _) = feats_cpu["gen"], feats_cpu["ref"]
+            fid_cpu = float(fid_oracle.calculate_frechet_distance(*fid_oracle.calculate_activation_statistics(fg_c),
+                                                                  *fid_oracle.calculate_activation_statistics(fr_c)))
+            is_cpu = is_oracle.inception_score_from_logits(lg_c, is_oracle.T_COCO, 10, "coco", dtype=np.float32)
+            out["parity"] = {
+                "n": n_cpu, "against": "oracle/ (CPU: PIL-exact resize, fp32 InceptionV3, np.cov, scipy sqrtm; fp32 IS* reduction) on "
+                                       "the first n images of the timed set vs the first n reference images, same weights",
+                "fid_device": fid_dev, "fid_oracle": fid_cpu, "dfid": abs(fid_dev - fid_cpu),
+                "is_device": is_dev[0], "is_oracle": is_cpu[0], "dis": abs(is_dev[0] - is_cpu[0]),
+                "dis_std": abs(is_dev[1] - is_cpu[1]),
+                "max_feature_err_rel": float(np.abs(fg.cpu().numpy() - fg_c).max() / np.abs(fg_c).max()),
+                "tolerance": {"dfid": 1e-3, "dis": 1e-4}}
+        if world == 1 and not args.no_cross_check and isinstance(eng.fused, SplitTrunk):
+            out["cross_check"] = cross_check_fp32(eng, data, chunks, lo, n_total, mu, sigma, mu_ref, sigma_ref,
+                                                  float(res["fid"]), (is_mean, is_std), solver, dev)
         print(json.dumps(out), flush=True)
     tdist.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def fid_score_is(logits, dev):
+    from tise_toolbox_amd import device
+    from tise_toolbox_amd.engine import T_COCO
+    acc = device.InceptionScoreAccumulator(logits.shape[1], logits.shape[0], T_COCO, 10, "coco", False, dev)
+    acc.update(logits.contiguous(), 0)
+    m, s, _ = acc.finalize()
+    return m, s
+
+
+def cross_check_fp32(eng, data, chunks, lo, n_total, mu, sigma, mu_ref, sigma_ref, fid_split, is_split, solver, dev):
+    """The timed set once more through EXACT fp32 convolutions (MIOpen, immediate mode) with the same weights and
+    the same statistics / Frechet / IS* kernels: what the split-fp16 operand format costs at the job's full size."""
+    from tise_toolbox_amd import device
+    from tise_toolbox_amd.engine import RealismEngine, T_COCO
+    old = {k: os.environ.get(k) for k in ("TISE_CONV", "TISE_MIOPEN_FIND")}
+    os.environ["TISE_CONV"], os.environ["TISE_MIOPEN_FIND"] = "miopen", "0"
+    try:
+        ref_eng = RealismEngine(dims=2048, device_index=dev.index, seed=0, with_logits=True)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    t0 = time.perf_counter()
+    ref_eng.begin(n_total=n_total, temperature=T_COCO, splits=10, rule="coco")
+    max_err, max_abs = torch.zeros((), device=dev), torch.zeros((), device=dev)
+    sub = min(125, chunks[0][1] - chunks[0][0])               # MIOpen fp32 workspace: smaller batches than the HIP trunk
+    for a, b in chunks:
+        for i in range(a, b, sub):
+            j = min(i + sub, b)
+            f_ref = ref_eng.step_u8(data[i:j], lo + i)
+            f_split, _ = eng.features_from_u8(data[i:j])
+            max_err = torch.maximum(max_err, (f_split - f_ref).abs().max())
+            max_abs = torch.maximum(max_abs, f_ref.abs().max())
+    mu32, sig32 = ref_eng.statistics()
+    fid32 = float(solver.distance(mu32, sig32, mu_ref, sigma_ref)["fid"])
+    is32 = ref_eng.inception_score()
+    torch.cuda.synchronize()
+    return {"n": n_total, "against": "the same images and weights through MIOpen fp32 convolutions (TISE_CONV=miopen), same "
+                                     "statistics / Frechet / IS* kernels",
+            "fid_split": fid_split, "fid_fp32": fid32, "dfid": abs(fid_split - fid32),
+            "is_split": is_split[0], "is_fp32": is32[0], "dis": abs(is_split[0] - is32[0]), "dis_std": abs(is_split[1] - is32[1]),
+            "max_feature_err_rel": float((max_err / max_abs).item()), "seconds": time.perf_counter() - t0}
 
 
 if __name__ == "__main__":

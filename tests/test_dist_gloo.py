@@ -97,3 +97,25 @@ def test_shard_files_global_drop_last():
     assert got == files[:1000]
     shard, base = tdist.shard_files(list(range(30)), 64, 0, 2)                 # N < batch: nothing is used
     assert shard == [] and base == 0
+
+
+def test_bench_strong_scaling_shards_cover_the_job_once():
+    """bench.py --scaling strong (SURVEY 8(d) Config 3): ONE 30k set, contiguous 30000/N images per rank, device
+    batches that divide a rank's range (500/500/500/750 at 1/2/4/8 GPUs)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from tise_toolbox_amd import dist as tdist
+    want_batch = {1: 500, 2: 500, 4: 500, 8: 750}
+    for world in (1, 2, 3, 4, 8):
+        covered = []
+        for r in range(world):
+            lo, hi = tdist.shard_range(30000, r, world)
+            rb = bench.rank_batch(hi - lo)
+            if world in want_batch:
+                assert rb == want_batch[world] and (hi - lo) % rb == 0
+            chunks = [(a, min(a + rb, hi - lo)) for a in range(0, hi - lo, rb)]
+            assert chunks[0][0] == 0 and chunks[-1][1] == hi - lo
+            covered += [(lo + a, lo + b) for a, b in chunks]
+        assert covered[0][0] == 0 and covered[-1][1] == 30000
+        assert all(x[1] == y[0] for x, y in zip(covered[:-1], covered[1:]))
+    assert bench.rank_batch(1250) == 625 and bench.rank_batch(100) == 100

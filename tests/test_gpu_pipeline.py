@@ -13,6 +13,7 @@ import torch
 
 from oracle import fid_oracle, inception_oracle, is_oracle, resize_oracle
 from tests import _cases
+from tise_toolbox_amd.weights import SYNTHETIC_TAG
 
 pytestmark = pytest.mark.gpu
 
@@ -123,8 +124,12 @@ def test_cli_end_to_end(setup, tmp_path, capsys):
     npz = tmp_path / "ref_stats.npz"
     out1 = tmp_path / "o1.txt"
     v1 = fid_score.main(["--batch-size", "5", "--path1", str(tmp_path / "ref"), "--path2", str(gdir),
-                         "--saved_file", str(out1), "--gpu", "0", "--num-workers", "2", "--save-stats", str(tmp_path / "gen_stats.npz")])
-    assert out1.read_text() == f"FID: {v1}"
+                         "--saved_file", str(out1), "--gpu", "0", "--num-workers", "2", "--save-stats", str(tmp_path / "gen_stats.npz"),
+                         "--synthetic-weights"])
+    assert out1.read_text() == f"FID: {v1}" + SYNTHETIC_TAG
+    # without --weights / --synthetic-weights there is no silent stand-in (the reference always loads pretrained)
+    with pytest.raises(RuntimeError, match="no parameters for InceptionV3"):
+        fid_score.main(["--batch-size", "5", "--path1", str(tmp_path / "ref"), "--path2", str(gdir)])
     # oracle pipeline on the same files, same walk order, same drop-last rule
     def oracle_stats(root, bs):
         files = img_data.get_filenames(str(root))
@@ -143,12 +148,39 @@ def test_cli_end_to_end(setup, tmp_path, capsys):
     np.savez(npz, mu=m1, sigma=s1)
     out2 = tmp_path / "o2.txt"
     v2 = fid_score.main(["--batch-size", "5", "--path1", str(npz), "--path2", str(gdir), "--saved_file", str(out2),
-                         "--label", "O-FID", "--num-workers", "0"])
+                         "--label", "O-FID", "--num-workers", "0", "--synthetic-weights"])
     assert out2.read_text().startswith("O-FID: ") and abs(v2 - want) <= 1e-3
     g = np.load(tmp_path / "gen_stats.npz")
     np.testing.assert_allclose(g["mu"], m2, atol=1e-5)
     with pytest.raises(RuntimeError, match="Invalid path"):
-        fid_score.main(["--path1", str(tmp_path / "missing"), "--path2", str(gdir)])
+        fid_score.main(["--path1", str(tmp_path / "missing"), "--path2", str(gdir), "--synthetic-weights"])
+    # STATS-ONLY mode (section 8 f1): --path1 omitted -> {mu, sigma} of --path2, no Frechet distance solved
+    fid_score.calculate_frechet_distance.last_result = "untouched"
+    so = tmp_path / "only_stats.npz"
+    assert fid_score.main(["--batch-size", "5", "--path2", str(gdir), "--save-stats", str(so), "--num-workers", "0",
+                           "--synthetic-weights"]) is None
+    assert fid_score.calculate_frechet_distance.last_result == "untouched"
+    g2 = np.load(so)
+    assert g2["mu"].dtype == np.float64 and g2["sigma"].shape == (2048, 2048)
+    # against np.mean / np.cov of the DEVICE features of the same files: accumulation parity at rounding level
+    np.testing.assert_array_equal(g2["mu"], g["mu"])
+    np.testing.assert_array_equal(g2["sigma"], g["sigma"])
+    np.testing.assert_allclose(g2["sigma"], s2, rtol=0, atol=2e-5 * np.abs(s2).max())       # vs the CPU-oracle features
+    files = img_data.get_filenames(str(gdir))
+    files = files[:fid_oracle.n_used_images(len(files), 5)]
+    from tise_toolbox_amd.engine import RealismEngine
+    eng = RealismEngine(dims=2048, seed=0)
+    idx = [int(os.path.basename(f).split(".")[0]) for f in files]
+    fdev = torch.cat([eng.features_from_u8(torch.from_numpy(setup["gen"][idx[i:i + 5]]).to(eng.device))[0]
+                      for i in range(0, len(idx), 5)]).double().cpu().numpy()          # same batches as the CLI run
+    mu_d, sig_d = fid_oracle.calculate_activation_statistics(fdev)
+    np.testing.assert_allclose(g2["mu"], mu_d, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(g2["sigma"], sig_d, rtol=0, atol=1e-12 * np.abs(sig_d).max())
+    # and the saved file feeds the .npz branch
+    v3 = fid_score.main(["--batch-size", "5", "--path1", str(so), "--path2", str(gdir), "--num-workers", "0", "--synthetic-weights"])
+    assert abs(v3) <= 1e-6
+    with pytest.raises(SystemExit):
+        fid_score.main(["--path2", str(gdir), "--synthetic-weights"])                       # neither --path1 nor --save-stats
 
 
 def test_is_cli(setup, tmp_path):
@@ -159,8 +191,8 @@ def test_is_cli(setup, tmp_path):
     for i in range(30):
         Image.fromarray(setup["gen"][i]).save(d / f"{i:05d}.png")
     out = tmp_path / "is.txt"
-    mean, std = isc.main(["--image_folder", str(d), "--saved_file", str(out), "--batch-size", "7"])
-    assert out.read_text() == "[Inception Score] mean: {:.5f} std: {:.5f}".format(mean, std)
+    mean, std = isc.main(["--image_folder", str(d), "--saved_file", str(out), "--batch-size", "7", "--synthetic-weights"])
+    assert out.read_text() == "[Inception Score] mean: {:.5f} std: {:.5f}".format(mean, std) + SYNTHETIC_TAG
     files = img_data.get_filenames(str(d))
     idx = [int(os.path.basename(f).split(".")[0]) for f in files]
     want = is_oracle.inception_score_from_logits(setup["lg"][idx], is_oracle.T_COCO, 10, "coco", dtype=np.float32)
@@ -183,8 +215,10 @@ def test_object_centric_inception_score(setup, tmp_path):
     ds = ois.IgnoreLabelDataset(str(d))
     assert len(ds) == 37 and ds[0].dtype == torch.uint8
     out = tmp_path / "ois.txt"
-    mean, std = ois.main(["--image_dir", str(d), "--saved_file", str(out), "--gpu_id", "0"])
-    assert out.read_text() == f"O-IS: {mean} +-  {std}"
+    mean, std = ois.main(["--image_dir", str(d), "--saved_file", str(out), "--gpu_id", "0", "--synthetic-weights"])
+    assert out.read_text() == f"O-IS: {mean} +-  {std}" + SYNTHETIC_TAG
+    with pytest.raises(RuntimeError, match="no parameters for 80-class"):
+        ois.main(["--image_dir", str(d), "--saved_file", str(out), "--gpu_id", "0"])
     # oracle: PIL-exact resize, (x - 0.5) / 0.5, CPU fp32 trunk without the inception.py:120-124 affine, 80-class fc
     sd = {k: v.float() for k, v in build_inception3(num_classes=80, seed=0, calibration="pm1").state_dict().items()}
     logits = []
@@ -232,3 +266,106 @@ def test_u8_stem_path_bit_identical_to_fp32_input_path(cuda_device, monkeypatch)
     fa, la = a.features_from_u8(imgs)
     fb, lb = b.features_from_u8(imgs)
     assert torch.equal(fa, fb) and torch.equal(la, lb)
+
+
+def _run_ranks(world, argv, tmp_path, module="tise_toolbox_amd.fid_score", timeout=600):
+    """`world` processes of a CLI on THIS box's single GPU, rendezvous over gloo (TISE_DIST_BACKEND): the
+    data-parallel product code path (shard_files / shard_range + all_reduce of the device buffers) end to end.
+    On an 8-GPU node the same code runs with backend nccl (= RCCL)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TISE_DIST_BACKEND="gloo", PYTHONPATH=root)
+        procs.append(subprocess.Popen([sys.executable, "-m", module] + argv, env=env, cwd=root,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, out))
+    return outs
+
+
+def test_two_ranks_with_an_empty_shard(setup, tmp_path):
+    """fewer batches than ranks.  5 images, batch 2 -> 2 batches; with 3 ranks rank 2 gets nothing and must
+    still join the all-reduce; the result equals the single-process run.  And N < batch globally: every rank raises
+    the same ZeroDivisionError instead of one crashing while the others hang in the collective."""
+    from PIL import Image
+    from tise_toolbox_amd import fid_score
+    gdir, rdir = tmp_path / "gen", tmp_path / "ref"
+    gdir.mkdir(); rdir.mkdir()
+    for i in range(5):
+        Image.fromarray(setup["gen"][i]).save(gdir / f"{i:05d}.png")
+    for i in range(7):
+        Image.fromarray(setup["ref"][i]).save(rdir / f"{i:05d}.png")
+    argv = ["--batch-size", "2", "--path1", str(rdir), "--path2", str(gdir), "--num-workers", "0", "--synthetic-weights"]
+    single = fid_score.main(argv)
+    out = tmp_path / "dp.txt"
+    res = _run_ranks(3, argv + ["--saved_file", str(out)], tmp_path)
+    assert all(rc == 0 for rc, _ in res), res
+    got = float(out.read_text().split()[1])
+    assert abs(got - single) <= 1e-9 * max(1.0, abs(single)), (got, single)
+    res = _run_ranks(2, ["--batch-size", "16", "--path1", str(rdir), "--path2", str(gdir), "--num-workers", "0",
+                         "--synthetic-weights"], tmp_path, timeout=300)
+    assert all(rc != 0 and "ZeroDivisionError" in o for rc, o in res), res
+
+
+def test_ragged_crops_one_trunk_pass_and_per_class_fid(setup, tmp_path):
+    """ADVICE r1 + section 8 f2: crops of different sizes are resized into ONE batch (a single trunk pass), results
+    equal the per-image path bit for bit; --per-class groups crops by the {class} token (crop_object.py:45) and
+    every class's FID equals the plain FID of a directory holding only that class."""
+    from PIL import Image
+    from tise_toolbox_amd import fid_score
+    eng = setup["eng"]
+    rng = np.random.default_rng(5)
+    crops = [torch.from_numpy(setup["gen"][i][:int(rng.integers(20, 200)), :int(rng.integers(20, 200))].copy()) for i in range(12)]
+    fa, la = eng.features_from_u8_list(crops)
+    for i in (0, 5, 11):
+        fb, lb = eng.features_from_u8(crops[i].unsqueeze(0).to(eng.device))
+        # same arithmetic per image; the batch size only changes which workgroup computes a pixel
+        assert torch.allclose(fa[i], fb[0], rtol=0, atol=1e-6 * float(fb.abs().max()))
+    assert fid_score.class_of_crop("/x/COCO_val_000012_traffic light_37.png") == "traffic light"
+    assert fid_score.class_of_crop("img_7_dog_0.png") == "dog"
+    with pytest.raises(ValueError):
+        fid_score.class_of_crop("plain.png")
+    classes = ["dog", "traffic light", "cup"]
+    counts = {"gen": {"dog": 6, "traffic light": 5, "cup": 1}, "ref": {"dog": 4, "traffic light": 7, "cup": 3}}
+    k = 0
+    for side in ("gen", "ref"):
+        for c in classes:
+            os.makedirs(tmp_path / f"{side}_{c}", exist_ok=True)
+        os.makedirs(tmp_path / side, exist_ok=True)
+        for j in range(max(counts[side].values())):                      # interleave the classes in the directory
+            for c in classes:
+                if j >= counts[side][c]:
+                    continue
+                im = setup[side][k % len(setup[side])][:40 + 9 * (k % 7), :50 + 11 * (k % 5)]
+                name = f"im_{k}_{c}_{k}.png"
+                Image.fromarray(im).save(tmp_path / side / name)
+                Image.fromarray(im).save(tmp_path / f"{side}_{c}" / name)
+                k += 1
+    out = tmp_path / "pc.txt"
+    per = fid_score.main(["--batch-size", "4", "--path1", str(tmp_path / "ref"), "--path2", str(tmp_path / "gen"),
+                          "--label", "O-FID", "--num-classes", "80", "--per-class", "--num-workers", "0",
+                          "--synthetic-weights", "--saved_file", str(out)])
+    assert list(per) == ["dog", "traffic light"]                         # cup: a single crop on the gen side
+    text = out.read_text()
+    assert "O-FID[dog]: " in text and "skipped" in text and "cup" in text.splitlines()[-1]
+    for c in per:
+        n1, n2 = counts["ref"][c], counts["gen"][c]
+        # plain FID of the class's own directories; batch size = class size so that nothing is dropped
+        from tise_toolbox_amd.inception import InceptionV3
+        model = InceptionV3([3], num_classes=80, seed=0).cuda()
+        m1, s1 = fid_score._compute_statistics_of_path(str(tmp_path / f"ref_{c}"), model, n1, 2048, True, 0)
+        m2, s2 = fid_score._compute_statistics_of_path(str(tmp_path / f"gen_{c}"), model, n2, 2048, True, 0)
+        want = fid_score.calculate_frechet_distance(m1, s1, m2, s2)
+        assert abs(per[c] - want) <= 1e-6 * max(1.0, abs(want)), (c, per[c], want)

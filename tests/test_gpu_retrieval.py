@@ -116,8 +116,10 @@ def test_rp_cli_end_to_end_with_stand_in_towers(cuda_device, tmp_path):
     pickle.dump(items, open(pkl, "wb"))
     out = tmp_path / "rp.txt"
     mean, std = RP_coco.main(["--image_dir", str(img_dir), "--rp_input_file", str(pkl), "--saved_file_path", str(out),
-                              "--gpu_id", str(cuda_device.index or 0), "--seed", "4", "--batch-size", "8"])
-    assert open(out).read() == f"R-precision: {mean} +- {std}"
+                              "--gpu_id", str(cuda_device.index or 0), "--seed", "4", "--batch-size", "8",
+                              "--synthetic-weights"])
+    from tise_toolbox_amd.weights import SYNTHETIC_TAG
+    assert open(out).read() == f"R-precision: {mean} +- {std}" + SYNTHETIC_TAG
     # oracle on the same embeddings
     model = clip_model.build_clip().to(cuda_device).half()
     caps, index = RP_coco.caption_table(items)

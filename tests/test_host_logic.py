@@ -215,3 +215,37 @@ def test_bpe_tokenizer_on_synthetic_merges(tmp_path):
     assert out[0, 5:].sum() == 0
     with pytest.raises(RuntimeError):
         tok(["bus " * 100])
+
+
+def test_weights_resolution_never_silently_synthetic(tmp_path, monkeypatch, capsys):
+    """the reference always loads pretrained parameters; a missing file must not turn into stand-ins."""
+    from tise_toolbox_amd import weights
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "torch_home"))
+    monkeypatch.chdir(tmp_path)
+    for kind in ("inception", "inception80"):
+        with pytest.raises(RuntimeError, match="no parameters for"):
+            weights.resolve(None, False, kind)
+    path, tag = weights.resolve(None, True, "inception")
+    assert path is None and tag == weights.SYNTHETIC_TAG
+    assert "SEEDED STAND-IN" in capsys.readouterr().err
+    with pytest.raises(RuntimeError, match="Invalid path"):
+        weights.resolve(str(tmp_path / "nope.pth"), False, "inception")
+    f = tmp_path / "w.pth"; f.write_bytes(b"x")
+    assert weights.resolve(str(f), True, "inception") == (str(f), "")
+    # the files the reference itself would read are found without a flag
+    hub = tmp_path / "torch_home" / "hub" / "checkpoints"; hub.mkdir(parents=True)
+    (hub / "inception_v3_google-1a9a5a14.pth").write_bytes(b"x")
+    assert weights.resolve(None, False, "inception") == (str(hub / "inception_v3_google-1a9a5a14.pth"), "")
+    (tmp_path / "weights").mkdir()
+    (tmp_path / "weights" / "inceptionv3_fine_to_with_80_coco_classes.pth").write_bytes(b"x")
+    assert weights.resolve(None, False, "inception80")[0] == os.path.join("weights", "inceptionv3_fine_to_with_80_coco_classes.pth")
+
+
+def test_ranking_collect_refuses_synthetic_results(tmp_path):
+    from tise_toolbox_amd import ranking_score as rs, weights
+    f = tmp_path / "fid.txt"
+    f.write_text("FID: 12.5")
+    assert rs.parse_result_file("FID", str(f)) == 12.5
+    f.write_text("FID: 12.5" + weights.SYNTHETIC_TAG)
+    with pytest.raises(ValueError, match="synthetic"):
+        rs.parse_result_file("FID", str(f))

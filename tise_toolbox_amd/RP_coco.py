@@ -19,7 +19,7 @@ import random
 import numpy as np
 import torch
 
-from . import _lib, clip_model, device
+from . import _lib, clip_model, device, weights as tweights
 
 
 def parse_args(argv=None):
@@ -28,8 +28,10 @@ def parse_args(argv=None):
     parser.add_argument("--rp_input_file", default="captions/COCO_RP_captions.pkl", type=str)
     parser.add_argument("--saved_file_path", default=None, type=str, help="Path to file saving result")
     parser.add_argument("--gpu_id", default="0", type=str)
-    parser.add_argument("--weights", default=None, type=str, help="OpenAI CLIP ViT-B/32 state_dict (.pt); seeded stand-in otherwise")
-    parser.add_argument("--vocab", default=None, type=str, help="bpe_simple_vocab_16e6.txt.gz; word-hash stand-in otherwise")
+    parser.add_argument("--weights", default=None, type=str, help="OpenAI CLIP ViT-B/32 state_dict (.pt); default: ~/.cache/clip/ViT-B-32.pt")
+    parser.add_argument("--vocab", default=None, type=str, help="bpe_simple_vocab_16e6.txt.gz (required with real weights)")
+    parser.add_argument("--synthetic-weights", action="store_true",
+                        help="seeded stand-in towers + word-hash tokenizer (plumbing / throughput only; results are tagged)")
     parser.add_argument("--seed", default=None, type=int, help="seed of the bin shuffle (reference: unseeded)")
     parser.add_argument("--batch-size", default=256, type=int)
     return parser.parse_args(argv)
@@ -118,7 +120,10 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise _lib.TiseLibraryError("RP_coco needs an MI355X: there is no CPU path")
     dev = torch.device(f"cuda:{args.gpu_id}")
-    model = clip_model.build_clip(args.weights).to(dev).half()         # clip.load on a GPU serves fp16 weights
+    wpath, tag = tweights.resolve(args.weights, args.synthetic_weights, "clip")
+    if wpath is not None and not args.vocab:
+        raise RuntimeError("real CLIP weights need the BPE vocabulary: pass --vocab bpe_simple_vocab_16e6.txt.gz")
+    model = clip_model.build_clip(wpath).to(dev).half()                # clip.load on a GPU serves fp16 weights
     tokenizer = clip_model.BPETokenizer(args.vocab) if args.vocab else clip_model.HashTokenizer()
     with open(args.rp_input_file, "rb") as f:
         rp_input = pickle.load(f)
@@ -131,10 +136,10 @@ def main(argv=None):
     mean, std, scores = r_precision(img, txt, torch.from_numpy(index).to(dev), perm, normalize=False, logit_scale=scale)
     for bin_idx, s in enumerate(scores):
         print(f"Bin: {bin_idx}, RP: {s}")
-    print(f"R-precision: {mean} +- {std}")
+    print(f"R-precision: {mean} +- {std}{tag}")
     if args.saved_file_path is not None:
         with open(args.saved_file_path, "w") as f:
-            f.write(f"R-precision: {mean} +- {std}")
+            f.write(f"R-precision: {mean} +- {std}{tag}")
     return mean, std
 
 

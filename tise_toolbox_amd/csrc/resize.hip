@@ -17,7 +17,9 @@
 // (256x256 -> 299x299: 196 608 + 1 072 812 = 1 269 420 B).
 #include <math.h>
 #include <string.h>
+#include <list>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 #include "common.h"
 
@@ -71,25 +73,52 @@ void precompute_coeffs(int in_size, int out_size, CoeffTable& t) {
 }
 
 struct DevPlan {
+    int device;      // HIP device the table lives on (one process may drive several GPUs)
     int h, w, oh, ow;
     int ksx, ksy;
     int rt;          // output rows per workgroup
     int span;        // max source rows any row tile needs
     int* dev;        // bounds_x[ow*2] | kx[ow*ksx] | bounds_y[oh*2] | ky[oh*ksy] | tile_y0[ntiles]
+    size_t cap;      // ints allocated at dev
     int off_kx, off_by, off_ky, off_t0, ntiles;
 };
 
+// Plan cache: least-recently-used list + hash index, keyed by (device, h, w, oh, ow).  Object crops (O-FID / O-IS)
+// arrive in thousands of distinct sizes: the cache holds 8192 plans (~12 KB each) and an evicted plan's device
+// buffer is REUSED for the new plan when it is large enough, so steady state does no hipMalloc / hipFree (hipFree
+// is a device-wide synchronisation).
+struct PlanKey {
+    int device, h, w, oh, ow;
+    bool operator==(const PlanKey& o) const { return device == o.device && h == o.h && w == o.w && oh == o.oh && ow == o.ow; }
+};
+struct PlanKeyHash {
+    size_t operator()(const PlanKey& k) const {
+        size_t x = (size_t)k.device;
+        for (int v : {k.h, k.w, k.oh, k.ow}) x = x * 1000003u ^ (size_t)v;
+        return x;
+    }
+};
+constexpr size_t PLAN_CACHE_CAP = 8192;
 std::mutex g_plan_mu;
-std::vector<DevPlan> g_plans;
+std::list<DevPlan> g_plans;                                                   // front = most recently used
+std::unordered_map<PlanKey, std::list<DevPlan>::iterator, PlanKeyHash> g_plan_index;
 
 int get_plan(int h, int w, int oh, int ow, DevPlan* out) {
+    int device = 0;
+    TISE_HIP_CHECK(hipGetDevice(&device));
     std::lock_guard<std::mutex> lk(g_plan_mu);
-    for (const DevPlan& p : g_plans)
-        if (p.h == h && p.w == w && p.oh == oh && p.ow == ow) { *out = p; return TISE_OK; }
+    const PlanKey key{device, h, w, oh, ow};
+    auto hit = g_plan_index.find(key);
+    if (hit != g_plan_index.end()) {
+        g_plans.splice(g_plans.begin(), g_plans, hit->second);
+        *out = g_plans.front();
+        return TISE_OK;
+    }
     CoeffTable tx, ty;
     precompute_coeffs(w, ow, tx);
     precompute_coeffs(h, oh, ty);
     DevPlan p;
+    p.device = device;
     p.h = h; p.w = w; p.oh = oh; p.ow = ow; p.ksx = tx.ksize; p.ksy = ty.ksize;
     // pick the row tile so staged source rows + horizontal-pass rows fit comfortably in LDS
     const size_t lds_budget = 144 * 1024;
@@ -129,24 +158,42 @@ int get_plan(int h, int w, int oh, int ow, DevPlan* out) {
         host.push_back(lo);
     }
     p.dev = nullptr;
-    TISE_HIP_CHECK(hipMalloc((void**)&p.dev, host.size() * sizeof(int)));
+    p.cap = 0;
+    if (g_plans.size() >= PLAN_CACHE_CAP) {
+        // evict the least recently used plan; any kernel still reading its table was enqueued before this call on
+        // the caller's stream(s) -- order the overwrite behind them with a device synchronisation only in this
+        // (rare: > 8192 live sizes) case
+        DevPlan victim = g_plans.back();
+        g_plan_index.erase(PlanKey{victim.device, victim.h, victim.w, victim.oh, victim.ow});
+        g_plans.pop_back();
+        TISE_HIP_CHECK(hipDeviceSynchronize());
+        if (victim.device == device && victim.cap >= host.size()) { p.dev = victim.dev; p.cap = victim.cap; }
+        else (void)hipFree(victim.dev);
+    }
+    if (!p.dev) {
+        p.cap = host.size() + 1024;                                          // slack so a later, larger plan can reuse it
+        TISE_HIP_CHECK(hipMalloc((void**)&p.dev, p.cap * sizeof(int)));
+    }
     TISE_HIP_CHECK(hipMemcpy(p.dev, host.data(), host.size() * sizeof(int), hipMemcpyHostToDevice));
-    if (g_plans.size() >= 64) { hipFree(g_plans.front().dev); g_plans.erase(g_plans.begin()); }
-    g_plans.push_back(p);
+    g_plans.push_front(p);
+    g_plan_index[key] = g_plans.begin();
     *out = p;
     return TISE_OK;
 }
 
 // device copies of the 3x256 fp32 byte->value tables, keyed by content (a run uses one or two)
-struct LutEntry { float host[3 * 256]; float* dev; };
+struct LutEntry { int device; float host[3 * 256]; float* dev; };
 std::mutex g_lut_mu;
 std::vector<LutEntry*> g_luts;
 
 int get_lut(const float* lut, float** dev) {
+    int device = 0;
+    TISE_HIP_CHECK(hipGetDevice(&device));
     std::lock_guard<std::mutex> lk(g_lut_mu);
     for (LutEntry* e : g_luts)
-        if (memcmp(e->host, lut, sizeof(e->host)) == 0) { *dev = e->dev; return TISE_OK; }
+        if (e->device == device && memcmp(e->host, lut, sizeof(e->host)) == 0) { *dev = e->dev; return TISE_OK; }
     LutEntry* e = new LutEntry;
+    e->device = device;
     memcpy(e->host, lut, sizeof(e->host));
     e->dev = nullptr;
     hipError_t err = hipMalloc((void**)&e->dev, sizeof(e->host));

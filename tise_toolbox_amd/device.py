@@ -51,6 +51,9 @@ def make_lut(normalize_input=True, scale_pm1=False):
     return np.ascontiguousarray(lut)
 
 
+_IDENTITY_LUT = np.ascontiguousarray(np.tile(np.arange(256, dtype=np.float32) / np.float32(255.0), (3, 1)))
+
+
 def resize_bilinear_u8(src_u8, out_hw=(299, 299), lut=None, channels_last=True, return_u8=False):
     """(N,H,W,3) uint8 CUDA tensor -> (N,3,oh,ow) fp32 network input (PIL-exact bilinear).
 
@@ -79,17 +82,23 @@ def resize_bilinear_u8(src_u8, out_hw=(299, 299), lut=None, channels_last=True, 
     return (out, u8) if return_u8 else out
 
 
-def resize_u8_only(src_u8, out_hw=(299, 299)):
+def resize_u8_only(src_u8, out_hw=(299, 299), out=None):
     """(N,H,W,3) uint8 CUDA tensor -> the Pillow-exact resized uint8 image (N,oh,ow,3); no float output (the stem
-    convolution applies the input table itself: SplitTrunk.forward_u8)."""
+    convolution applies the input table itself: SplitTrunk.forward_u8).  ``out``: preallocated contiguous
+    (N,oh,ow,3) uint8 destination (a slice of a batch buffer when crops of different sizes are stacked)."""
     _require_cuda(src_u8)
     if src_u8.dtype != torch.uint8 or src_u8.dim() != 4 or src_u8.shape[3] != 3:
         raise ValueError("src_u8 must be (N,H,W,3) uint8")
     src_u8 = src_u8.contiguous()
     n, h, w, _ = src_u8.shape
     oh, ow = out_hw
-    u8 = torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=src_u8.device)
-    lut = np.ascontiguousarray(make_lut(True), dtype=np.float32)          # unused by the kernel when dst is NULL
+    if out is None:
+        u8 = torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=src_u8.device)
+    else:
+        u8 = out
+        if u8.dtype != torch.uint8 or tuple(u8.shape) != (n, oh, ow, 3) or not u8.is_contiguous() or not u8.is_cuda:
+            raise ValueError("out must be a contiguous (N,oh,ow,3) uint8 CUDA tensor")
+    lut = _IDENTITY_LUT                                                   # unused by the kernel when dst is NULL
     _lib.call("tise_resize_bilinear_u8", _ptr(src_u8), n, h, w, None, oh, ow, 1,
               lut.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _ptr(u8), _stream())
     return u8

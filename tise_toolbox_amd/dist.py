@@ -80,6 +80,11 @@ def broadcast_module_(module, src=0):
     return module
 
 
+def world_size():
+    """Size of the initialised process group (1 when torch.distributed is not in use)."""
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

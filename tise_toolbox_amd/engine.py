@@ -3,7 +3,9 @@
 One ``RealismEngine`` per process / GPU.  A step takes a batch of decoded uint8 images that is
 already in HBM and
   1. resizes it to 299x299 and applies ToTensor + the input affine      (csrc/resize.hip)
-  2. runs the InceptionV3 trunk to pool3 (+ the fc head for IS*)        (PyTorch-ROCm / MIOpen, fp32)
+  2. runs the InceptionV3 trunk to pool3 (+ the fc head for IS*)        (csrc/conv_split.hip, conv_pipe.hip,
+                                                                          trunk_ops.hip: hand-written split-fp16
+                                                                          MFMA convolutions; fc GEMM via torch)
   3. folds the pool3 rows into fp64 {n, sum x, sum x x^T}               (csrc/stats.hip, fp64 MFMA)
   4. folds the logits into the per-split IS* sums                        (csrc/is_score.hip)
 Nothing returns to the host until the end: ``reduce()`` all-reduces the sufficient statistics over
@@ -144,6 +146,24 @@ class RealismEngine:
         return feats.clone(), (logits.clone() if logits is not None else None)
 
     @torch.no_grad()
+    def features_from_u8_list(self, crops):
+        """Ragged batch: list of (H_i,W_i,3) uint8 tensors (object crops of different sizes, O-FID / O-IS) ->
+        pool3 (B,dims) [and logits].  Each crop is resized (Pillow-exact) into its row of ONE (B,299,299,3) uint8
+        buffer -- one small launch per crop, resize plans cached per size -- and the trunk runs ONCE on the batch."""
+        if len(crops) == 0:
+            raise ValueError("empty batch")
+        u8 = torch.empty((len(crops), 299, 299, 3), dtype=torch.uint8, device=self.device)
+        for i, c in enumerate(crops):
+            if c.dim() == 4:
+                c = c[0]
+            device.resize_u8_only(c.to(self.device, non_blocking=True).unsqueeze(0), (299, 299), out=u8[i:i + 1])
+        if self._u8_stem:
+            return self._trunk_u8(u8)
+        lut = self.lut_dev.view(3, 256)
+        x = torch.stack([lut[c][u8[..., c].long()] for c in range(3)], dim=-1)              # byte -> input value, NHWC
+        return self._trunk(x.permute(0, 3, 1, 2), prenormalized=True)                       # NCHW view, channels_last
+
+    @torch.no_grad()
     def features_from_float(self, batch):
         """(B,3,H,W) fp32 in [0,1] (the reference's DataLoader output) -> pool3 (B,dims) fp32."""
         x = batch.to(self.device, non_blocking=True).float()
@@ -181,6 +201,13 @@ class RealismEngine:
 
     def step_u8(self, batch_u8, idx_base=0):
         feats, logits = self.features_from_u8(batch_u8)
+        self.stats.update(feats)
+        if self.is_acc is not None:
+            self.is_acc.update(logits, idx_base)
+        return feats
+
+    def step_u8_list(self, crops, idx_base=0):
+        feats, logits = self.features_from_u8_list(crops)
         self.stats.update(feats)
         if self.is_acc is not None:
             self.is_acc.update(logits, idx_base)

@@ -16,10 +16,14 @@ list is sharded over N GPUs and the sufficient statistics are combined with one 
 Deviations from the reference, all deliberate (SURVEY.md notes N3-N5):
   * ``--gpu ""`` (CPU mode) is refused: this package is the MI355X path and has no CPU fallback.
   * ``--path1/--path2`` are required (upstream defaults them to the int 64 by a copy-paste slip).
-  * extra flags: ``--weights`` (torchvision-format state_dict; there is no network to download
-    it), ``--seed`` (stand-in weights when no file is given), ``--save-stats`` (write mu/sigma .npz,
-    the format upstream only reads), ``--label`` ("FID" | "O-FID", object_fidelity/O-FID/fid_score.py:216-222),
-    ``--num-classes`` (80 for the O-FID fine-tune, O-FID/inception.py:58-64).
+  * extra flags: ``--weights`` (torchvision-format state_dict; there is no network to download it; without the flag
+    the file the reference would read is looked up, see ``weights.py``), ``--synthetic-weights`` + ``--seed``
+    (seeded stand-in parameters for plumbing / throughput runs: results are tagged), ``--save-stats`` (write
+    mu/sigma .npz, the format upstream only reads; with ``--path1`` omitted this is the STATS-ONLY mode: no
+    Frechet distance is solved), ``--label`` ("FID" | "O-FID", object_fidelity/O-FID/fid_score.py:216-222),
+    ``--num-classes`` (80 for the O-FID fine-tune, O-FID/inception.py:58-64), ``--per-class`` (extension, BASELINE
+    configs[4]: one FID per object class, crops grouped by the ``{class}`` token of ``{stem}_{class}_{k}.png``,
+    object_fidelity/crop_object.py:45).
 """
 import os
 import sys
@@ -30,7 +34,7 @@ import numpy as np
 import torch
 import torch.utils.data
 
-from . import _lib, device, dist as tdist, img_data
+from . import _lib, device, dist as tdist, img_data, weights as tweights
 from .engine import RealismEngine, frechet_solver, require_gpu
 from .inception import InceptionV3
 
@@ -43,12 +47,17 @@ def _build_parser():
     parser.add_argument("--dims", type=int, default=2048, choices=list(InceptionV3.BLOCK_INDEX_BY_DIM),
                         help=("Dimensionality of Inception features to use. " "By default, uses pool3 features"))
     parser.add_argument("-c", "--gpu", default="0", type=str, help="GPU to use (CPU mode is not provided)")
-    parser.add_argument("--path1", type=str, required=True)
+    parser.add_argument("--path1", type=str, default=None, help="omit together with --save-stats: statistics of "
+                        "--path2 only, no Frechet distance")
     parser.add_argument("--path2", type=str, required=True)
     parser.add_argument("--saved_file", type=str, default="")
     parser.add_argument("--weights", type=str, default=None, help="torchvision-format InceptionV3 state_dict (.pth)")
     parser.add_argument("--num-classes", type=int, default=1000)
-    parser.add_argument("--seed", type=int, default=0, help="seed of the stand-in weights when --weights is absent")
+    parser.add_argument("--synthetic-weights", action="store_true",
+                        help="seeded stand-in parameters (plumbing / throughput only; results are tagged)")
+    parser.add_argument("--seed", type=int, default=0, help="seed of the --synthetic-weights parameters")
+    parser.add_argument("--per-class", action="store_true",
+                        help="O-FID extension: one FID per object class ({stem}_{class}_{k}.png crops)")
     parser.add_argument("--save-stats", type=str, default="", help="write mu/sigma of --path2 to this .npz")
     parser.add_argument("--label", type=str, default="FID", choices=["FID", "O-FID"])
     parser.add_argument("--num-workers", type=int, default=min(32, os.cpu_count() or 8),
@@ -72,9 +81,8 @@ def _engine_for(model, dims):
 
 def _forward_batch(engine, model, batch):
     """One batch -> (B, dims) fp32 features on the device, for either input convention."""
-    if isinstance(batch, (list, tuple)):                 # ragged uint8 crops: one resize launch per image
-        feats = [engine.features_from_u8(b.unsqueeze(0).to(engine.device, non_blocking=True))[0] for b in batch]
-        return torch.cat(feats, 0)
+    if isinstance(batch, (list, tuple)):                 # ragged uint8 crops: resize each into one batch, ONE trunk pass
+        return engine.features_from_u8_list(batch)[0]
     if batch.dtype == torch.uint8:                       # (B,H,W,3) decoded images: fused device resize
         return engine.features_from_u8(batch.to(engine.device, non_blocking=True))[0]
     if isinstance(model, InceptionV3):
@@ -167,11 +175,17 @@ def calculate_activation_statistics(images, model, batch_size=64, dims=2048, cud
     """
     _check_cuda(cuda)
     model.eval()
-    d0 = images.__len__() * batch_size                    # fid_score.py:90-96 bookkeeping
-    if batch_size > d0:
-        print(("Warning: batch size is bigger than the data size. " "Setting batch size to data size"))
-        batch_size = d0
-    n_batches = d0 // batch_size
+    if tdist.world_size() > 1:
+        # data-parallel: `images` is THIS rank's shard and may be empty (fewer batches than ranks).  The reference's
+        # single-process bookkeeping below would divide by zero there while the other ranks wait in the all-reduce,
+        # so an empty rank contributes zeros and the emptiness check is made once, on the global count.
+        n_batches = images.__len__()
+    else:
+        d0 = images.__len__() * batch_size                # fid_score.py:90-96 bookkeeping
+        if batch_size > d0:
+            print(("Warning: batch size is bigger than the data size. " "Setting batch size to data size"))
+            batch_size = d0
+        n_batches = d0 // batch_size                      # ZeroDivisionError for an empty loader, as upstream
     engine = _engine_for(model, dims)
     stats = device.StatsAccumulator(dims, engine.device)
     for i, batch in enumerate(images):
@@ -179,6 +193,8 @@ def calculate_activation_statistics(images, model, batch_size=64, dims=2048, cud
             break
         stats.update(_forward_batch(engine, model, batch))
     tdist.all_reduce_sum_(stats.buffer())
+    if tdist.world_size() > 1 and stats.count() == 0:     # identical on every rank (read after the all-reduce)
+        raise ZeroDivisionError("no complete batch in the image set (global N < batch size)")
     mu, sigma = stats.finalize()
     if verbose:
         print(" done")
@@ -204,16 +220,22 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
     return calculate_activation_statistics(dataloader, model, batch_size, dims, cuda)
 
 
+def _build_model(dims, weights, num_classes, seed):
+    block_idx = InceptionV3.BLOCK_INDEX_BY_DIM[dims]
+    model = InceptionV3([block_idx], weights=weights, num_classes=num_classes, seed=seed)
+    model.cuda()                                          # fid_score.py:232-233
+    return model
+
+
 def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_classes=1000, seed=0,
                               save_stats="", num_workers=8):
-    """Calculates the FID of two paths (fid_score.py:223-238)."""
+    """Calculates the FID of two paths (fid_score.py:223-238).  ``weights=None`` = seeded stand-in parameters (the
+    CLI only allows that behind --synthetic-weights)."""
     for p in paths:
         if not os.path.exists(p):
             raise RuntimeError("Invalid path: %s" % p)    # :225-227
     _check_cuda(cuda)
-    block_idx = InceptionV3.BLOCK_INDEX_BY_DIM[dims]
-    model = InceptionV3([block_idx], weights=weights, num_classes=num_classes, seed=seed)
-    model.cuda()                                          # :232-233
+    model = _build_model(dims, weights, num_classes, seed)
     m1, s1 = _compute_statistics_of_path(paths[0], model, batch_size, dims, cuda, num_workers)
     m2, s2 = _compute_statistics_of_path(paths[1], model, batch_size, dims, cuda, num_workers)
     if save_stats and tdist.is_main():
@@ -222,23 +244,126 @@ def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_c
     return fid_value
 
 
+def save_statistics_of_path(path, out_npz, batch_size, cuda, dims, weights=None, num_classes=1000, seed=0,
+                            num_workers=8):
+    """STATS-ONLY mode: the step BEFORE the reference path -- write the ``.npz {mu, sigma}`` that
+    ``_compute_statistics_of_path`` (fid_score.py:200-203) reads (the reference ships such files,
+    download_evaluation_data.py:11-12, but no script that makes them).  No Frechet distance is solved."""
+    if not os.path.exists(path):
+        raise RuntimeError("Invalid path: %s" % path)
+    _check_cuda(cuda)
+    model = _build_model(dims, weights, num_classes, seed)
+    mu, sigma = _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers)
+    if tdist.is_main():
+        np.savez(out_npz, mu=np.asarray(mu), sigma=np.asarray(sigma))
+    return mu, sigma
+
+
+def class_of_crop(filename):
+    """``{stem}_{class}_{count}.png`` (object_fidelity/crop_object.py:45) -> class name (may contain spaces; the
+    image stem may contain underscores, so split from the right)."""
+    base = os.path.basename(filename)
+    base = base[:base.rfind(".")] if "." in base else base
+    parts = base.rsplit("_", 2)
+    if len(parts) != 3 or not parts[2].isdigit():
+        raise ValueError(f"not a crop file name ({{stem}}_{{class}}_{{k}}.png): {filename}")
+    return parts[1]
+
+
+def _class_statistics(path, model, batch_size, dims, num_workers):
+    """One pass over a crop directory -> {class: StatsAccumulator}.  Every crop is used (no drop-last: a class is
+    not a DataLoader); batches are formed over the walk-ordered list and each row is folded into its class."""
+    files = img_data.get_filenames(path)
+    classes = [class_of_crop(f) for f in files]
+    names = sorted(set(classes))
+    rank, world, _ = tdist.env_world()
+    lo, hi = tdist.shard_range(len(files), rank, world)
+    engine = _engine_for(model, dims)
+    accs = {c: device.StatsAccumulator(dims, engine.device) for c in names}
+    dataset = img_data.Dataset(path, transform=None, file_names=files[lo:hi])
+    loader = torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=False, drop_last=False,
+                                         num_workers=num_workers, collate_fn=img_data.collate_u8, pin_memory=True)
+    base = lo
+    for batch in loader:
+        feats = _forward_batch(engine, model, batch)
+        cls = classes[base:base + feats.shape[0]]
+        for c in sorted(set(cls)):
+            idx = torch.tensor([i for i, x in enumerate(cls) if x == c], device=feats.device)
+            accs[c].update(feats.index_select(0, idx))
+        base += feats.shape[0]
+    for c in names:                                        # same class list on every rank (same walk)
+        tdist.all_reduce_sum_(accs[c].buffer())
+    return accs
+
+
+def calculate_per_class_fid(paths, batch_size, cuda, dims, weights=None, num_classes=80, seed=0, num_workers=8,
+                            min_count=2):
+    """EXTENSION (BASELINE configs[4]; the reference computes ONE O-FID over all crops): a Frechet
+    distance per object class.  Returns (OrderedDict class -> fid, skipped) where ``skipped`` lists classes with
+    fewer than ``min_count`` crops on either side (covariance undefined)."""
+    from collections import OrderedDict
+    for p in paths:
+        if not os.path.isdir(p):
+            raise RuntimeError("Invalid path: %s" % p)
+    _check_cuda(cuda)
+    model = _build_model(dims, weights, num_classes, seed)
+    a1 = _class_statistics(paths[0], model, batch_size, dims, num_workers)
+    a2 = _class_statistics(paths[1], model, batch_size, dims, num_workers)
+    out, skipped = OrderedDict(), []
+    for c in sorted(set(a1) | set(a2)):
+        if c not in a1 or c not in a2 or a1[c].count() < min_count or a2[c].count() < min_count:
+            skipped.append(c)
+            continue
+        m1, s1 = a1[c].finalize()
+        m2, s2 = a2[c].finalize()
+        out[c] = float(calculate_frechet_distance(m1, s1, m2, s2))
+    return out, skipped
+
+
 def main(argv=None):
-    args = _build_parser().parse_args(argv)
+    parser = _build_parser()
+    args = parser.parse_args(argv)
     if args.gpu == "":
         _check_cuda(False)
+    if args.path1 is None and not args.save_stats:
+        parser.error("--path1 is required (omit it only together with --save-stats: statistics-only mode)")
     rank, world, local_rank = tdist.init_from_env()
     if world == 1:
         os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu)        # reference: CUDA_VISIBLE_DEVICES = args.gpu (:243)
+    kind = "inception80" if (args.label == "O-FID" and args.num_classes == 80) else "inception"
+    wpath, tag = tweights.resolve(args.weights, args.synthetic_weights, kind)
+    if args.path1 is None:                                             # statistics-only (SURVEY 8 f1)
+        if tdist.is_main():
+            print([args.path2])
+        mu, sigma = save_statistics_of_path(args.path2, args.save_stats, args.batch_size, args.gpu, args.dims, wpath,
+                                            args.num_classes, args.seed, args.num_workers)
+        if tdist.is_main():
+            print(f"statistics of {args.path2} -> {args.save_stats}{tag}")
+        return None
     paths = [args.path1, args.path2]
     if tdist.is_main():
         print(paths)                                                   # :247
-    fid_value = calculate_fid_given_paths(paths, args.batch_size, args.gpu, args.dims, args.weights,
+    if args.per_class:
+        per, skipped = calculate_per_class_fid(paths, args.batch_size, args.gpu, args.dims, wpath, args.num_classes,
+                                               args.seed, args.num_workers)
+        mean = float(np.mean(list(per.values()))) if per else float("nan")
+        if tdist.is_main():
+            lines = [f"{args.label}[{c}]: {v}{tag}" for c, v in per.items()]
+            lines.append(f"{args.label} (mean of {len(per)} classes): {mean}{tag}")
+            if skipped:
+                lines.append("skipped (fewer than 2 crops on a side): " + ", ".join(skipped))
+            if args.saved_file:
+                with open(args.saved_file, "w") as f:
+                    f.write("\n".join(lines))
+            print("\n".join(lines))
+        return per
+    fid_value = calculate_fid_given_paths(paths, args.batch_size, args.gpu, args.dims, wpath,
                                           args.num_classes, args.seed, args.save_stats, args.num_workers).item()
     if tdist.is_main():
         if args.saved_file:
             with open(args.saved_file, "w") as f:
-                f.write(f"{args.label}: {fid_value}")                  # :251-252 (no trailing newline)
-        print(f"{args.label}: {fid_value}")                            # :254
+                f.write(f"{args.label}: {fid_value}{tag}")             # :251-252 (no trailing newline)
+        print(f"{args.label}: {fid_value}{tag}")                       # :254
     return fid_value
 
 

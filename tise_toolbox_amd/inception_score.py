@@ -22,7 +22,7 @@ import numpy as np
 import torch
 import torch.utils.data
 
-from . import _lib, device, dist as tdist, img_data
+from . import _lib, device, dist as tdist, img_data, weights as tweights
 from .engine import RealismEngine, T_BIRD, T_COCO, T_OIS, require_gpu
 
 warnings.filterwarnings("ignore")
@@ -105,10 +105,9 @@ def get_inception_score(images, splits=10):
               drop_first_class=_CONFIG["drop_first_class"])
     base = lo
     for batch in loader:
-        if isinstance(batch, (list, tuple)):
-            for b in batch:
-                eng.step_u8(b.unsqueeze(0).to(eng.device, non_blocking=True), base)
-                base += 1
+        if isinstance(batch, (list, tuple)):              # images of different sizes: one trunk pass for the batch
+            eng.step_u8_list(batch, base)
+            base += len(batch)
         else:
             eng.step_u8(batch.to(eng.device, non_blocking=True), base)
             base += batch.shape[0]
@@ -134,9 +133,11 @@ def _build_parser():
     parser.add_argument("--rule", type=str, default="coco", choices=["coco", "bird", "ois"])
     parser.add_argument("--drop-first-class", action="store_true", help="bird: class 0 is background")
     parser.add_argument("--batch-size", type=int, default=50)
-    parser.add_argument("--weights", type=str, default=None)
+    parser.add_argument("--weights", type=str, default=None, help="torchvision-format InceptionV3 state_dict (.pth)")
+    parser.add_argument("--synthetic-weights", action="store_true",
+                        help="seeded stand-in parameters (plumbing / throughput only; results are tagged)")
     parser.add_argument("--num-classes", type=int, default=1000)
-    parser.add_argument("--seed", type=int, default=0)
+    parser.add_argument("--seed", type=int, default=0, help="seed of the --synthetic-weights parameters")
     parser.add_argument("--label", type=str, default="IS", choices=["IS", "O-IS", "bird"])
     return parser
 
@@ -146,7 +147,9 @@ def main(argv=None):
     rank, world, _ = tdist.init_from_env()
     if world == 1:
         os.environ.setdefault("HIP_VISIBLE_DEVICES", str(args.gpu))   # :146
-    configure(weights=args.weights, num_classes=args.num_classes, seed=args.seed, temperature=args.temperature,
+    wpath, tag = tweights.resolve(args.weights, args.synthetic_weights,
+                                  "inception80" if args.label == "O-IS" and args.num_classes == 80 else "inception")
+    configure(weights=wpath, num_classes=args.num_classes, seed=args.seed, temperature=args.temperature,
               batch_size=args.batch_size, rule=args.rule, drop_first_class=args.drop_first_class)
     images = load_data(args.image_folder)
     print(".......")
@@ -162,8 +165,8 @@ def main(argv=None):
             shown = "[Inception Score] mean: {:.2f} std: {:.2f}".format(mean, std)
         if args.saved_file:
             with open(args.saved_file, "w") as f:
-                f.write(text)
-        print(shown)
+                f.write(text + tag)
+        print(shown + tag)
     return mean, std
 
 

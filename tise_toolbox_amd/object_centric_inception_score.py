@@ -20,7 +20,7 @@ import torch
 import torch.utils.data
 from PIL import Image
 
-from . import device, dist as tdist, img_data
+from . import device, dist as tdist, img_data, weights as tweights
 from .engine import RealismEngine, T_OIS, require_gpu
 from .inception import InceptionV3
 
@@ -79,19 +79,17 @@ def inception_score(imgs, cuda=True, batch_size=32, resize=False, splits=1, weig
     eng.begin(n_total=N, temperature=temperature, splits=splits, rule="ois")
     base = lo
     for batch in loader:
-        items = batch if isinstance(batch, (list, tuple)) else [batch]
-        for b in items:
-            if b.dtype == torch.uint8:
-                if b.dim() == 3:
-                    b = b.unsqueeze(0)
-                feats, logits = eng.features_from_u8(b.to(eng.device, non_blocking=True))
-            else:
-                x = b.to(eng.device).float()
-                if resize:
-                    x = torch.nn.functional.interpolate(x, size=(299, 299), mode="bilinear")     # :38,49
-                feats, logits = eng._trunk(x.contiguous(memory_format=torch.channels_last), prenormalized=True)
-            eng.is_acc.update(logits, base)
-            base += logits.shape[0]
+        if isinstance(batch, (list, tuple)):              # crops of different sizes: resized into ONE batch
+            feats, logits = eng.features_from_u8_list(batch)
+        elif batch.dtype == torch.uint8:
+            feats, logits = eng.features_from_u8(batch.to(eng.device, non_blocking=True))
+        else:
+            x = batch.to(eng.device).float()
+            if resize:
+                x = torch.nn.functional.interpolate(x, size=(299, 299), mode="bilinear")         # :38,49
+            feats, logits = eng._trunk(x.contiguous(memory_format=torch.channels_last), prenormalized=True)
+        eng.is_acc.update(logits, base)
+        base += logits.shape[0]
     tdist.all_reduce_sum_(eng.is_acc.acc)
     mean, std, _ = eng.is_acc.finalize()
     return np.float64(mean), np.float64(std)
@@ -103,7 +101,9 @@ def parse_args(argv=None):
     parser.add_argument("--saved_file", default="", type=str)
     parser.add_argument("--gpu_id", default=0, type=int)
     parser.add_argument("--weights", default=None, type=str, help=f"reference default: {DEFAULT_WEIGHTS}")
-    parser.add_argument("--seed", default=0, type=int)
+    parser.add_argument("--synthetic-weights", action="store_true",
+                        help="seeded stand-in parameters (plumbing / throughput only; results are tagged)")
+    parser.add_argument("--seed", default=0, type=int, help="seed of the --synthetic-weights parameters")
     return parser.parse_args(argv)
 
 
@@ -112,16 +112,17 @@ def main(argv=None):
     rank, world, _ = tdist.init_from_env()
     if world == 1:
         torch.cuda.set_device(args.gpu_id)                                    # :121
+    wpath, tag = tweights.resolve(args.weights, args.synthetic_weights, "inception80")       # :45
     print("Load images from: ", args.image_dir)
     imgs = IgnoreLabelDataset(args.image_dir)
     print("Calculating Inception Score...")
     IS_mean, IS_std = inception_score(imgs, cuda=True, batch_size=32, resize=False, splits=10,      # :122
-                                      weights=args.weights, seed=args.seed)
+                                      weights=wpath, seed=args.seed)
     if tdist.is_main():
         if args.saved_file:
             with open(args.saved_file, "w") as f:
-                f.write(f"O-IS: {IS_mean} +-  {IS_std}")                     # :126-127
-        print(f"O-IS: {IS_mean} +- {IS_std}")                                # :129
+                f.write(f"O-IS: {IS_mean} +-  {IS_std}{tag}")                # :126-127
+        print(f"O-IS: {IS_mean} +- {IS_std}{tag}")                           # :129
     return IS_mean, IS_std
 
 

@@ -104,6 +104,8 @@ _RESULT_PATTERNS = {
 def parse_result_file(metric, path):
     """Value of `metric` from a result file written by the corresponding script."""
     text = open(path).read()
+    if "[synthetic weights" in text:                       # weights.SYNTHETIC_TAG: a plumbing run, not a score
+        raise ValueError(f"{path}: produced with --synthetic-weights (seeded stand-in parameters); not a real {metric}")
     m = re.search(_RESULT_PATTERNS[metric], text, re.M)
     if not m:
         raise ValueError(f"{path}: no {metric} result line")
