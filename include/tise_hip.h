@@ -107,6 +107,17 @@ int tise_frechet_destroy(tise_frechet_t* h);
 int tise_frechet_distance(tise_frechet_t* h, const double* mu1_dev, const double* sigma1_dev,
                           const double* mu2_dev, const double* sigma2_dev, double diag_offset,
                           double* out_dev, void* stream);
+/* Two-step form.  Tr sqrtm(S1 S2) is symmetric in its arguments and the factor of ONE covariance does not depend on
+ * the other: when one side's statistics are known early -- the reference .npz of fid_score.py:200-203 -- its pivoted
+ * Cholesky (tise_frechet_prefactor, any stream; synchronises THAT stream to read the rank) can overlap the network
+ * passes of the other side, and tise_frechet_distance_prefactored (which waits for the factor through an event) leaves
+ * only GEMM + tridiagonalisation + bisection after the last batch.  (mu_f, sigma_f) = the factored side, sigma_f the
+ * same matrix that was given to tise_frechet_prefactor.  No diag_offset: on TISE_FLAG_NONFINITE the caller falls back
+ * to tise_frechet_distance with the reference's eps (fid_score.py:156-160). */
+int tise_frechet_prefactor(tise_frechet_t* h, const double* sigma_dev, void* stream);
+int tise_frechet_distance_prefactored(tise_frechet_t* h, const double* mu_f_dev, const double* sigma_f_dev,
+                                      const double* mu_o_dev, const double* sigma_o_dev, double* out_dev, void* stream);
+int tise_frechet_prefactor_ms(tise_frechet_t* h, double* ms_host);   /* HIP-event duration of the last prefactor */
 /* Optional phase timing of tise_frechet_distance with HIP events on the caller's stream.
  * ms_host[5] = pivoted Cholesky | GEMMs | tridiagonalisation | bisection | final reduction.
  * tise_frechet_phase_ms waits for the last recorded call to finish. */

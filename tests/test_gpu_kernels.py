@@ -167,7 +167,7 @@ def test_pivoted_cholesky_reconstructs(dev, d, kind):
     assert np.abs(rec - s1).max() <= 1e-13 * d * np.abs(s1).max()
 
 
-@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 65, 200, 515])
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 65, 200, 515, 1030, 2048])
 def test_eigvalsh_matches_lapack(dev, n):
     from tise_toolbox_amd import device
     rng = np.random.default_rng(n)
@@ -215,6 +215,28 @@ def test_frechet_d2048_vs_reference_scalar(dev, golden_dir, kind):
     assert abs(got - ref) <= (1e-9 if kind == "fullrank" else 1e-4), (got, ref)
     res = fid_score.calculate_frechet_distance.last_result
     assert res["rank"] == 2048 if kind == "fullrank" else res["rank"] < 1100
+
+
+@pytest.mark.parametrize("kind", ["fullrank", "rankdef"])
+def test_frechet_prefactored_equals_one_call_form(dev, kind):
+    """tise_frechet_prefactor (side stream) + tise_frechet_distance_prefactored == tise_frechet_distance, bit for bit
+    (same kernels, the Cholesky merely hoisted); symmetric use: the FACTORED side may be either argument."""
+    from tise_toolbox_amd import device
+    d = 192
+    m1, s1, m2, s2 = _cases.frechet_case(d, kind, seed=5)
+    solver = device.FrechetSolver(d, dev)
+    one = solver.distance(m1, s1, m2, s2)
+    solver.prefactor(torch.as_tensor(s1, device=dev))
+    two = solver.distance_prefactored(m1, m2, s2)
+    assert two["fid"] == one["fid"] and two["rank"] == one["rank"] and two["flags"] == one["flags"]
+    assert solver.prefactor_ms() > 0.0
+    want = fid_oracle.calculate_frechet_distance(m1, s1, m2, s2)
+    solver.prefactor(torch.as_tensor(s2, device=dev))                  # factor the OTHER side
+    three = solver.distance_prefactored(m2, m1, s1)
+    assert abs(three["fid"] - want) <= (1e-9 if kind == "fullrank" else 2e-5)
+    fresh = device.FrechetSolver(d, dev)
+    with pytest.raises(Exception):
+        fresh.distance_prefactored(m1, m2, s2)                          # nothing factored yet
 
 
 def test_frechet_properties(dev):

@@ -52,6 +52,9 @@ SIGNATURES = {
     "tise_frechet_create": (c_int, [c_int, POINTER(c_void_p)]),
     "tise_frechet_destroy": (c_int, [c_void_p]),
     "tise_frechet_distance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_void_p, c_void_p]),
+    "tise_frechet_prefactor": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "tise_frechet_distance_prefactored": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tise_frechet_prefactor_ms": (c_int, [c_void_p, POINTER(c_double)]),
     "tise_frechet_set_profiling": (c_int, [c_void_p, c_int]),
     "tise_frechet_phase_ms": (c_int, [c_void_p, POINTER(c_double), POINTER(c_int)]),
     "tise_eigvalsh": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

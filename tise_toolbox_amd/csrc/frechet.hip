@@ -32,6 +32,7 @@
 // formulation: non-finite input is reported through flag bit 0 and the Python mirror applies the
 // reference's eps retry through `diag_offset`.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include "common.h"
@@ -40,6 +41,8 @@
 #define PCHOL_NP 8          // k-chunks of the left-looking matvec
 #define SY_RC 256           // rows per row-chunk of the fused sytrd update/matvec (4 phases x 64 rows)
 #define SY_CC 64            // columns per workgroup
+#define SYF_G 512           // workgroups of the fused one-launch-per-column tridiagonalisation
+#define SYF_MAX_N 6144      // 3 vectors of n doubles in LDS (144 KB)
 
 struct FrState {
     int piv;        // next pivot (pchol)
@@ -59,10 +62,14 @@ struct tise_frechet {
     double *diag, *colbuf;    // d each
     double *va, *vb, *w;      // d each
     double *td, *te, *eig;    // d each
+    double* fz;               // fused tridiagonalisation: p[2][d] | partial dots [2][SYF_G] | tau[d]
     int* chosen;              // d
     FrState* st;
     int profiling;            // record phase events (tise_frechet_set_profiling)
     hipEvent_t ev[6];         // start | pchol end | gemm end | sytrd end | bisect end | finish end
+    hipEvent_t evp[2];        // tise_frechet_prefactor: start | end (on the stream it ran on)
+    int prefactored;          // h->lt holds the factor of the matrix given to tise_frechet_prefactor
+    int pf_rank;
     int last_rank;
 };
 
@@ -495,6 +502,111 @@ __global__ __launch_bounds__(256) void sytrd_update_matvec_kernel(double* __rest
     if (ph == 0 && live) partial[(int64_t)rc * n + c] = ((s_part[0][lc] + s_part[1][lc]) + s_part[2][lc]) + s_part[3][lc];
 }
 
+// One launch per column (default for n <= SYF_MAX_N).  The two-launch scheme above spends 7 us per column in a
+// single-workgroup kernel and 15 us in an update kernel whose 256 workgroups each walk 64 rows serially.  Here
+// EVERY workgroup first repeats the O(n) bookkeeping of column k for itself -- finish w_{k-1} from the raw
+// product p = A v_{k-1} and the partial dot products the previous launch left, form row k with reflector k-1
+// applied on the fly, generate reflector k (identical arithmetic in every workgroup, so all agree bit for bit) --
+// keeping w_{k-1}, v_{k-1}, v_k in LDS, and then owns whole ROWS of the trailing block: wave = one row at a
+// time, lanes along the row (coalesced 512-byte segments),
+//     A[j][c] -= v_{k-1}[j] w[c] + w[j] v_{k-1}[c]          (c, j >= k+1; skipped for k == 0)
+//     p_k[j]   = sum_c A[j][c] v_k[c]                        (wave reduction; complete per row: no partials)
+// plus the workgroup's share of p_k . v_k.  Rows are dealt round-robin over the LIVE rows, so late columns keep
+// every launched workgroup busy.  Exact symmetry is kept the same way as above (__dmul_rn/__dadd_rn).
+__global__ __launch_bounds__(256) void sytrd_fused_kernel(double* __restrict__ A, int n, int k,
+                                                          const double* __restrict__ vprev_g, double* __restrict__ vcur_g,
+                                                          const double* __restrict__ p_prev, double* __restrict__ p_cur,
+                                                          const double* __restrict__ sd_prev, int g_prev,
+                                                          double* __restrict__ sd_cur, double* __restrict__ td,
+                                                          double* __restrict__ te, double* __restrict__ tau_arr) {
+    extern __shared__ double smem[];
+    double* s_w = smem;
+    double* s_vp = smem + n;
+    double* s_vk = smem + 2 * (size_t)n;
+    __shared__ double s_val[16];
+    const int tid = threadIdx.x;
+    double wk = 0.0, vpk = 0.0;
+    if (k > 0) {
+        const double tau = tau_arr[k - 1];
+        double d = 0.0;
+        for (int g = tid; g < g_prev; g += 256) d += sd_prev[g];
+        d = block_sum(d, s_val);                    // p . v_{k-1}
+        const double alpha = -0.5 * tau * (tau * d);
+        for (int i = k + tid; i < n; i += 256) {
+            const double vp = vprev_g[i];
+            s_vp[i] = vp;
+            s_w[i] = tau * p_prev[i] + alpha * vp;
+        }
+        __syncthreads();
+        wk = s_w[k];
+        vpk = s_vp[k];
+    }
+    double xs = 0.0;                                // sum of squares over i >= k+2
+    for (int i = k + tid; i < n; i += 256) {
+        double x = A[(int64_t)k * n + i];
+        if (k > 0) x -= __dadd_rn(__dmul_rn(s_vp[i], wk), __dmul_rn(s_w[i], vpk));
+        s_vk[i] = x;
+        if (i >= k + 2) xs += x * x;
+    }
+    xs = block_sum(xs, s_val);                      // (contains the barrier that publishes s_vk)
+    const double xk = s_vk[k], x0 = s_vk[k + 1];
+    double beta, tau_k, scale;
+    if (xs == 0.0 || !isfinite(xs)) { tau_k = 0.0; beta = x0; scale = 0.0; }
+    else {
+        const double nrm = sqrt(x0 * x0 + xs);
+        beta = -copysign(nrm, x0);
+        tau_k = (beta - x0) / beta;
+        scale = 1.0 / (x0 - beta);
+    }
+    __syncthreads();
+    for (int i = k + tid; i < n; i += 256) {
+        const double v = (i == k) ? 0.0 : (i == k + 1) ? 1.0 : s_vk[i] * scale;
+        s_vk[i] = v;
+        if (blockIdx.x == 0) vcur_g[i] = v;
+    }
+    if (blockIdx.x == 0 && tid == 0) { td[k] = xk; te[k] = beta; tau_arr[k] = tau_k; }
+    __syncthreads();
+    // ---- own rows of the trailing block ---------------------------------------------------------
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nlive = n - (k + 1);
+    const int c0 = (k + 1) & ~15;                   // 128-byte aligned start of the row segment
+    double pd = 0.0;
+    for (int r = blockIdx.x * 4 + wave; r < nlive; r += gridDim.x * 4) {
+        const int j = k + 1 + r;
+        double* row = A + (int64_t)j * n;
+        const double vpj = k > 0 ? s_vp[j] : 0.0, wj = k > 0 ? s_w[j] : 0.0;
+        double acc = 0.0;
+        for (int cb = c0; cb < n; cb += 256) {      // four 64-lane segments per trip: loads first, then the arithmetic
+            double a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = cb + 64 * u + lane;
+                a[u] = (c > k && c < n) ? row[c] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = cb + 64 * u + lane;
+                if (c > k && c < n) {
+                    double v = a[u];
+                    if (k > 0) {
+                        v -= __dadd_rn(__dmul_rn(vpj, s_w[c]), __dmul_rn(wj, s_vp[c]));
+                        row[c] = v;
+                    }
+                    acc += v * s_vk[c];
+                }
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            p_cur[j] = acc;
+            pd += acc * s_vk[j];
+        }
+    }
+    if (lane == 0) s_val[wave] = pd;
+    __syncthreads();
+    if (tid == 0) sd_cur[blockIdx.x] = ((s_val[0] + s_val[1]) + s_val[2]) + s_val[3];
+}
+
 __global__ void sytrd_last_kernel(const double* __restrict__ A, int n, double* __restrict__ td) {
     if (threadIdx.x == 0 && blockIdx.x == 0) td[n - 1] = A[(int64_t)(n - 1) * n + (n - 1)];
 }
@@ -676,6 +788,35 @@ int run_eigvalsh_inplace(tise_frechet* h, int n, hipStream_t st) {
         TISE_HIP_CHECK(hipMemcpyAsync(h->eig, A, sizeof(double), hipMemcpyDeviceToDevice, st));
         return TISE_OK;
     }
+    static const bool two_launch = getenv("TISE_SYTRD_TWO_LAUNCH") != nullptr;     // A/B switch (tests, tools/frechet_probe.py)
+    if (n <= SYF_MAX_N && !two_launch) {
+        double* pb[2] = {h->fz, h->fz + h->d};
+        double* sd[2] = {h->fz + 2 * (size_t)h->d, h->fz + 2 * (size_t)h->d + SYF_G};
+        double* tau_arr = h->fz + 2 * (size_t)h->d + 2 * SYF_G;
+        double* vv[2] = {h->va, h->vb};
+        const size_t lds = 3 * (size_t)n * sizeof(double);
+        if (lds > 48 * 1024)
+            TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(sytrd_fused_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int g_prev = 0;
+        for (int k = 0; k <= n - 2; ++k) {
+            const int nlive = n - (k + 1);
+            int g = ceil_div(nlive, 4);
+            if (g > SYF_G) g = SYF_G;
+            hipLaunchKernelGGL(sytrd_fused_kernel, dim3(g), dim3(256), lds, st, A, n, k, vv[(k + 1) & 1], vv[k & 1],
+                               pb[(k + 1) & 1], pb[k & 1], sd[(k + 1) & 1], g_prev, sd[k & 1], h->td, h->te, tau_arr);
+            g_prev = g;
+        }
+        TISE_LAUNCH_CHECK();
+        // launch k = n-2 (trivial reflector, tau = 0) has applied reflector n-3 to A[n-1][n-1]
+        hipLaunchKernelGGL(sytrd_last_kernel, dim3(1), dim3(64), 0, st, A, n, h->td);
+        TISE_LAUNCH_CHECK();
+        if (h->profiling) TISE_HIP_CHECK(hipEventRecord(h->ev[3], st));
+        hipLaunchKernelGGL(gershgorin_kernel, dim3(1), dim3(1024), 0, st, h->td, h->te, n, h->st);
+        hipLaunchKernelGGL(bisect_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, st, h->td, h->te, n, h->st, h->eig);
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
     const dim3 ugrid(ceil_div(n, SY_CC), ceil_div(n, SY_RC));   // 32 x 8 = 256 workgroups at n = 2048
     double* vprev = h->va;
     double* vcur = h->vb;
@@ -707,7 +848,8 @@ int tise_frechet_create(int d, tise_frechet_t** out) {
     const size_t dd = (size_t)d * d;
     const size_t nchunk = (size_t)((d + SY_RC - 1) / SY_RC + 1) > (size_t)PCHOL_NP ? (size_t)((d + SY_RC - 1) / SY_RC + 1) : (size_t)PCHOL_NP;
     // one allocation, carved
-    const size_t total = 3 * dd + nchunk * d + 8 * (size_t)d + 64;
+    const size_t fz = 3 * (size_t)d + 2 * SYF_G;
+    const size_t total = 3 * dd + nchunk * d + 8 * (size_t)d + fz + 64;
     double* base = nullptr;
     hipError_t e = hipMalloc((void**)&base, total * sizeof(double) + (size_t)d * sizeof(int) + sizeof(FrState) + 256);
     if (e != hipSuccess) { tise_set_last_hip_error((int)e); delete h; return TISE_ERR_HIP; }
@@ -726,11 +868,12 @@ int tise_frechet_create(int d, tise_frechet_t** out) {
     h->td = p; p += d;
     h->te = p; p += d;
     h->eig = p; p += d;
+    h->fz = p; p += fz;
     p += 8;
     h->st = reinterpret_cast<FrState*>(p); p += (sizeof(FrState) + 7) / 8 + 8;
     h->chosen = reinterpret_cast<int*>(p);
-    for (int i = 0; i < 6; ++i) {
-        e = hipEventCreate(&h->ev[i]);
+    for (int i = 0; i < 8; ++i) {
+        e = hipEventCreate(i < 6 ? &h->ev[i] : &h->evp[i - 6]);
         if (e != hipSuccess) { tise_set_last_hip_error((int)e); (void)hipFree(base); delete h; return TISE_ERR_HIP; }
     }
     *out = h;
@@ -740,6 +883,7 @@ int tise_frechet_create(int d, tise_frechet_t** out) {
 int tise_frechet_destroy(tise_frechet_t* h) {
     if (!h) return TISE_OK;
     for (int i = 0; i < 6; ++i) (void)hipEventDestroy(h->ev[i]);
+    for (int i = 0; i < 2; ++i) (void)hipEventDestroy(h->evp[i]);
     (void)hipFree(h->lt);   // lt is the base of the single allocation
     delete h;
     return TISE_OK;
@@ -772,20 +916,24 @@ int tise_eigvalsh(tise_frechet_t* h, const double* a_dev, int n, double* w_dev, 
     return TISE_OK;
 }
 
-int tise_frechet_distance(tise_frechet_t* h, const double* mu1_dev, const double* sigma1_dev, const double* mu2_dev,
-                          const double* sigma2_dev, double diag_offset, double* out_dev, void* stream) {
-    if (!h || !mu1_dev || !sigma1_dev || !mu2_dev || !sigma2_dev || !out_dev) return TISE_ERR_INVALID_ARG;
-    hipStream_t st = (hipStream_t)stream;
+static int frechet_core(tise_frechet_t* h, const double* mu1_dev, const double* sigma1_dev, const double* mu2_dev,
+                        const double* sigma2_dev, double diag_offset, double* out_dev, hipStream_t st, bool factor_here) {
     const int d = h->d;
     int r = 0;
     if (h->profiling) TISE_HIP_CHECK(hipEventRecord(h->ev[0], st));
-    int rc = run_pchol(h, sigma1_dev, diag_offset, &r, st);
-    if (rc != TISE_OK) return rc;
+    if (factor_here) {
+        h->prefactored = 0;
+        int rc = run_pchol(h, sigma1_dev, diag_offset, &r, st);
+        if (rc != TISE_OK) return rc;
+    } else {
+        r = h->pf_rank;
+    }
     h->last_rank = r;
     if (h->profiling) {
         TISE_HIP_CHECK(hipEventRecord(h->ev[1], st));
         if (r <= 1) { TISE_HIP_CHECK(hipEventRecord(h->ev[2], st)); TISE_HIP_CHECK(hipEventRecord(h->ev[3], st)); }
     }
+    int rc = TISE_OK;
     if (r > 0) {
         // T1^T (r x d) = L^T (r x d) * S2 (d x d)
         rc = launch_gemm(h->lt, d, 1, sigma2_dev, d, 1, h->t1, d, r, d, d, st);
@@ -808,6 +956,48 @@ int tise_frechet_distance(tise_frechet_t* h, const double* mu1_dev, const double
                        diag_offset, h->eig, r, h->st, out_dev);
     TISE_LAUNCH_CHECK();
     if (h->profiling) TISE_HIP_CHECK(hipEventRecord(h->ev[5], st));
+    return TISE_OK;
+}
+
+int tise_frechet_distance(tise_frechet_t* h, const double* mu1_dev, const double* sigma1_dev, const double* mu2_dev,
+                          const double* sigma2_dev, double diag_offset, double* out_dev, void* stream) {
+    if (!h || !mu1_dev || !sigma1_dev || !mu2_dev || !sigma2_dev || !out_dev) return TISE_ERR_INVALID_ARG;
+    return frechet_core(h, mu1_dev, sigma1_dev, mu2_dev, sigma2_dev, diag_offset, out_dev, (hipStream_t)stream, true);
+}
+
+// The factor of ONE covariance does not depend on the other: when one side's statistics are known early (the
+// reference .npz of the README recipe, fid_score.py:200-203), its pivoted Cholesky can run on a side stream while
+// the other side's images are still going through the network, and the serial tail after the last batch is only
+// GEMM + tridiagonalisation + bisection.  Tr sqrtm(S1 S2) is symmetric in (S1, S2), so either side may be factored.
+int tise_frechet_prefactor(tise_frechet_t* h, const double* sigma_dev, void* stream) {
+    if (!h || !sigma_dev) return TISE_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    h->prefactored = 0;
+    TISE_HIP_CHECK(hipEventRecord(h->evp[0], st));
+    int r = 0;
+    int rc = run_pchol(h, sigma_dev, 0.0, &r, st);          // synchronises `st` (rank read-back), not the device
+    if (rc != TISE_OK) return rc;
+    TISE_HIP_CHECK(hipEventRecord(h->evp[1], st));
+    h->pf_rank = r;
+    h->prefactored = 1;
+    return TISE_OK;
+}
+
+int tise_frechet_distance_prefactored(tise_frechet_t* h, const double* mu_f_dev, const double* sigma_f_dev,
+                                      const double* mu_o_dev, const double* sigma_o_dev, double* out_dev, void* stream) {
+    if (!h || !mu_f_dev || !sigma_f_dev || !mu_o_dev || !sigma_o_dev || !out_dev) return TISE_ERR_INVALID_ARG;
+    if (!h->prefactored) return TISE_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    TISE_HIP_CHECK(hipStreamWaitEvent(st, h->evp[1], 0));   // the factor was produced on another stream
+    return frechet_core(h, mu_f_dev, sigma_f_dev, mu_o_dev, sigma_o_dev, 0.0, out_dev, st, false);
+}
+
+int tise_frechet_prefactor_ms(tise_frechet_t* h, double* ms_host) {
+    if (!h || !ms_host || !h->prefactored) return TISE_ERR_INVALID_ARG;
+    TISE_HIP_CHECK(hipEventSynchronize(h->evp[1]));
+    float ms = 0.f;
+    TISE_HIP_CHECK(hipEventElapsedTime(&ms, h->evp[0], h->evp[1]));
+    *ms_host = (double)ms;
     return TISE_OK;
 }
 

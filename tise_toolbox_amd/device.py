@@ -220,6 +220,40 @@ class FrechetSolver:
         return {"fid": np.float64(o[0]), "tr_covmean": float(o[1]), "diff2": float(o[2]), "tr1": float(o[3]),
                 "tr2": float(o[4]), "rank": int(o[5]), "n_negative": int(o[6]), "flags": int(o[7])}
 
+    def prefactor(self, sigma, stream=None):
+        """Start the pivoted Cholesky of ``sigma`` (d,d fp64 CUDA tensor, kept alive by the solver) on ``stream``
+        (default: a private side stream, so it overlaps whatever the current stream is doing).  The host blocks
+        until that stream has finished the factorisation (the numerical rank is read back), not the device."""
+        sigma = self._prep(sigma, (self.dims, self.dims))
+        if stream is None:
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            stream = self._side
+        stream.wait_stream(torch.cuda.current_stream(self.device))        # sigma may still be in flight there
+        self._pf_sigma = sigma
+        _lib.call("tise_frechet_prefactor", self._h, _ptr(sigma), ctypes.c_void_p(stream.cuda_stream))
+        sigma.record_stream(stream)
+        return self
+
+    def distance_prefactored(self, mu_f, mu_o, sigma_o):
+        """Frechet distance between (mu_f, the sigma given to prefactor()) and (mu_o, sigma_o)."""
+        d = self.dims
+        if getattr(self, "_pf_sigma", None) is None:
+            raise RuntimeError("prefactor() has not been called")
+        mu_f = self._prep(mu_f, (d,)); mu_o = self._prep(mu_o, (d,))
+        sigma_o = self._prep(sigma_o, (d, d))
+        out = torch.empty(_lib.TISE_FRECHET_OUT_DOUBLES, dtype=torch.float64, device=self.device)
+        _lib.call("tise_frechet_distance_prefactored", self._h, _ptr(mu_f), _ptr(self._pf_sigma), _ptr(mu_o), _ptr(sigma_o),
+                  _ptr(out), _stream())
+        o = out.cpu().numpy()
+        return {"fid": np.float64(o[0]), "tr_covmean": float(o[1]), "diff2": float(o[2]), "tr1": float(o[3]),
+                "tr2": float(o[4]), "rank": int(o[5]), "n_negative": int(o[6]), "flags": int(o[7])}
+
+    def prefactor_ms(self):
+        ms = ctypes.c_double()
+        _lib.call("tise_frechet_prefactor_ms", self._h, ctypes.byref(ms))
+        return ms.value
+
     def set_profiling(self, on=True):
         _lib.call("tise_frechet_set_profiling", self._h, 1 if on else 0)
 

@@ -237,11 +237,23 @@ def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_c
     _check_cuda(cuda)
     model = _build_model(dims, weights, num_classes, seed)
     m1, s1 = _compute_statistics_of_path(paths[0], model, batch_size, dims, cuda, num_workers)
+    # the first side's covariance is complete: factor it on a side stream while the second side's images are decoded
+    # and pushed through the network (Tr sqrtm(S1 S2) is symmetric in its arguments; csrc/frechet.hip)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    solver = frechet_solver(dims, dev)
+    use_pf = tuple(np.shape(s1)) == (dims, dims) and tuple(np.shape(m1)) == (dims,)
+    if use_pf:
+        solver.prefactor(torch.as_tensor(np.ascontiguousarray(s1, dtype=np.float64), device=dev))
     m2, s2 = _compute_statistics_of_path(paths[1], model, batch_size, dims, cuda, num_workers)
     if save_stats and tdist.is_main():
         np.savez(save_stats, mu=np.asarray(m2), sigma=np.asarray(s2))
-    fid_value = calculate_frechet_distance(m1, s1, m2, s2)
-    return fid_value
+    if not use_pf or np.shape(m1) != np.shape(m2) or np.shape(s1) != np.shape(s2):
+        return calculate_frechet_distance(m1, s1, m2, s2)     # generic path (shape asserts :149-150 included)
+    res = solver.distance_prefactored(np.atleast_1d(m1), np.atleast_1d(m2), np.atleast_2d(s2))
+    if res["flags"] & _lib.TISE_FLAG_NONFINITE:          # :156-160 (eps retry) lives in calculate_frechet_distance
+        return calculate_frechet_distance(m1, s1, m2, s2)
+    calculate_frechet_distance.last_result = res
+    return np.float64(res["fid"])
 
 
 def save_statistics_of_path(path, out_npz, batch_size, cuda, dims, weights=None, num_classes=1000, seed=0,
