@@ -607,6 +607,128 @@ __global__ __launch_bounds__(256) void sytrd_fused_kernel(double* __restrict__ A
     if (tid == 0) sd_cur[blockIdx.x] = ((s_val[0] + s_val[1]) + s_val[2]) + s_val[3];
 }
 
+// n <= 2048 form of the kernel above (the metric's d): the launch is latency-, not bandwidth-bound for most
+// columns (measured 13.4 us per column with three dependent load phases and five barriers in the bookkeeping),
+// so here every global value the bookkeeping needs -- tau, the partial dots, v_{k-1}, p, row k, and the first
+// segments of the wave's own trailing row -- is requested up front (8 elements per thread per vector), every
+// wave sums the partial dots for itself, and two barriers remain.  Rows map to workgroups by a FIXED rule
+// (row j -> workgroup j / 4, one row per wave), so a row is revisited by the same XCD in every launch and the
+// 33.5 MB matrix stays spread over the eight 4 MB L2s; the grid starts at the first workgroup (rounded down to
+// a multiple of 8, which keeps the workgroup -> XCD map) that still owns a live row.
+__global__ __launch_bounds__(256) void sytrd_fused8_kernel(double* __restrict__ A, int n, int k, int wg0,
+                                                           const double* __restrict__ vprev_g, double* __restrict__ vcur_g,
+                                                           const double* __restrict__ p_prev, double* __restrict__ p_cur,
+                                                           const double* __restrict__ sd_prev, int sd_lo, int sd_hi,
+                                                           double* __restrict__ sd_cur, double* __restrict__ td,
+                                                           double* __restrict__ te, double* __restrict__ tau_arr) {
+    __shared__ double s_w[2048], s_vp[2048], s_vk[2048];
+    __shared__ double s_val[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wg = wg0 + blockIdx.x;
+    const int j = wg * 4 + wave;                                  // this wave's row
+    const bool row_live = j > k && j < n;
+    const int c0 = (k + 1) & ~15;
+    // ---- every global request first --------------------------------------------------------------
+    double xr[8], vpr[8], ppr[8], ar[32];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = k + tid + 256 * u;
+        xr[u] = i < n ? A[(int64_t)k * n + i] : 0.0;
+        vpr[u] = (k > 0 && i < n) ? vprev_g[i] : 0.0;
+        ppr[u] = (k > 0 && i < n) ? p_prev[i] : 0.0;
+    }
+    // the wave's whole trailing row (<= 32 segments of 64 doubles) is requested now: its latency hides under the
+    // bookkeeping, and the row is never the limiter of memory-level parallelism (4 requests per lane in flight per
+    // trip measured 1.7 us per 256-column trip: 19 us at k = 0)
+    double* row = A + (int64_t)(row_live ? j : k) * n;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const int c = c0 + 64 * u + lane;
+        ar[u] = (row_live && c > k && c < n) ? row[c] : 0.0;
+    }
+    double tau = 0.0, alpha = 0.0, wk = 0.0, vpk = 0.0;
+    if (k > 0) {
+        tau = tau_arr[k - 1];
+        double d = 0.0;
+        for (int g = sd_lo + lane; g < sd_hi; g += 64) d += sd_prev[g];
+        d = wave_sum(d);                                          // p . v_{k-1}: every wave for itself, same order
+        alpha = -0.5 * tau * (tau * d);
+        vpk = vprev_g[k];
+        wk = tau * p_prev[k] + alpha * vpk;
+    }
+    // ---- w_{k-1}, v_{k-1} -> LDS; row k with reflector k-1 applied; its tail norm -----------------
+    double xs = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = k + tid + 256 * u;
+        if (i < n) {
+            double x = xr[u];
+            if (k > 0) {
+                const double w = tau * ppr[u] + alpha * vpr[u];
+                s_w[i] = w;
+                s_vp[i] = vpr[u];
+                x -= __dadd_rn(__dmul_rn(vpr[u], wk), __dmul_rn(w, vpk));
+            }
+            xr[u] = x;
+            if (i >= k + 2) xs += x * x;
+        }
+    }
+    xs = wave_sum(xs);
+    if (lane == 0) s_val[wave] = xs;
+    // x_k and x_{k+1} sit in thread 0 (u = 0) and thread 1 (u = 0): publish them with the same barrier
+    __shared__ double s_x[2];
+    if (tid < 2 && k + tid < n) s_x[tid] = xr[0];
+    __syncthreads();
+    xs = ((s_val[0] + s_val[1]) + s_val[2]) + s_val[3];
+    const double xk = s_x[0], x0 = s_x[1];
+    double beta, tau_k, scale;
+    if (xs == 0.0 || !isfinite(xs)) { tau_k = 0.0; beta = x0; scale = 0.0; }
+    else {
+        const double nrm = sqrt(x0 * x0 + xs);
+        beta = -copysign(nrm, x0);
+        tau_k = (beta - x0) / beta;
+        scale = 1.0 / (x0 - beta);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = k + tid + 256 * u;
+        if (i < n) {
+            const double v = (i == k) ? 0.0 : (i == k + 1) ? 1.0 : xr[u] * scale;
+            s_vk[i] = v;
+            if (blockIdx.x == 0) vcur_g[i] = v;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) { td[k] = xk; te[k] = beta; tau_arr[k] = tau_k; }
+    __syncthreads();
+    // ---- the wave's row of the trailing block -------------------------------------------------------
+    double pd = 0.0;
+    if (row_live) {
+        const double vpj = k > 0 ? s_vp[j] : 0.0, wj = k > 0 ? s_w[j] : 0.0;
+        double acc = 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int c = c0 + 64 * u + lane;
+            if (c > k && c < n) {
+                double v = ar[u];
+                if (k > 0) {
+                    v -= __dadd_rn(__dmul_rn(vpj, s_w[c]), __dmul_rn(wj, s_vp[c]));
+                    row[c] = v;
+                }
+                acc += v * s_vk[c];
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            p_cur[j] = acc;
+            pd = acc * s_vk[j];
+        }
+    }
+    __syncthreads();                                                // s_val reuse
+    if (lane == 0) s_val[wave] = pd;
+    __syncthreads();
+    if (tid == 0) sd_cur[wg] = ((s_val[0] + s_val[1]) + s_val[2]) + s_val[3];
+}
+
 __global__ void sytrd_last_kernel(const double* __restrict__ A, int n, double* __restrict__ td) {
     if (threadIdx.x == 0 && blockIdx.x == 0) td[n - 1] = A[(int64_t)(n - 1) * n + (n - 1)];
 }
@@ -789,6 +911,30 @@ int run_eigvalsh_inplace(tise_frechet* h, int n, hipStream_t st) {
         return TISE_OK;
     }
     static const bool two_launch = getenv("TISE_SYTRD_TWO_LAUNCH") != nullptr;     // A/B switch (tests, tools/frechet_probe.py)
+    if (n <= 2048 && !two_launch && getenv("TISE_SYTRD_FUSED_GENERIC") == nullptr) {
+        double* pb[2] = {h->fz, h->fz + h->d};
+        double* sd[2] = {h->fz + 2 * (size_t)h->d, h->fz + 2 * (size_t)h->d + SYF_G};
+        double* tau_arr = h->fz + 2 * (size_t)h->d + 2 * SYF_G;
+        double* vv[2] = {h->va, h->vb};
+        const int wg_end = ceil_div(n, 4);                           // workgroup g owns rows 4g .. 4g+3
+        int sd_lo = 0, sd_hi = 0;
+        for (int k = 0; k <= n - 2; ++k) {
+            const int wg0 = ((k + 1) / 4) & ~7;                      // first workgroup with a live row, XCD map kept
+            hipLaunchKernelGGL(sytrd_fused8_kernel, dim3(wg_end - wg0), dim3(256), 0, st, A, n, k, wg0, vv[(k + 1) & 1],
+                               vv[k & 1], pb[(k + 1) & 1], pb[k & 1], sd[(k + 1) & 1], sd_lo, sd_hi, sd[k & 1], h->td,
+                               h->te, tau_arr);
+            sd_lo = wg0;
+            sd_hi = wg_end;
+        }
+        TISE_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sytrd_last_kernel, dim3(1), dim3(64), 0, st, A, n, h->td);
+        TISE_LAUNCH_CHECK();
+        if (h->profiling) TISE_HIP_CHECK(hipEventRecord(h->ev[3], st));
+        hipLaunchKernelGGL(gershgorin_kernel, dim3(1), dim3(1024), 0, st, h->td, h->te, n, h->st);
+        hipLaunchKernelGGL(bisect_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, st, h->td, h->te, n, h->st, h->eig);
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
     if (n <= SYF_MAX_N && !two_launch) {
         double* pb[2] = {h->fz, h->fz + h->d};
         double* sd[2] = {h->fz + 2 * (size_t)h->d, h->fz + 2 * (size_t)h->d + SYF_G};
