@@ -223,16 +223,15 @@ int tise_cosine_top1(const void* img_emb_dev, const void* txt_emb_dev, const int
  * `args` points to a host-side tise_conv_args (copied into the launch).  `tn` = tile width | kernel variant:
  * the low four bits give the output tile, 128 pixels x 32*tn channels with tn in {1..5} (tn = 1 only with the
  * DMA variants); weights and scale/bias must be padded to a multiple of 32*tn rows and of 32 in K.
- * Variant bits (same arithmetic; the first five give bit-identical results):
- *   0    operands staged through registers          16   direct-to-LDS DMA, two stages
- *   32   8 waves, 256-pixel tile, three stages      64   weights straight to registers
- *   128  DMA with the address arithmetic hoisted out of the K loop when Cin % 32 == 0 (the default of the
- *        Python layer; falls back to 16 otherwise)
- *   256  window-resident input for stride-1 multi-tap convolutions; weights packed [cout][tap][Cin rounded
- *        up to 32], K order (channel block, tap)
- *   512  conv_pipe.hip: persistent 8-wave kernels, 256-pixel tiles, three stages; the low four bits then
- *        select tile width / wave layout / schedule (see tise_conv_pipe_launch in conv_pipe.hip); weights
- *        packed as for 256, rows padded to the configuration's tile width.
+ * Variant bits (same arithmetic; 0, 16 and 128 give bit-identical results):
+ *   0    operands staged through registers (reference kernel of the tests)
+ *   16   direct-to-LDS DMA, two stages (generic K order; also serves M >= 2^31)
+ *   128  DMA with the address arithmetic hoisted out of the K loop, K order (tap, 32-channel block) + paired
+ *        16-channel tails (the default of the Python layer; falls back to 16 when the packing differs)
+ *   512  conv_pipe.hip: the low eight bits select a configuration (33: resident-weights sliding-window kernel
+ *        for Cin = 32 3x3 stride 1; 45-47: wave-specialised 256-pixel tiles); weights packed
+ *        [cout][tap][Cin rounded up to 32], rows padded to the configuration's tile width.
+ *   (Round 1's variants 32 / 64 / 256 and pipe configurations 0-15, 40-44 tied with 128 and were removed.)
  * Bits 8..11 of args->nseg are measurement switches (tools/conv_ablate.py, tools/conv_stamps.py) and must be
  * zero in product calls.
  * ------------------------------------------------------------------------------------------ */
@@ -260,6 +259,12 @@ typedef struct {
 } tise_conv_args;
 
 int tise_conv_split_f16(const tise_conv_args* args, int tn, void* stream);
+
+/* Range guard of the split format: every kernel that writes split planes (the convolution epilogues, the stem
+ * convolution, the average-pool tail) raises a per-device flag when a value it converts exceeds the fp16 range
+ * (65504; it would become +inf in the hi plane) or is NaN.  Reads the flag into *flag_host (0 / 1), clears it and
+ * synchronises `stream`.  The Python mirror calls it once per image set and raises FloatingPointError. */
+int tise_split_overflow_check(int* flag_host, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * fp64 GEMM building block (MFMA v_mfma_f64_16x16x4_f64), exported for tests/bench only:

@@ -78,6 +78,7 @@ SIGNATURES = {
                                               c_void_p]),
     "tise_split_mean_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tise_conv_split_f16": (c_int, [c_void_p, c_int, c_void_p]),
+    "tise_split_overflow_check": (c_int, [POINTER(c_int), c_void_p]),
     "tise_gemm_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
                                c_int, c_int, c_int, c_void_p]),
 }

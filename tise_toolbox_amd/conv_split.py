@@ -60,18 +60,12 @@ def pick_tn(cout):
 
 # conv_pipe.hip tile widths by configuration index, and the configuration for a given Cout: least padded work,
 # ties to the wider tile
-PIPE_BN = {0: 128, 1: 96, 2: 64, 3: 160, 4: 64, 5: 32, 6: 128, 8: 128, 9: 96, 10: 64, 11: 128, 12: 96, 13: 64, 14: 32, 7: 128, 15: 96, 33: 32, 40: 128, 41: 96, 42: 64, 43: 128, 44: 160, 45: 128, 46: 96, 47: 128}
+PIPE_BN = {33: 32, 45: 128, 46: 96, 47: 128}
 
 
 def pick_pipe_cfg(cout):
-    best = None
-    for cfg in (0, 1, 2, 5):
-        bn = PIPE_BN[cfg]
-        work = -(-cout // bn) * bn
-        key = (work, -bn)
-        if best is None or key < best[0]:
-            best = (key, cfg)
-    return best[1]
+    """Wave-specialised 256-pixel kernel: 96-cout tiles when they waste less padded work than 128-cout tiles."""
+    return 46 if -(-cout // 96) * 96 < -(-cout // 128) * 128 else 45
 
 
 # Optional per-layer kernel choice (TISE_CONV_AUTO=1), from tools/conv_pipe_probe.py on the trunk's shapes at batch 500
@@ -103,11 +97,12 @@ class SplitConv:
         self.padding = tuple(padding)
         self.tn = tn or pick_tn(cout)
         self.pipe_cfg = None
-        # kernel variant: "reg" register-staged (4 waves), "glds" direct-to-LDS 2-stage (4 waves),
-        # "glds3" direct-to-LDS 3-stage, 8 waves, 256-pixel tile, "gldsb" weights straight to registers,
-        # "fast" = glds with hoisted addressing (default), "win" = window-resident input for stride-1
-        # multi-tap layers (A/B variant: measured equal to "fast" within +-3 %, profiles/r01g_conv_window_probe.txt)
+        # kernel variant: "fast" = LDS-DMA staging with hoisted addressing (default); "glds" = its generic form (any
+        # Cin % 16 == 0 / K order, M >= 2^31); "reg" = register-staged reference kernel (the bitwise baseline of the
+        # tests); "pipe" = conv_pipe.hip configurations (33: Conv2d_2a; 45-47: opt-in table below)
         self.variant = variant or os.environ.get("TISE_CONV_VARIANT", "fast")
+        if self.variant not in ("fast", "glds", "reg", "pipe"):
+            raise ValueError(f"unknown conv variant {self.variant!r} (round 2 removed glds3 / gldsb / win)")
         if variant is None and self.variant == "fast" and os.environ.get("TISE_CONV_AUTO", "0") == "1":
             auto = AUTO_PIPE_CFG.get((cin, cout, kh, kw, self.stride[0]))
             if auto is not None and self.stride[0] == self.stride[1]:
@@ -126,9 +121,7 @@ class SplitConv:
         wp = torch.zeros((self.cout_pad, self.kpad), dtype=torch.float32)
         wp[:cout, :self.k] = wk
         self.w = split(wp).to(device).contiguous()                  # (2, Cout_pad, Kpad) fp16
-        # window kernel (stride 1, more than one tap): weights packed [tap][Cin rounded up to 32]
-        self.win = self.variant == "win" and self.stride == (1, 1) and kh * kw > 1
-        if self.win or self.pipe_cfg is not None:
+        if self.pipe_cfg is not None:                               # conv_pipe.hip: weights packed [tap][Cin rounded up to 32]
             cin_pad = -(-cin // 32) * 32
             ww = torch.zeros((self.cout_pad, kh * kw, cin_pad), dtype=torch.float32)
             ww[:cout, :, :cin] = wk.reshape(cout, kh * kw, cin)
@@ -190,10 +183,8 @@ class SplitConv:
             e0.record()
         if self.pipe_cfg is not None:
             code = 512 | self.pipe_cfg
-        elif self.win:
-            code = 256 | self.tn
         else:
-            code = self.tn | {"reg": 0, "glds": 16, "glds3": 32, "gldsb": 64, "fast": 128, "win": 128}[self.variant]
+            code = self.tn | {"reg": 0, "glds": 16, "fast": 128}[self.variant]
         _lib.call("tise_conv_split_f16", ctypes.byref(a), code,
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         if timer is not None:

@@ -40,4 +40,18 @@ int tise_device_info(int* cu_count, int* gcn_arch_is_gfx950, size_t* total_mem) 
     return TISE_OK;
 }
 
+// per-translation-unit range-guard words (common.h)
+int tise_internal_split_flag_conv_split(int* host_flag, void* stream);
+int tise_internal_split_flag_conv_pipe(int* host_flag, void* stream);
+int tise_internal_split_flag_trunk_ops(int* host_flag, void* stream);
+
+int tise_split_overflow_check(int* flag_host, void* stream) {
+    if (!flag_host) return TISE_ERR_INVALID_ARG;
+    *flag_host = 0;
+    int rc = tise_internal_split_flag_conv_split(flag_host, stream);
+    if (rc == TISE_OK) rc = tise_internal_split_flag_conv_pipe(flag_host, stream);
+    if (rc == TISE_OK) rc = tise_internal_split_flag_trunk_ops(flag_host, stream);
+    return rc;
+}
+
 }  // extern "C"

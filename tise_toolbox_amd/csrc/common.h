@@ -33,3 +33,34 @@ __device__ __forceinline__ double wave_max(double v) {
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
     return v;
 }
+
+// Range guard of the split-fp16 activation format (v ~= hi + lo * 2^-11, hi = fp16(v)): a value above the fp16
+// range (65504) would become +inf in the hi plane and poison every later layer without any visible failure.  Every
+// kernel that WRITES split planes keeps the running maximum of what it converts (one v_max per element; all values
+// are post-ReLU, i.e. >= 0) and raises bit 0 of a per-device word when it exceeds the range; the host reads and
+// clears the words with tise_split_overflow_check (capi.hip; the Python mirror raises FloatingPointError).
+// The library is built without relocatable device code, so each translation unit has its OWN word (unnamed
+// namespace) and exports a reader for it with TISE_DEFINE_SPLIT_FLAG_READER.
+#define TISE_F16_MAX 65504.0f
+namespace {
+__device__ int g_tise_split_overflow_tu;
+__device__ __forceinline__ void tise_flag_split_overflow(float running_max) {
+    if (!(running_max <= TISE_F16_MAX)) atomicOr(&g_tise_split_overflow_tu, 1);     // also catches NaN
+}
+}  // namespace
+#define TISE_DEFINE_SPLIT_FLAG_READER(NAME)                                                                          \
+    extern "C" int NAME(int* host_flag, void* stream) {                                                             \
+        hipStream_t st_ = (hipStream_t)stream;                                                                      \
+        int v_ = 0;                                                                                                 \
+        TISE_HIP_CHECK(hipMemcpyFromSymbolAsync(&v_, HIP_SYMBOL(g_tise_split_overflow_tu), sizeof(int), 0,          \
+                                                hipMemcpyDeviceToHost, st_));                                       \
+        TISE_HIP_CHECK(hipStreamSynchronize(st_));                                                                  \
+        if (v_) {                                                                                                   \
+            const int z_ = 0;                                                                                       \
+            TISE_HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_tise_split_overflow_tu), &z_, sizeof(int), 0,        \
+                                                  hipMemcpyHostToDevice, st_));                                     \
+            TISE_HIP_CHECK(hipStreamSynchronize(st_));                                                              \
+        }                                                                                                           \
+        *host_flag |= v_;                                                                                           \
+        return TISE_OK;                                                                                             \
+    }

@@ -62,6 +62,7 @@ __device__ __forceinline__ void store_tiles(const tise_conv_args& p, float16_t (
     constexpr int PITCH = Staging<TW>::PITCH;
     const int lane = threadIdx.x & 63;
     const int nseg = p.nseg & 0xff;
+    float vmax = 0.f;                                            // range guard of the split format (common.h)
 #pragma unroll
     for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -91,6 +92,7 @@ __device__ __forceinline__ void store_tiles(const tise_conv_args& p, float16_t (
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float r = fmaxf(v[k] + bs[k], 0.f);
+                            vmax = fmaxf(vmax, r);
                             hi[k] = (_Float16)r;
                             lo[k] = (_Float16)((r - (float)hi[k]) * 2048.0f);
                         }
@@ -146,6 +148,7 @@ __device__ __forceinline__ void store_tiles(const tise_conv_args& p, float16_t (
                 }
             }
         }
+    tise_flag_split_overflow(vmax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -207,6 +210,7 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float1
     const int lane = threadIdx.x & 63;
     const long long left = (GRID ? (long long)p.N * p.H * p.W : p.M) - m0w;   // rows of this tile that exist (wave-uniform)
     const int rows_ok = left > 32 ? 32 : (left < 0 ? 0 : (int)left);
+    float vmax = 0.f;                                            // range guard of the split format (common.h)
 #pragma unroll
     for (int t0 = 0; t0 < TNW; t0 += TW) {
         const int nt = (TNW - t0) < TW ? (TNW - t0) : TW;
@@ -232,6 +236,7 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float1
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float r = fmaxf(v[k] + bs[k], 0.f);
+                        vmax = fmaxf(vmax, r);
                         hi[k] = (_Float16)r;
                         lo[k] = (_Float16)((r - (float)hi[k]) * 2048.0f);
                     }
@@ -278,6 +283,7 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float1
             }
         }
     }
+    tise_flag_split_overflow(vmax);
 }
 
 }  // namespace conv_epi

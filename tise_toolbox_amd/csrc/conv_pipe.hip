@@ -1,36 +1,17 @@
-// Persistent, deep-pipelined form of the split-precision convolution (conv_split.hip explains the arithmetic:
+// Persistent, wave-specialised forms of the split-precision convolution (conv_split.hip explains the arithmetic:
 // v ~= hi + lo * 2^-11, three fp16 MFMAs per product, fp32 accumulate; same operand formats, same results up
-// to fp32 summation order).
+// to fp32 summation order).  Two kernels live here:
 //
-// Why a second kernel: tools/conv_ablate.py on the 128-pixel, 2-stage kernels shows that neither the MFMAs
-// (alone 55-65 % of the launch) nor the L2->LDS DMA (alone about the same) is saturated -- every K-step waits
-// `vmcnt(0)` on a DMA issued one step earlier (~0.8 us round trip under load against ~0.6 us of MFMA work per
-// CU-step), and the epilogue (15-40 % of a launch for K <= 1000) runs with the DMA engine idle.  That is the
-// "two barriers per K-step" ceiling of cdna_hip_programming.md section 5 (~900 TF fp16; the trunk layers sit
-// at 750-1000).  This kernel follows that section's way past it:
-//   * ONE workgroup of 8 waves per CU, 256 pixels x BN couts per tile, all 160 KB of LDS: three operand stages
-//     of 32 k each, the DMA (global_load_lds_dwordx4, 1 KB pieces) running TWO K-steps ahead of the MFMAs;
-//   * a counted `s_waitcnt vmcnt(L)` (L = pieces one wave issues per stage) and a raw `s_barrier` per step:
-//     the newest stage stays in flight across the barrier, nothing in the loop ever drains the queue;
-//   * PERSISTENT: each workgroup walks tiles v = it * gridDim + slot and the DMA cursor runs ahead of the MFMA
-//     cursor ACROSS tile boundaries, so the first two stages of the next tile land while this tile's epilogue
-//     runs; the epilogue stages through the one LDS stage that is free at that moment, privately per wave
-//     (no workgroup barrier inside it);
-//   * the K loop is (tap, 32-channel block) with pointer increments only (as the "fast" kernel); Cin that is
-//     not a multiple of 32 (80, 48) is handled by zero-padded weights [tap][Cin rounded up to 32] and a per-lane
-//     channel guard on the pixel operand;
-//   * the MFMA operands are swapped (weights first): the accumulator of a lane then holds 4 CONSECUTIVE couts
-//     of one pixel per register quad, so the epilogue converts and stages with 8-byte LDS writes.
-// Ordering rules (MI355X_MICROARCH.md, "Read a staged buffer one phase AFTER the wait that retires it"):
-//   RAW  stage of step g was issued during step g-2; each wave's vmcnt(L) at the top of step g retires its own
-//        pieces of it (loads return in order; stores still in flight only make the wait longer, never shorter),
-//        the barrier that follows makes every wave's pieces visible to every reader.
-//   WAR  the DMA for step g+2 overwrites the stage read in step g-1; it is issued after the barrier of step g,
-//        which a wave reaches only after the ds_reads feeding its step g-1 MFMAs have returned.
-//   Epilogue: `vmcnt(0)` + barrier after the tile's last step (all fragment reads of the stage that becomes
-//        the staging area are done; everything issued so far has landed, so the next two steps need no wait),
-//        and the staging stage is not overwritten before the next step's barrier, which every wave reaches only
-//        after its epilogue.
+//   conv_win32_kernel   (configuration 33)  resident-weights sliding-window kernel for Cin = 32, 3x3, stride 1:
+//                       the default for Conv2d_2a (1.34 -> 1.05 ms at batch 500).
+//   conv_spec_kernel    (configurations 45-47) 256-pixel tiles, 8 compute + 4 service waves: opt-in per-layer
+//                       table TISE_CONV_AUTO=1 (5-13 % faster in isolation on the deep 1x1 layers, bit-identical;
+//                       no gain in the bench).
+//
+// Round 1 also carried a 3-stage persistent kernel (ping-pong and lockstep schedules, configurations 0-10), its
+// window-resident form (7, 11-15) and 128-pixel wave-specialised configurations (40-44).  All of them measured
+// within +-3 % of the default `fast` kernel (profiles/r01g_conv_pipe_probe.txt, r01i_conv_spec_probe.txt) and were
+// removed in round 2 together with their tests; the measurements stay in profiles/ and DESIGN.md.
 #include <hip/hip_fp16.h>
 #include "common.h"
 #include "conv_epilogue.h"
@@ -51,144 +32,14 @@ __device__ __attribute__((aligned(64))) unsigned char g_pipe_zero_page[64];
 #define CP_BK 32
 #define CP_TWAVE (conv_epi::Staging<1>::BYTES)   // staging bytes per wave (one 32 x 32 accumulator tile)
 
-// WN waves along couts, 8 / WN along pixels; a wave owns TMW x TNW accumulator tiles of 32 x 32.
-template <int WN, int TMW, int TNW, bool PP>
-__global__ __launch_bounds__(512, 1) void conv_pipe_kernel(const ConvArgs p, const int ncb, const int tiles_n,
-                                                           const long long ntiles) {
-    constexpr int WM = 8 / WN;
-    constexpr bool EPI_GRID = false;
-    static_assert(WM * TMW * 32 == CP_BM, "tile is 256 pixels");
-    constexpr int BN = 32 * TNW * WN;
-    constexpr int A_PLANE = CP_BM * 64, B_PLANE = BN * 64;
-    constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
-    constexpr int NBPIECE = BN / 8;                       // weight DMA pieces per stage (2 planes x BN/16)
-    constexpr int NBP = (NBPIECE + 7) / 8;                // per wave (surplus slots repeat a piece)
-    constexpr int L = 4 + NBP;                            // DMA pieces one wave issues per stage
-    static_assert(8 * CP_TWAVE <= STAGE, "epilogue staging must fit one stage");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave - wm * WN;
-    // slot of this workgroup in the tile order: workgroups of one XCD (blockIdx % 8) take neighbouring tiles
-    const long long G = (long long)gridDim.x;
-    long long slot = blockIdx.x;
-    {
-        const long long q = G >> 3, r = G & 7, xcd = slot & 7, idx = slot >> 3;
-        slot = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int ntaps = p.KH * p.KW;
-    const int nsteps = ntaps * ncb;                       // K-steps per tile
-    const int kstride = nsteps * CP_BK;                   // halfs per weight row
-    const long long my_tiles = slot < ntiles ? (ntiles - slot + G - 1) / G : 0;
-    const long long total = my_tiles * nsteps;            // K-steps this workgroup computes
-    if (total == 0) return;
-
-    const int cl = (lane & 3) ^ ((lane >> 4) & 3);        // logical 16-byte chunk this lane's DMA pieces fetch
-    const int cleft = p.Cin - cl * 8;                     // channel guard: block cb is real iff cb * 32 < cleft
-    const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
-    const _Float16* wgt = reinterpret_cast<const _Float16*>(p.w);
-    const _Float16* zp = reinterpret_cast<const _Float16*>(g_pipe_zero_page);
-
-    // ---- DMA cursor ---------------------------------------------------------------------------------
-    long long is_v = slot;                                // tile being fetched
-    int is_kh = 0, is_kw = 0, is_cb = 0, is_stage = 0;
-    long long issued = 0;
-    int ih0[2], iw0[2];
-    const _Float16* img[2];
-    const _Float16* pa[2];
-    bool rok[2];
-    const _Float16* pb[NBP];
-    int pb_off[NBP];
-    long long pb_row[NBP];
-#pragma unroll
-    for (int i = 0; i < NBP; ++i) {
-        const int q = (wave + 8 * i) % NBPIECE;
-        const int plane = q >= NBPIECE / 2 ? 1 : 0;
-        const int rb = q - plane * (NBPIECE / 2);
-        pb_row[i] = (plane ? p.w_plane : 0) + (long long)(rb * 16 + (lane >> 2)) * kstride + cl * 8;
-        pb_off[i] = 2 * A_PLANE + plane * B_PLANE + rb * 1024;
-    }
-#define CP_TAP()                                                                                          \
-    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                     \
-        const int ih = ih0[jj] + is_kh, iw = iw0[jj] + is_kw;                                              \
-        const bool ok = rok[jj] && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;                             \
-        pa[jj] = ok ? img[jj] + ((long long)ih * p.W + iw) * p.Cin : nullptr;                              \
-    }
-#define CP_TILE()                                                                                         \
-    {                                                                                                     \
-        const long long tm_ = is_v / tiles_n;                                                             \
-        const int tn_ = (int)(is_v - tm_ * tiles_n);                                                      \
-        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                 \
-            const long long pix = tm_ * CP_BM + (2 * wave + jj) * 16 + (lane >> 2);                       \
-            rok[jj] = pix < p.M;                                                                           \
-            const long long pp = rok[jj] ? pix : 0;                                                        \
-            const int ohw = p.OH * p.OW;                                                                   \
-            const int n = (int)(pp / ohw);                                                                 \
-            const int rem = (int)(pp - (long long)n * ohw);                                                \
-            const int oh = rem / p.OW, ow = rem - oh * p.OW;                                               \
-            ih0[jj] = oh * p.SH - p.PH;                                                                    \
-            iw0[jj] = ow * p.SW - p.PW;                                                                    \
-            img[jj] = xg + (long long)n * p.H * p.W * p.Cin + cl * 8;                                      \
-        }                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < NBP; ++i)                                                    \
-            pb[i] = wgt + (long long)tn_ * BN * kstride + pb_row[i];                                       \
-        CP_TAP()                                                                                           \
-    }
-#define CP_ISSUE()                                                                                        \
-    {                                                                                                     \
-        unsigned char* sb_ = lds + is_stage * STAGE;                                                       \
-        const bool cok = is_cb * CP_BK < cleft;                                                            \
-        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                 \
-            const _Float16* pj = pa[jj];                                                                   \
-            const bool ok = pj != nullptr && cok;                                                          \
-            const _Float16* sh = ok ? pj : zp;                                                             \
-            const _Float16* sl = ok ? pj + p.x_plane : zp;                                                 \
-            unsigned char* da_ = sb_ + (2 * wave + jj) * 1024;                                             \
-            __builtin_amdgcn_global_load_lds(sh, (lds_ptr_t)da_, 16, 0, 0);                                \
-            __builtin_amdgcn_global_load_lds(sl, (lds_ptr_t)(da_ + A_PLANE), 16, 0, 0);                    \
-            pa[jj] = pj ? pj + CP_BK : nullptr;                                                            \
-        }                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < NBP; ++i) {                                                  \
-            /* locals on purpose (array elements as direct builtin arguments make hipcc drop the host stub) */ \
-            const _Float16* sw_ = pb[i];                                                                   \
-            unsigned char* dw_ = sb_ + pb_off[i];                                                          \
-            __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)dw_, 16, 0, 0);                               \
-            pb[i] = sw_ + CP_BK;                                                                           \
-        }                                                                                                  \
-        is_stage = is_stage == 2 ? 0 : is_stage + 1;                                                       \
-        ++issued;                                                                                          \
-        if (++is_cb == ncb) {                                   /* wave-uniform: next tap / next tile */   \
-            is_cb = 0;                                                                                     \
-            if (++is_kw == p.KW) { is_kw = 0; ++is_kh; }                                                   \
-            if (is_kh == p.KH) {                                                                           \
-                is_kh = 0;                                                                                 \
-                is_v += G;                                                                                 \
-                if (issued < total) CP_TILE()                                                              \
-            } else {                                                                                       \
-                CP_TAP()                                                                                   \
-            }                                                                                              \
-        }                                                                                                  \
-    }
-
-    // ---- MFMA cursor --------------------------------------------------------------------------------
-    float16_t acc_main[TMW][TNW], acc_corr[TMW][TNW];
+// accumulator reset and one K-step of fragment reads + MFMAs; the using kernel defines acc_main / acc_corr
+// [TMW][TNW], fo0 / fo1 (swizzled fragment offsets), fa_off / fb_off, A_PLANE / B_PLANE, NGROUPS and NR2.
 #define CP_ZERO()                                                                                         \
     _Pragma("unroll") for (int i = 0; i < TMW; ++i)                                                        \
         _Pragma("unroll") for (int t = 0; t < TNW; ++t)                                                    \
             _Pragma("unroll") for (int j = 0; j < 16; ++j) { acc_main[i][t][j] = 0.f; acc_corr[i][t][j] = 0.f; }
-    CP_ZERO()
-
-    // fragment read offsets: row (lane & 31), logical chunk 2*s + (lane >> 5), swizzled with (row >> 2) & 3
-    const int fswz = ((lane & 31) >> 2) & 3;
-    const int fo0 = (lane & 31) * 64 + (((lane >> 5)) ^ fswz) * 16;
-    const int fo1 = (lane & 31) * 64 + ((2 + (lane >> 5)) ^ fswz) * 16;
-    const int fa_off = wm * TMW * 32 * 64;
-    const int fb_off = 2 * A_PLANE + wn * TNW * 32 * 64;
-
-    // One K-step: all fragment reads written first, the MFMAs after them, and a sched_group_barrier sequence
-    // that makes the scheduler emit "2 reads, 3 MFMAs" alternately after the first 4 reads.
-    constexpr int NREADS = 4 * (TMW + TNW), NGROUPS = 2 * TMW * TNW;
-    constexpr int NR2 = (NREADS - 4) / 2;
+// all fragment reads written first, the MFMAs after them, and a sched_group_barrier sequence that makes the
+// scheduler emit "2 reads, 3 MFMAs" alternately after the first 4 reads
 #define CP_COMPUTE(SB)                                                                                    \
     {                                                                                                     \
         half8_t fa_[2][TMW][2], fb_[2][TNW][2];                                                            \
@@ -218,474 +69,6 @@ __global__ __launch_bounds__(512, 1) void conv_pipe_kernel(const ConvArgs p, con
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                             \
         }                                                                                                  \
     }
-
-    // ping-pong schedule: the fragment reads of a step happen one phase before its MFMAs
-    half8_t pa_[2][TMW][2], pb_[2][TNW][2];
-#define CP_READS(SB)                                                                                      \
-    _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                        \
-        const int fo = s ? fo1 : fo0;                                                                      \
-        _Pragma("unroll") for (int i = 0; i < TMW; ++i) {                                                  \
-            const unsigned char* ap = (SB) + fa_off + i * 32 * 64 + fo;                                    \
-            pa_[s][i][0] = *reinterpret_cast<const half8_t*>(ap);                                          \
-            pa_[s][i][1] = *reinterpret_cast<const half8_t*>(ap + A_PLANE);                                \
-        }                                                                                                  \
-        _Pragma("unroll") for (int t = 0; t < TNW; ++t) {                                                  \
-            const unsigned char* bp = (SB) + fb_off + t * 32 * 64 + fo;                                    \
-            pb_[s][t][0] = *reinterpret_cast<const half8_t*>(bp);                                          \
-            pb_[s][t][1] = *reinterpret_cast<const half8_t*>(bp + B_PLANE);                                \
-        }                                                                                                  \
-    }
-#define CP_MFMAS()                                                                                        \
-    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                          \
-        _Pragma("unroll") for (int i = 0; i < TMW; ++i)                                                    \
-            _Pragma("unroll") for (int t = 0; t < TNW; ++t) {                                              \
-                acc_main[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pb_[s][t][0], pa_[s][i][0], acc_main[i][t], 0, 0, 0); \
-                acc_corr[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pb_[s][t][1], pa_[s][i][0], acc_corr[i][t], 0, 0, 0); \
-                acc_corr[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pb_[s][t][0], pa_[s][i][1], acc_corr[i][t], 0, 0, 0); \
-            }
-
-    // ---- epilogue of the tile c_v, staging through the stage at SB (private 4.5 KB per wave): conv_epilogue.h
-#define CP_EPILOGUE(SB)                                                                                   \
-    {                                                                                                     \
-        const long long tm_ = c_v / tiles_n;                                                              \
-        const int n0 = (int)(c_v - tm_ * tiles_n) * BN;                                                   \
-        const long long m0 = tm_ * CP_BM;                                                                 \
-        conv_epi::store_tiles<TMW, TNW, EPI_GRID, 1>(p, acc_main, acc_corr, (SB) + wave * CP_TWAVE,       \
-                                                     m0 + wm * TMW * 32, n0 + wn * TNW * 32);             \
-    }
-
-    // ---- pipeline -----------------------------------------------------------------------------------
-    // ablation switches for tools/conv_ablate.py (never set by the product path): 0x100 no DMA after the
-    // prologue, 0x200 no fragment reads / MFMAs, 0x400 no epilogue
-    const bool ab_dma = !(p.nseg & 0x100), ab_mma = !(p.nseg & 0x200), ab_epi = !(p.nseg & 0x400);
-    CP_TILE()
-    CP_ISSUE()
-    if (issued < total) CP_ISSUE()
-    long long c_v = slot;
-    long long landed = 0;
-    int c_step = 0, c_stage = 0;
-    // in-kernel stamps (tools/conv_stamps.py, flag 0x800): waves 0 and 4 of workgroup 0 record s_memtime at five
-    // points of each of the first 96 steps into 4 KB of LDS behind the stages; dumped to seg[3].dst at the end
-    const bool stamps = (p.nseg & 0x800) && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0;
-    unsigned* stamp_lds = reinterpret_cast<unsigned*>(lds + 3 * STAGE) + (wave >> 2) * 512;
-#define CP_STAMP(K)                                                                                       \
-    if (stamps && done < 96) {                                                                             \
-        stamp_lds[done * 5 + (K)] = (unsigned)__builtin_readcyclecounter();                                \
-        if ((K) == 0 && (done == 20 || done == 60)) /* 100 MHz wall clock: calibrates the cycle counter */ \
-            stamp_lds[480 + (done == 60)] = (unsigned)__builtin_amdgcn_s_memrealtime();                    \
-    }
-    if (!PP) {
-        for (long long done = 0; done < total; ++done) {
-            CP_STAMP(0)
-            if (done >= landed) {
-                if (issued > done + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            CP_STAMP(1)
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            CP_STAMP(2)
-            if (issued < total) {
-                if (ab_dma) CP_ISSUE() else ++issued;
-            }
-            CP_STAMP(3)
-            const unsigned char* sb = lds + c_stage * STAGE;
-            if (ab_mma) CP_COMPUTE(sb)
-            CP_STAMP(4)
-            if (++c_step == nsteps) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                landed = issued;
-                unsigned char* st = lds + c_stage * STAGE;
-                if (ab_epi || p.M < 0) CP_EPILOGUE(st)
-                CP_ZERO()
-                c_step = 0;
-                c_v += G;
-            }
-            c_stage = c_stage == 2 ? 0 : c_stage + 1;
-        }
-    } else {
-        // Ping-pong: waves 0-3 (group A) and 4-7 (group B) -- one of each per SIMD -- run the same two-phase step
-        //   P1: fragment reads of step g -> registers, DMA of step g+2, lgkmcnt(0)     P2: the step's MFMAs
-        // one barrier apart, so that on every SIMD one wave is in its MFMA phase while the other issues DMA and
-        // LDS reads (the DMA issue blocks its wave for 100-400 cycles per piece once the TA queue fills: in-kernel
-        // stamps, tools/conv_stamps.py).  Barrier #2g ends B's P2(g-1) and A's P2(g-1)+1 ... ordering:
-        //   stage g is read by A in interval 2g and by B in interval 2g+1, so every wave retires its own pieces of
-        //   stage g+1 (counted vmcnt, the newest stage stays in flight) before barrier #2g+2: A at the end of its
-        //   P2(g), B at the end of its P1(g); the DMA of step g+2 overwrites stage g-1, whose last reads (B's
-        //   P1(g-1)) returned before barrier #2g.
-        const bool grpB = wave >= 4;
-        long long done = 0;
-        if (issued > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        landed = 1;
-#define CP_CERTIFY()                                                                                      \
-        if (done + 1 < total && done + 1 >= landed) {                                                      \
-            if (issued > done + 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");                \
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
-        }
-        for (long long tile = 0; tile < my_tiles; ++tile) {
-            if (grpB) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-            for (int step = 0; step < nsteps; ++step) {
-                CP_STAMP(0)
-                const unsigned char* sb = lds + c_stage * STAGE;
-                if (ab_mma) { CP_READS(sb) }
-                if (issued < total) {
-                    if (ab_dma) CP_ISSUE() else ++issued;
-                }
-                CP_STAMP(1)
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (grpB) { CP_CERTIFY() }
-                CP_STAMP(2)
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                CP_STAMP(3)
-                __builtin_amdgcn_s_setprio(1);
-                if (ab_mma) { CP_MFMAS() }
-                __builtin_amdgcn_s_setprio(0);
-                if (!grpB) { CP_CERTIFY() }
-                CP_STAMP(4)
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                ++done;
-                c_stage = c_stage == 2 ? 0 : c_stage + 1;
-            }
-            if (!grpB) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            landed = issued;
-            unsigned char* st = lds + (c_stage == 0 ? 2 : c_stage - 1) * STAGE;
-            if (ab_epi || p.M < 0) CP_EPILOGUE(st)
-            CP_ZERO()
-            c_v += G;
-            __builtin_amdgcn_s_barrier();            // staging area free before anyone's next DMA lands in it
-            asm volatile("" ::: "memory");
-        }
-    }
-    if (stamps) {
-        unsigned* out = reinterpret_cast<unsigned*>(p.seg[3].dst) + (wave >> 2) * 512;
-        for (int i = 0; i < 482; ++i) out[i] = stamp_lds[i];
-    }
-}
-
-template <int WN, int TMW, int TNW, bool PP>
-int launch_cfg(const ConvArgs* a, hipStream_t st) {
-    constexpr int BN = 32 * TNW * WN;
-    constexpr int STAGE = 2 * CP_BM * 64 + 2 * BN * 64;
-    constexpr int LDS = 3 * STAGE + ((3 * STAGE + 4096 <= 160 * 1024) ? 4096 : 0);   // + stamp area when it fits
-    if ((a->nseg & 0x800) && LDS == 3 * STAGE) return TISE_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pipe_kernel<WN, TMW, TNW, PP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
-    const int ncb = (a->Cin + CP_BK - 1) / CP_BK;
-    const int tiles_n = (a->Cout + BN - 1) / BN;
-    const long long ntiles = ((a->M + CP_BM - 1) / CP_BM) * tiles_n;
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        TISE_HIP_CHECK(hipGetDevice(&dev));
-        TISE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const long long grid = ntiles < ncu ? ntiles : ncu;
-    hipLaunchKernelGGL((conv_pipe_kernel<WN, TMW, TNW, PP>), dim3((unsigned)grid), dim3(512), LDS, st, *a, ncb, tiles_n, ntiles);
-    TISE_LAUNCH_CHECK();
-    return TISE_OK;
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// Window form (stride-1 convolutions with more than one tap).  glds_rate (tools/microbench) puts the LDS-DMA
-// path at 30 B/clk/CU for the 16-row x 64-B pieces used here (38 for 128-B rows): a 256 x 128 x 32 step needs
-// 48 KB = ~1500 DMA cycles against 1536 MFMA cycles per SIMD, so the per-tap implicit GEMM is DMA-bound
-// whatever the schedule.  Here the 256 tile rows are consecutive pixels of the INPUT grid and a tap is a row
-// offset (kh-PH)*W + (kw-PW) into one resident WINDOW of 256 + (KH-1)*W + KW-1 grid pixels per 32-channel
-// block: the window is fetched once per channel block (double-buffered, prefetched during the previous
-// block's taps), only the weight tile (BN x 32 k, 3 stages, two steps ahead, counted vmcnt) streams per step:
-// ~22 KB instead of 48 KB per step for a 3x3 at 35^2.  Border handling as conv_split.hip's window variant:
-// valid convolutions compute the grid pixels without an output and drop them in the epilogue; padded ones
-// mask, per lane and tap, fragments whose source lies outside the image.
-// K order is (channel block, tap); weights packed [cout][tap][Cin rounded up to 32] as for the kernel above.
-template <int WN, int TMW, int TNW, bool PP>
-__global__ __launch_bounds__(512, 1) void conv_pipew_kernel(const ConvArgs p, const int ncb, const int tiles_n,
-                                                            const int R16, const int nwin) {
-    constexpr int WM = 8 / WN;
-    constexpr bool EPI_GRID = true;
-    static_assert(WM * TMW * 32 == CP_BM, "tile is 256 pixels");
-    constexpr int BN = 32 * TNW * WN;
-    constexpr int B_PLANE = BN * 64;
-    constexpr int BSTAGE = 2 * B_PLANE;
-    constexpr int NBPIECE = BN / 8;
-    constexpr int NBP = (NBPIECE + 7) / 8;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    const int win_plane = R16 * 64;
-    const int win_bytes = 2 * win_plane;
-    unsigned char* bst = lds + nwin * win_bytes;          // three weight stages behind the window buffer(s)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave - wm * WN;
-    const long long nwg = (long long)gridDim.x;
-    long long c_v = blockIdx.x;
-    {
-        const long long q = nwg >> 3, r = nwg & 7, xcd = c_v & 7, idx = c_v >> 3;
-        c_v = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const long long tile_m = c_v / tiles_n;
-    const int n0t = (int)(c_v - tile_m * tiles_n) * BN;
-    const long long m0t = tile_m * CP_BM;
-    const long long mgrid = (long long)p.N * p.H * p.W;
-    const int ntaps = p.KH * p.KW;
-    const int nsteps = ncb * ntaps;
-    const int kstride = nsteps * CP_BK;
-    const int minoff = -p.PH * p.W - p.PW;
-    const int wpieces = 2 * (R16 >> 4);                   // DMA pieces of one window (2 planes)
-    const int wpw = (wpieces + 7) >> 3;                   // per wave (surplus slots repeat a piece)
-
-    const int cl = (lane & 3) ^ ((lane >> 4) & 3);
-    const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
-    const _Float16* wgt = reinterpret_cast<const _Float16*>(p.w);
-    const _Float16* zp = reinterpret_cast<const _Float16*>(g_pipe_zero_page);
-
-    // per-lane tap validity (padded convolutions), one mask per accumulator row tile
-    unsigned tapmask[TMW];
-#pragma unroll
-    for (int i = 0; i < TMW; ++i) {
-        tapmask[i] = 0xffffffffu;
-        if (p.PH | p.PW) {
-            const long long g = m0t + (wm * TMW + i) * 32 + (lane & 31);
-            const long long hw = (long long)p.H * p.W;
-            const int rem = (int)(g % hw);
-            const int y = rem / p.W, x = rem - y * p.W;
-            unsigned m = 0u;
-            for (int kh = 0, t = 0; kh < p.KH; ++kh)
-                for (int kw = 0; kw < p.KW; ++kw, ++t) {
-                    const int yy = y + kh - p.PH, xx = x + kw - p.PW;
-                    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) m |= 1u << t;
-                }
-            tapmask[i] = m;
-        }
-    }
-
-    // weight DMA pointers (advance 32 halfs per step: K order (cb, tap) is the packed order [tap][cb] permuted,
-    // so the pointer is rebuilt from (cb, tap) each step: one multiply-add)
-    long long pb_row[NBP];
-    int pb_off[NBP];
-#pragma unroll
-    for (int i = 0; i < NBP; ++i) {
-        const int q = (wave + 8 * i) % NBPIECE;
-        const int plane = q >= NBPIECE / 2 ? 1 : 0;
-        const int rb = q - plane * (NBPIECE / 2);
-        pb_row[i] = (plane ? p.w_plane : 0) + (long long)(n0t + rb * 16 + (lane >> 2)) * kstride + cl * 8;
-        pb_off[i] = plane * B_PLANE + rb * 1024;
-    }
-#define CW_WEIGHTS(CB, TAP, SBUF)                                                                         \
-    _Pragma("unroll") for (int i = 0; i < NBP; ++i) {                                                      \
-        const _Float16* sw_ = wgt + pb_row[i] + ((TAP) * ncb + (CB)) * CP_BK;                              \
-        unsigned char* dw_ = bst + (SBUF) * BSTAGE + pb_off[i];                                            \
-        __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)dw_, 16, 0, 0);                                   \
-    }
-#define CW_WINDOW(CB, WBUF)                                                                               \
-    {                                                                                                     \
-        const int c = (CB) * CP_BK + cl * 8;                                                               \
-        const bool c_ok = c < p.Cin;                                                                       \
-        for (int k = 0; k < wpw; ++k) {                                                                    \
-            int q = wave + 8 * k;                                                                          \
-            q = q >= wpieces ? q - wpieces : q;                                                            \
-            const int plane = q >= (R16 >> 4) ? 1 : 0;                                                     \
-            const int rb = q - plane * (R16 >> 4);                                                         \
-            const long long g = m0t + minoff + rb * 16 + (lane >> 2);                                      \
-            const bool ok = c_ok && g >= 0 && g < mgrid;                                                   \
-            const _Float16* src = xg + (plane ? p.x_plane : 0) + g * p.Cin + c;                            \
-            src = ok ? src : zp;                                                                           \
-            unsigned char* dst = lds + (WBUF) * win_bytes + plane * win_plane + rb * 1024;                 \
-            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);                               \
-        }                                                                                                  \
-    }
-// wait until at most NB + EXTRA of this wave's DMA pieces are outstanding (immediate operand: dispatch on EXTRA)
-#define CW_WAIT(EXTRA)                                                                                    \
-    switch (EXTRA) {                                                                                      \
-        case 0: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP) : "memory"); break;                          \
-        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + 1) : "memory"); break;                      \
-        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + 2) : "memory"); break;                      \
-        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + 3) : "memory"); break;                      \
-        case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + 4) : "memory"); break;                      \
-        case 5: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + 5) : "memory"); break;                      \
-        case 6: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + 6) : "memory"); break;                      \
-        case 7: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + 7) : "memory"); break;                      \
-        case 8: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP + 8) : "memory"); break;                      \
-        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP) : "memory"); break;                         \
-    }
-
-    float16_t acc_main[TMW][TNW], acc_corr[TMW][TNW];
-    CP_ZERO()
-
-    const int fswz = ((lane & 31) >> 2) & 3;
-    const int fb0 = (lane & 31) * 64 + ((lane >> 5) ^ fswz) * 16;
-    const int fb1 = (lane & 31) * 64 + ((2 + (lane >> 5)) ^ fswz) * 16;
-    const int fb_off = wn * TNW * 32 * 64;
-    const int lrow0 = wm * TMW * 32 + (lane & 31) - minoff;   // window row of accumulator row tile 0 at offset 0
-    constexpr int NREADS = 4 * (TMW + TNW), NGROUPS = 2 * TMW * TNW;
-    constexpr int NR2 = (NREADS - 4) / 2;
-
-    // prologue: window of block 0, weights of steps 0 and 1
-    CW_WINDOW(0, 0)
-    CW_WEIGHTS(0, 0, 0)
-    {
-        const int t1 = ntaps > 1 ? 1 : 0, c1 = ntaps > 1 ? 0 : 1;
-        if (nsteps > 1) CW_WEIGHTS(c1, t1, 1)
-    }
-    int cb = 0, tap = 0, kh = 0, kw = 0;
-    int n_cb = ntaps > 2 ? 0 : (ntaps == 2 ? 1 : 2), n_tap = ntaps > 2 ? 2 : 0;   // (cb, tap) of step g+2
-    if (ntaps == 1) { n_cb = 2; n_tap = 0; }
-    int extra = 0;                                         // window pieces issued after the newest weights
-    int stage = 0;
-    half8_t fa_[2][TMW][2], fb_[2][TNW][2];
-// fragments of the current tap: window row = tile row + tap offset
-#define CW_READS()                                                                                        \
-    {                                                                                                     \
-        const int toff = (kh - p.PH) * p.W + (kw - p.PW);                                                  \
-        const unsigned char* wbase = lds + (nwin > 1 ? (cb & 1) : 0) * win_bytes;                          \
-        const unsigned char* bb = bst + stage * BSTAGE + fb_off;                                           \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
-            _Pragma("unroll") for (int i = 0; i < TMW; ++i) {                                              \
-                const int wrow = lrow0 + i * 32 + toff;                                                    \
-                const int ao = wrow * 64 + (((2 * s + (lane >> 5)) ^ ((wrow >> 2) & 3)) * 16);             \
-                u32x4_t ah = *reinterpret_cast<const u32x4_t*>(wbase + ao);                                \
-                u32x4_t al = *reinterpret_cast<const u32x4_t*>(wbase + win_plane + ao);                    \
-                const unsigned am = (tapmask[i] >> tap) & 1u ? 0xffffffffu : 0u;                           \
-                ah &= am; al &= am;                                                                        \
-                fa_[s][i][0] = __builtin_bit_cast(half8_t, ah);                                            \
-                fa_[s][i][1] = __builtin_bit_cast(half8_t, al);                                            \
-            }                                                                                              \
-            _Pragma("unroll") for (int t = 0; t < TNW; ++t) {                                              \
-                const unsigned char* bp = bb + t * 32 * 64 + (s ? fb1 : fb0);                              \
-                fb_[s][t][0] = *reinterpret_cast<const half8_t*>(bp);                                      \
-                fb_[s][t][1] = *reinterpret_cast<const half8_t*>(bp + B_PLANE);                            \
-            }                                                                                              \
-        }                                                                                                  \
-    }
-#define CW_MFMAS()                                                                                        \
-    _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                          \
-        _Pragma("unroll") for (int i = 0; i < TMW; ++i)                                                    \
-            _Pragma("unroll") for (int t = 0; t < TNW; ++t) {                                              \
-                acc_main[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][i][0], acc_main[i][t], 0, 0, 0); \
-                acc_corr[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][1], fa_[s][i][0], acc_corr[i][t], 0, 0, 0); \
-                acc_corr[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][i][1], acc_corr[i][t], 0, 0, 0); \
-            }
-// DMA of step g+2 (weights) and, at the first tap of a block, of the next block's window (after the weights)
-#define CW_ISSUE()                                                                                        \
-    {                                                                                                     \
-        if (step + 2 < nsteps) {                                                                           \
-            const int s2 = stage >= 1 ? stage - 1 : 2;     /* (stage + 2) % 3 */                           \
-            CW_WEIGHTS(n_cb, n_tap, s2)                                                                    \
-            if (++n_tap == ntaps) { n_tap = 0; ++n_cb; }                                                   \
-        }                                                                                                  \
-        if (tap == 0 && cb + 1 < ncb && nwin > 1) { CW_WINDOW(cb + 1, (cb + 1) & 1) }                      \
-    }
-#define CW_ADVANCE()                                                                                      \
-    stage = stage == 2 ? 0 : stage + 1;                                                                    \
-    if (++tap == ntaps) { tap = 0; kh = 0; kw = 0; ++cb; }                                                 \
-    else if (++kw == p.KW) { kw = 0; ++kh; }
-    if (!PP || nwin == 1 || ntaps < 3) {
-        for (int step = 0; step < nsteps; ++step) {
-            if (step + 1 < nsteps) { CW_WAIT(extra) } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            extra = (tap == 0 && cb + 1 < ncb && nwin > 1) ? wpw : 0;
-            CW_ISSUE()
-            CW_READS()
-            CW_MFMAS()
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-            for (int q = 0; q < NGROUPS; ++q) {
-                if (q < NR2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-            }
-            CW_ADVANCE()
-            if (tap == 0 && nwin == 1 && cb < ncb) {       // single window buffer: reload it between channel blocks
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-                CW_WINDOW(cb, 0)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-            }
-        }
-    } else {
-        // Ping-pong schedule (see conv_pipe_kernel): waves 0-3 and 4-7 one barrier apart, P1 = fragment reads +
-        // DMA issue, P2 = MFMAs.  A wave retires its pieces of the weights of step g+1 before barrier #2g+2 (group
-        // A after its P2(g), group B after its P1(g)); pieces issued after them stay in flight: the weights of
-        // step g+2 and a window issued in this or the previous step (ntaps >= 3: never both).
-        const bool grpB = wave >= 4;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBP) : "memory");      // window 0 and weights 0
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (grpB) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-        bool prev_win = false;
-        for (int step = 0; step < nsteps; ++step) {
-            const bool this_win = tap == 0 && cb + 1 < ncb;
-            CW_READS()
-            CW_ISSUE()
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const int ex = (this_win || prev_win) ? wpw : 0;
-            if (grpB && step + 1 < nsteps) {
-                if (step + 2 < nsteps) { CW_WAIT(ex) } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_setprio(1);
-            CW_MFMAS()
-            __builtin_amdgcn_s_setprio(0);
-            if (!grpB && step + 1 < nsteps) {
-                if (step + 2 < nsteps) { CW_WAIT(ex) } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            prev_win = this_win;
-            CW_ADVANCE()
-        }
-        if (!grpB) { __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    CP_EPILOGUE(lds)
-}
-
-template <int WN, int TMW, int TNW, bool PP>
-int launch_win(const ConvArgs* a, hipStream_t st) {
-    constexpr int BN = 32 * TNW * WN;
-    const int ncb = (a->Cin + CP_BK - 1) / CP_BK;
-    const int R = CP_BM + (a->KH - 1) * a->W + (a->KW - 1);
-    const int R16 = (R + 15) & ~15;
-    const size_t bst = 3 * (size_t)BN * 128;
-    int nwin = ncb > 1 ? 2 : 1;
-    if ((size_t)nwin * R16 * 128 + bst > 160 * 1024) nwin = 1;
-    size_t lds = (size_t)nwin * R16 * 128 + bst;
-    if (lds < 8 * CP_TWAVE) lds = 8 * CP_TWAVE;
-    if (lds > 160 * 1024 || a->KH * a->KW > 32 || (nwin > 1 && (2 * (R16 >> 4) + 7) / 8 > 8)) return TISE_ERR_UNSUPPORTED;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pipew_kernel<WN, TMW, TNW, PP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
-    const int tiles_n = (a->Cout + BN - 1) / BN;
-    const long long mg = (long long)a->N * a->H * a->W;
-    const long long ntiles = ((mg + CP_BM - 1) / CP_BM) * tiles_n;
-    if (ntiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((conv_pipew_kernel<WN, TMW, TNW, PP>), dim3((unsigned)ntiles), dim3(512), lds, st, *a, ncb, tiles_n, R16, nwin);
-    TISE_LAUNCH_CHECK();
-    return TISE_OK;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Resident-weights sliding-window kernel for the two 32-channel 3x3 layers of the stem (Conv2d_2a 149^2 x 32 -> 32
@@ -1166,43 +549,19 @@ int launch_spec(const ConvArgs* a, hipStream_t st) {
 
 }  // namespace
 
-// cfg: tile width / wave layout / schedule.  Ping-pong schedule: 0: 128 couts (4x2 waves of 64x64)  1: 96 (8x1 of
-// 32x96)  2: 64 (8x1 of 32x64)  4: 64 (4x2 of 64x32)  5: 32 (8x1 of 32x32).  Lockstep schedule (all waves in
-// the same phase): 8, 9, 10 = the layouts of 0, 1, 2;  3: 160 (8x1 of 32x160)  6: 128 (8x1 of 32x128).
-// Resident-weights sliding-window kernel for Cin = 32, 3x3, stride 1: 33 (32 couts per launch).
-// Wave-specialised persistent kernel (Cin % 32 == 0), 128-pixel tiles: 40 (128 couts, 2x2 compute waves), 41 (96), 42 (64),
-// 43 (128, 4x1), 44 (160).
-// Window kernel (stride 1, more than one tap): 11, 12, 13, 14 = 128, 96, 64, 32 couts (ping-pong);
-// 7, 15 = 128, 96 couts lockstep.
+// cfg 33: resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; 32 couts per launch).
+// cfg 45 / 46 / 47: wave-specialised persistent kernel (Cin % 32 == 0), 256-pixel tiles x 128 / 96 / 128 couts
+// (compute waves 4 x 2 of 64 x 64, 8 x 1 of 32 x 96, 8 x 1 of 32 x 128).
 int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream) {
     if (a->KH * a->KW * ((a->Cin + 31) / 32) < 1) return TISE_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     switch (cfg) {
-        case 0: return launch_cfg<2, 2, 2, true>(a, st);
-        case 1: return launch_cfg<1, 1, 3, true>(a, st);
-        case 2: return launch_cfg<1, 1, 2, true>(a, st);
-        case 4: return launch_cfg<2, 2, 1, true>(a, st);
-        case 5: return launch_cfg<1, 1, 1, true>(a, st);
-        case 8: return launch_cfg<2, 2, 2, false>(a, st);
-        case 9: return launch_cfg<1, 1, 3, false>(a, st);
-        case 10: return launch_cfg<1, 1, 2, false>(a, st);
-        case 3: return launch_cfg<1, 1, 5, false>(a, st);
         case 33: return launch_win32(a, st);
-        case 40: return launch_spec<2, 2, 2, 4>(a, st);       // 128 couts, compute waves 2 x 2 of 64 x 64
-        case 41: return launch_spec<1, 1, 3, 4>(a, st);       // 96 couts, compute waves 4 x 1 of 32 x 96
-        case 42: return launch_spec<1, 1, 2, 4>(a, st);       // 64
-        case 43: return launch_spec<1, 1, 4, 4>(a, st);       // 128, 4 x 1 of 32 x 128
-        case 44: return launch_spec<1, 1, 5, 4>(a, st);       // 160
-        case 45: return launch_spec<2, 2, 2, 8>(a, st);       // 256 pixels x 128 couts: 8 compute waves 4 x 2 of 64 x 64
-        case 46: return launch_spec<1, 1, 3, 8>(a, st);       // 256 x 96: 8 x 1 of 32 x 96
-        case 47: return launch_spec<1, 1, 4, 8>(a, st);       // 256 x 128: 8 x 1 of 32 x 128
-        case 7: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<2, 2, 2, false>(a, st);
-        case 15: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<1, 1, 3, false>(a, st);
-        case 11: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<2, 2, 2, true>(a, st);
-        case 12: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<1, 1, 3, true>(a, st);
-        case 13: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<1, 1, 2, true>(a, st);
-        case 14: if (a->SH != 1 || a->SW != 1) return TISE_ERR_INVALID_ARG; return launch_win<1, 1, 1, true>(a, st);
-        case 6: return launch_cfg<1, 1, 4, false>(a, st);
+        case 45: return launch_spec<2, 2, 2, 8>(a, st);
+        case 46: return launch_spec<1, 1, 3, 8>(a, st);
+        case 47: return launch_spec<1, 1, 4, 8>(a, st);
         default: return TISE_ERR_INVALID_ARG;
     }
 }
+
+TISE_DEFINE_SPLIT_FLAG_READER(tise_internal_split_flag_conv_pipe)

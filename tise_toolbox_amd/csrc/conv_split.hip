@@ -69,6 +69,7 @@ __device__ __forceinline__ void conv_split_epilogue(const ConvArgs& p, float16_t
     constexpr int NCH = BN / 8;                             // 16-byte chunks per row
     const int nseg = p.nseg & 0xff;
     _Float16 lo_keep[TN][16];
+    float vmax = 0.f;                                        // range guard of the split format (common.h)
 #pragma unroll
     for (int plane = 0; plane < 2; ++plane) {
 #pragma unroll
@@ -94,6 +95,7 @@ __device__ __forceinline__ void conv_split_epilogue(const ConvArgs& p, float16_t
                     float v = (acc_main[t][j] + acc_corr[t][j] * (1.0f / 2048.0f)) * sc;
                     if (s_mode == 0) {
                         v = fmaxf(v + bs, 0.f);
+                        vmax = fmaxf(vmax, v);
                         const _Float16 hi = (_Float16)v;
                         lo_keep[t][j] = (_Float16)((v - (float)hi) * 2048.0f);
                         *reinterpret_cast<_Float16*>(trow + r * T_PITCH) = hi;
@@ -130,6 +132,7 @@ __device__ __forceinline__ void conv_split_epilogue(const ConvArgs& p, float16_t
         }
         if (plane == 0) __syncthreads();
     }
+    tise_flag_split_overflow(vmax);
 }
 
 template <int TN>
@@ -389,254 +392,6 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Variant 3: 512 threads = 8 waves stacked along M (256 pixels x 32*TN couts per workgroup), THREE LDS
-// stages, DMA issued two K-steps ahead, one raw s_barrier per step with a counted s_waitcnt vmcnt(L) that
-// leaves the newest stage's L pieces in flight (the variant-2 structure has at most one stage of loads in
-// flight per workgroup and measured latency bound: ~48-64 KB in flight per CU against a ~1.5 us L2 round
-// trip).  Ordering (MI355X_MICROARCH "Read a staged buffer one phase AFTER the wait that retires it"):
-//   step s:  vmcnt(L) -> s_barrier -> issue DMA for step s+2 into stage (s+2)%3 -> MFMAs from stage s%3
-//   RAW: stage s%3 was issued in step s-2, retired by this wave's vmcnt before the barrier every reader passes.
-//   WAR: stage (s+2)%3 was last read in step s-1; a wave reaches the barrier of step s only after the
-//        ds_reads feeding its step s-1 MFMAs returned.
-template <int TN>
-__global__ __launch_bounds__(512) void conv_split_glds3_kernel(const ConvArgs p) {
-    constexpr int BM = 256;
-    constexpr int BN = 32 * TN;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
-    constexpr int STAGE = 2 * A_PLANE + 2 * B_PLANE;
-    constexpr int T_BYTES = BM * (BN * 2 + 16);
-    constexpr int LDS_BYTES = (3 * STAGE > T_BYTES) ? 3 * STAGE : T_BYTES;
-    constexpr int NB = (4 * TN + 7) / 8;                 // B DMA pieces per wave per stage
-    constexpr int L = 4 + NB;                            // DMA pieces per wave per stage
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (p.Cout + BN - 1) / BN;
-    const long long nwg = (long long)gridDim.x;
-    long long bid = blockIdx.x;
-    {
-        const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const long long tile_m = bid / tiles_n;
-    const int tile_n = (int)(bid - tile_m * tiles_n);
-    const long long m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
-
-    const int cl = (lane & 3) ^ ((lane >> 4) & 3);
-    const int unit = cl >> 1, sub8 = (cl & 1) * 8;
-    const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
-    const _Float16* wg = reinterpret_cast<const _Float16*>(p.w);
-    const _Float16* zp = reinterpret_cast<const _Float16*>(g_conv_zero_page);
-    int ih0[2], iw0[2];
-    long long ibase[2];
-    bool rok[2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const long long pix = m0 + (2 * wave + jj) * 16 + (lane >> 2);
-        rok[jj] = pix < p.M;
-        const long long pp = rok[jj] ? pix : 0;
-        const int ohw = p.OH * p.OW;
-        const int n = (int)(pp / ohw);
-        const int rem = (int)(pp - (long long)n * ohw);
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        ih0[jj] = oh * p.SH - p.PH;
-        iw0[jj] = ow * p.SW - p.PW;
-        ibase[jj] = (long long)n * p.H * p.W * p.Cin;
-    }
-    int a_c = unit * 16, a_kh = 0, a_kw = 0, a_k = unit * 16;
-    while (a_c >= p.Cin) { a_c -= p.Cin; if (++a_kw == p.KW) { a_kw = 0; ++a_kh; } }
-
-#define CG3_ISSUE(STEP, STAGEBASE)                                                                        \
-    {                                                                                                     \
-        _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                                                 \
-            const int ih = ih0[jj] + a_kh, iw = iw0[jj] + a_kw;                                            \
-            const bool ok = rok[jj] && a_k < p.K && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;            \
-            const _Float16* sh = xg + ibase[jj] + ((long long)ih * p.W + iw) * p.Cin + a_c + sub8;         \
-            const _Float16* sl = sh + p.x_plane;                                                           \
-            sh = ok ? sh : zp; sl = ok ? sl : zp;                                                          \
-            unsigned char* d = (STAGEBASE) + (2 * wave + jj) * 1024;                                       \
-            __builtin_amdgcn_global_load_lds(sh, (lds_ptr_t)d, 16, 0, 0);                                  \
-            __builtin_amdgcn_global_load_lds(sl, (lds_ptr_t)(d + A_PLANE), 16, 0, 0);                      \
-        }                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                   \
-            /* 4*TN pieces (2 planes x 2*TN row blocks) over 8 waves; a surplus slot repeats a piece      \
-               (same bytes to the same place) so that every wave issues exactly NB: the vmcnt count is    \
-               then wave independent */                                                                    \
-            const int q = (wave + 8 * i) % (4 * TN);                                                       \
-            const int plane = q >= 2 * TN ? 1 : 0;                                                         \
-            const int rb = q - plane * 2 * TN;                                                             \
-            const _Float16* sw = wg + (plane ? p.w_plane : 0) + (long long)(n0 + rb * 16 + (lane >> 2)) * p.Kpad + \
-                                 (STEP) * CS_BK + cl * 8;                                                  \
-            unsigned char* d = (STAGEBASE) + 2 * A_PLANE + plane * B_PLANE + rb * 1024;                    \
-            __builtin_amdgcn_global_load_lds(sw, (lds_ptr_t)d, 16, 0, 0);                                  \
-        }                                                                                                  \
-        a_k += CS_BK; a_c += CS_BK;                                                                        \
-        if (a_c >= p.Cin) { a_c -= p.Cin; if (++a_kw == p.KW) { a_kw = 0; ++a_kh; } }                      \
-        if (a_c >= p.Cin) { a_c -= p.Cin; if (++a_kw == p.KW) { a_kw = 0; ++a_kh; } }                      \
-    }
-
-    float16_t acc_main[TN], acc_corr[TN];
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { acc_main[t][j] = 0.f; acc_corr[t][j] = 0.f; }
-
-    const int nsteps = p.Kpad / CS_BK;
-    const int frow = (lane & 31) * 64;
-    const int fswz = ((lane & 31) >> 2) & 3;
-    CG3_ISSUE(0, lds)
-    if (nsteps > 1) CG3_ISSUE(1, lds + STAGE)
-    int cur_stage = 0, nxt_stage = 2;                    // stage of step s, stage that step s+2 goes to
-    for (int step = 0; step < nsteps; ++step) {
-        if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (step + 2 < nsteps) CG3_ISSUE(step + 2, lds + nxt_stage * STAGE)
-        const unsigned char* cur = lds + cur_stage * STAGE;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int choff = ((2 * s + (lane >> 5)) ^ fswz) * 16;
-            const unsigned char* ap = cur + wave * 32 * 64 + frow + choff;
-            const half8_t a_hi = *reinterpret_cast<const half8_t*>(ap);
-            const half8_t a_lo = *reinterpret_cast<const half8_t*>(ap + A_PLANE);
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const unsigned char* bp = cur + 2 * A_PLANE + t * 32 * 64 + frow + choff;
-                const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);
-                const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);
-                acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc_main[t], 0, 0, 0);
-                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc_corr[t], 0, 0, 0);
-                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc_corr[t], 0, 0, 0);
-            }
-        }
-        cur_stage = cur_stage == 2 ? 0 : cur_stage + 1;
-        nxt_stage = nxt_stage == 2 ? 0 : nxt_stage + 1;
-    }
-    __syncthreads();                                           // all fragment reads done before LDS is reused
-    conv_split_epilogue<TN, LDS_BYTES, BM>(p, acc_main, acc_corr, lds, m0, n0);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Variant 4 ("gldsb"): the LDS array of variant 2 turned out to be the busiest unit (per workgroup step:
-// 32 KB of DMA writes + 16 KB of A reads + 64 KB of B reads against 24 MFMAs per wave), so the pixel
-// operand, which every wave reads exactly once, no longer goes through LDS at all: each wave loads ITS 32
-// rows straight into MFMA-fragment registers one K-step ahead (4 x 16 B per lane, zero-filled by mask), and
-// only the weight tile -- shared by the four waves -- is staged (DMA, two stages, XOR swizzle as above).
-// LDS traffic per step drops from 112 KB to 80 KB at unchanged vector-memory traffic.
-template <int TN>
-__global__ __launch_bounds__(256, 2) void conv_split_gldsb_kernel(const ConvArgs p) {
-    constexpr int BN = 32 * TN;
-    constexpr int B_PLANE = BN * 64;
-    constexpr int STAGE = 2 * B_PLANE;
-    constexpr int T_BYTES = CS_BM * (BN * 2 + 16);
-    constexpr int LDS_BYTES = (2 * STAGE > T_BYTES) ? 2 * STAGE : T_BYTES;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (p.Cout + BN - 1) / BN;
-    const long long nwg = (long long)gridDim.x;
-    long long bid = blockIdx.x;
-    {
-        const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const long long tile_m = bid / tiles_n;
-    const int tile_n = (int)(bid - tile_m * tiles_n);
-    const long long m0 = tile_m * CS_BM;
-    const int n0 = tile_n * BN;
-
-    const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
-    const _Float16* wg = reinterpret_cast<const _Float16*>(p.w);
-    // ---- A role: this lane's pixel row, fragment chunk (lane >> 5) of both 16-channel units ----------
-    const long long pix = m0 + wave * 32 + (lane & 31);
-    const bool row_ok = pix < p.M;
-    int ih0, iw0;
-    long long ibase;
-    {
-        const long long pp = row_ok ? pix : 0;
-        const int ohw = p.OH * p.OW;
-        const int n = (int)(pp / ohw);
-        const int rem = (int)(pp - (long long)n * ohw);
-        const int oh = rem / p.OW, ow = rem - oh * p.OW;
-        ih0 = oh * p.SH - p.PH;
-        iw0 = ow * p.SW - p.PW;
-        ibase = (long long)n * p.H * p.W * p.Cin + (lane >> 5) * 8;
-    }
-    int u_c[2], u_kh[2], u_kw[2], u_k[2];               // running (c, kh, kw, k) of unit s = 0, 1
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        u_c[s] = s * 16; u_kh[s] = 0; u_kw[s] = 0; u_k[s] = s * 16;
-        while (u_c[s] >= p.Cin) { u_c[s] -= p.Cin; if (++u_kw[s] == p.KW) { u_kw[s] = 0; ++u_kh[s]; } }
-    }
-    // ---- B role (DMA): lane i -> row (i >> 2), logical chunk (i & 3) ^ ((i >> 4) & 3) ----------------
-    const int cl = (lane & 3) ^ ((lane >> 4) & 3);
-    u32x4_t an[4];                                       // next step's A fragments: [s*2 + plane]
-
-#define CB_ISSUE(STEP, STAGEBASE)                                                                         \
-    {                                                                                                     \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
-            const int ih = ih0 + u_kh[s], iw = iw0 + u_kw[s];                                              \
-            const bool ok = row_ok && u_k[s] < p.K && ih >= 0 && ih < p.H && iw >= 0 && iw < p.W;          \
-            const long long off = ok ? ibase + ((long long)ih * p.W + iw) * p.Cin + u_c[s] : 0;            \
-            const unsigned mk = ok ? 0xffffffffu : 0u;                                                     \
-            an[2 * s] = *reinterpret_cast<const u32x4_t*>(xg + off);                                       \
-            an[2 * s + 1] = *reinterpret_cast<const u32x4_t*>(xg + p.x_plane + off);                       \
-            an[2 * s] &= mk; an[2 * s + 1] &= mk;                                                          \
-            u_k[s] += CS_BK; u_c[s] += CS_BK;                                                              \
-            if (u_c[s] >= p.Cin) { u_c[s] -= p.Cin; if (++u_kw[s] == p.KW) { u_kw[s] = 0; ++u_kh[s]; } }   \
-            if (u_c[s] >= p.Cin) { u_c[s] -= p.Cin; if (++u_kw[s] == p.KW) { u_kw[s] = 0; ++u_kh[s]; } }   \
-        }                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                   \
-            const int q = wave * TN + i;                                                                   \
-            const int plane = q >= 2 * TN ? 1 : 0;                                                         \
-            const int rb = q - plane * 2 * TN;                                                             \
-            const _Float16* sw = wg + (plane ? p.w_plane : 0) + (long long)(n0 + rb * 16 + (lane >> 2)) * p.Kpad + \
-                                 (STEP) * CS_BK + cl * 8;                                                  \
-            __builtin_amdgcn_global_load_lds(sw, (lds_ptr_t)((STAGEBASE) + plane * B_PLANE + rb * 1024), 16, 0, 0); \
-        }                                                                                                  \
-    }
-
-    float16_t acc_main[TN], acc_corr[TN];
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { acc_main[t][j] = 0.f; acc_corr[t][j] = 0.f; }
-
-    const int nsteps = p.Kpad / CS_BK;
-    const int frow = (lane & 31) * 64;
-    const int fswz = ((lane & 31) >> 2) & 3;
-    CB_ISSUE(0, lds)
-    for (int step = 0; step < nsteps; ++step) {
-        const unsigned char* cur = lds + (step & 1) * STAGE;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        u32x4_t ac[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ac[q] = an[q];
-        if (step + 1 < nsteps) CB_ISSUE(step + 1, lds + ((step + 1) & 1) * STAGE)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int choff = ((2 * s + (lane >> 5)) ^ fswz) * 16;
-            const half8_t a_hi = __builtin_bit_cast(half8_t, ac[2 * s]);
-            const half8_t a_lo = __builtin_bit_cast(half8_t, ac[2 * s + 1]);
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const unsigned char* bp = cur + t * 32 * 64 + frow + choff;
-                const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);
-                const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);
-                acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc_main[t], 0, 0, 0);
-                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc_corr[t], 0, 0, 0);
-                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc_corr[t], 0, 0, 0);
-            }
-        }
-    }
-    __syncthreads();
-    conv_split_epilogue<TN, LDS_BYTES>(p, acc_main, acc_corr, lds, m0, n0);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Variant 5 ("fast", Cin % 32 == 0): variant 2 with the address arithmetic taken out of the K loop.
 // rocprofv3 counters on variant 2 (SQ_INSTS_VALU / SQ_VALU_MFMA_BUSY_CYCLES) showed ~130 vector and ~55
 // scalar instructions per wave per K-step next to 24 MFMAs: the per-step recomputation of every DMA source
@@ -851,165 +606,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     conv_epi::store_tiles_desc<TN, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, lds + EPI0, m0 + wave * 32);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Variant 6 ("win", stride-1 convolutions with more than one tap): the implicit-GEMM kernels above fetch a
-// 128-pixel x 32-channel operand tile per TAP, i.e. every input element KH*KW times (from L2, but through the
-// texture/DMA path and LDS each time) -- for the 32..96-channel layers at 147^2..35^2 that traffic, not the
-// MFMAs, sets the pace.  Here the tile rows are 128 CONSECUTIVE PIXELS OF THE INPUT GRID and the taps are
-// plain row offsets (kh-PH)*W + (kw-PW) into one resident WINDOW of 128 + (KH-1)*W + (KW-1) grid pixels per
-// 32-channel block: the window is DMA'd once, all KH*KW taps read their fragments from it (LDS row = lane row +
-// tap offset), only the weight tile streams per tap.  Input traffic drops by KH*KW / (1 + ((KH-1)W+KW-1)/128):
-// 2.7x (3x3 @147), 4.2x (3x3 @73), 5.8x (3x3 @35), 11.8x (5x5 @35), 3.9x (7x1 @17).
-// Border handling: a "valid" convolution simply computes the few grid pixels without an output (y >= OH or
-// x >= OW, 2.7 % at 149->147) and drops them in the epilogue; a padded one masks, per lane and tap, the
-// fragments whose source pixel lies outside the image (bit mask over the taps built once per lane).
-// Channel blocks beyond Cin (Cin = 80: third block half empty) read the zero page; the weights are packed
-// [tap][Cin rounded up to 32] for this kernel.
-template <int TN>
-__global__ __launch_bounds__(256, 2) void conv_split_win_kernel(const ConvArgs p, const int R16, const int ncb,
-                                                                const int nwin) {
-    constexpr int BN = 32 * TN;
-    constexpr int B_PLANE = BN * 64;
-    constexpr int BSTAGE = 2 * B_PLANE;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    const int win_plane = R16 * 64;                       // bytes per plane of one window buffer
-    const int win_bytes = 2 * win_plane;
-    unsigned char* bst = lds + nwin * win_bytes;          // two weight stages follow the window buffer(s)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_n = (p.Cout + BN - 1) / BN;
-    const long long nwg = (long long)gridDim.x;
-    long long bid = blockIdx.x;
-    {
-        const long long q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const long long tile_m = bid / tiles_n;
-    const int tile_n = (int)(bid - tile_m * tiles_n);
-    const long long m0 = tile_m * CS_BM;
-    const int n0 = tile_n * BN;
-    const long long mgrid = (long long)p.N * p.H * p.W;
-    const int ntaps = p.KH * p.KW;
-    const int cin_pad = ncb * CS_BK;
-    const int kwin = ntaps * cin_pad;                     // weight row length for this kernel
-    const int minoff = -p.PH * p.W - p.PW;
-
-    const int cl = (lane & 3) ^ ((lane >> 4) & 3);        // logical 16-byte chunk of this lane's DMA pieces
-    const _Float16* xg = reinterpret_cast<const _Float16*>(p.x);
-    const _Float16* wg = reinterpret_cast<const _Float16*>(p.w);
-    const _Float16* zp = reinterpret_cast<const _Float16*>(g_conv_zero_page);
-
-    // per-lane tap validity (padded convolutions): bit t set <=> tap t reads inside the image for this lane's pixel
-    unsigned tapmask = 0xffffffffu;
-    if (p.PH | p.PW) {
-        const long long g = m0 + wave * 32 + (lane & 31);
-        const long long hw = (long long)p.H * p.W;
-        const int rem = (int)(g % hw);
-        const int y = rem / p.W, x = rem - y * p.W;
-        tapmask = 0u;
-        for (int kh = 0, t = 0; kh < p.KH; ++kh)
-            for (int kw = 0; kw < p.KW; ++kw, ++t) {
-                const int yy = y + kh - p.PH, xx = x + kw - p.PW;
-                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) tapmask |= 1u << t;
-            }
-    }
-
-    // DMA of one window (channel block cb) into window buffer wbuf: 2 planes x R16/16 pieces over 4 waves
-#define CW_WINDOW(CB, WBUF)                                                                               \
-    {                                                                                                     \
-        const int npieces = 2 * (R16 >> 4);                                                               \
-        const int c = (CB) * CS_BK + cl * 8;                                                               \
-        const bool c_ok = c < p.Cin;                                                                       \
-        for (int q = wave; q < npieces; q += 4) {                                                          \
-            const int plane = q >= (R16 >> 4) ? 1 : 0;                                                     \
-            const int rb = q - plane * (R16 >> 4);                                                         \
-            const long long g = m0 + minoff + rb * 16 + (lane >> 2);                                       \
-            const bool ok = c_ok && g >= 0 && g < mgrid;                                                   \
-            const _Float16* src = xg + (plane ? p.x_plane : 0) + g * p.Cin + c;                            \
-            src = ok ? src : zp;                                                                           \
-            unsigned char* dst = lds + (WBUF) * win_bytes + plane * win_plane + rb * 1024;                 \
-            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);                               \
-        }                                                                                                  \
-    }
-    // DMA of the weight tile of (channel block, tap) into weight stage SBUF
-#define CW_WEIGHTS(CB, TAP, SBUF)                                                                         \
-    _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                       \
-        const int q = wave * TN + i;                                                                       \
-        const int plane = q >= 2 * TN ? 1 : 0;                                                             \
-        const int rb = q - plane * 2 * TN;                                                                 \
-        const _Float16* sw_ = wg + (plane ? p.w_plane : 0) + (long long)(n0 + rb * 16 + (lane >> 2)) * kwin + \
-                              (TAP) * cin_pad + (CB) * CS_BK + cl * 8;                                     \
-        unsigned char* dw_ = bst + (SBUF) * BSTAGE + plane * B_PLANE + rb * 1024;                          \
-        __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)dw_, 16, 0, 0);                                   \
-    }
-
-    float16_t acc_main[TN], acc_corr[TN];
-#pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { acc_main[t][j] = 0.f; acc_corr[t][j] = 0.f; }
-
-    const int lrow = wave * 32 + (lane & 31);             // this lane's tile row
-    const int fswz = ((lane & 31) >> 2) & 3;              // swizzle of the (row-aligned) weight tile
-    const int fb0 = (lane & 31) * 64 + ((lane >> 5) ^ fswz) * 16;
-    const int fb1 = (lane & 31) * 64 + ((2 + (lane >> 5)) ^ fswz) * 16;
-
-    CW_WINDOW(0, 0)
-    CW_WEIGHTS(0, 0, 0)
-    int cb = 0, tap = 0, kh = 0, kw = 0;
-    const int nsteps = ncb * ntaps;
-    for (int step = 0; step < nsteps; ++step) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (nwin == 1 && tap == 0 && cb > 0) {            // single window buffer: reload it between channel blocks
-            CW_WINDOW(cb, 0)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
-        // prefetch: next weight tile; at the first tap of a block also the next block's window
-        if (step + 1 < nsteps) {
-            const int ntap = tap + 1 == ntaps ? 0 : tap + 1;
-            const int ncbb = tap + 1 == ntaps ? cb + 1 : cb;
-            if ((step + 1) & 1) { CW_WEIGHTS(ncbb, ntap, 1) } else { CW_WEIGHTS(ncbb, ntap, 0) }
-        }
-        if (nwin > 1 && tap == 0 && cb + 1 < ncb) CW_WINDOW(cb + 1, (cb + 1) & 1)
-        // fragments of this tap: window row = tile row + tap offset
-        const int wrow = lrow + (kh - p.PH) * p.W + (kw - p.PW) - minoff;
-        const int aswz = (wrow >> 2) & 3;
-        const unsigned char* wb = lds + (nwin > 1 ? (cb & 1) : 0) * win_bytes + wrow * 64;
-        const unsigned char* bb = bst + (step & 1) * BSTAGE;
-        const unsigned am = (tapmask >> tap) & 1u ? 0xffffffffu : 0u;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int ao = ((2 * s + (lane >> 5)) ^ aswz) * 16;
-            u32x4_t ah = *reinterpret_cast<const u32x4_t*>(wb + ao);
-            u32x4_t al = *reinterpret_cast<const u32x4_t*>(wb + win_plane + ao);
-            ah &= am; al &= am;
-            const half8_t a_hi = __builtin_bit_cast(half8_t, ah);
-            const half8_t a_lo = __builtin_bit_cast(half8_t, al);
-            const int fo = s ? fb1 : fb0;
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const unsigned char* bp = bb + t * 32 * 64 + fo;
-                const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);
-                const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);
-                acc_main[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_hi, acc_main[t], 0, 0, 0);
-                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_hi, b_lo, acc_corr[t], 0, 0, 0);
-                acc_corr[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_lo, b_hi, acc_corr[t], 0, 0, 0);
-            }
-        }
-        if (++tap == ntaps) { tap = 0; kh = 0; kw = 0; ++cb; }
-        else if (++kw == p.KW) { kw = 0; ++kh; }
-    }
-    __syncthreads();
-    conv_split_epilogue<TN, (1 << 30), CS_BM, true>(p, acc_main, acc_corr, lds, m0, n0);
-}
 
 int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream);   // conv_pipe.hip
 
 extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     if (!args || !args->x || !args->w || !args->scale || !args->bias || (args->nseg & 0xff) < 1 || (args->nseg & 0xff) > 4 ||
-        args->Cin % 16 != 0 || args->Cin < 32 || (args->Kpad % CS_BK != 0 && !(tn & (256 | 512))) || args->M <= 0)
+        args->Cin % 16 != 0 || args->Cin < 32 || (args->Kpad % CS_BK != 0 && !(tn & 512)) || args->M <= 0)
         return TISE_ERR_INVALID_ARG;
     // the epilogues work on 8-cout chunks and 16-byte stores: segments must start on multiples of 8 couts and land
     // on 16-byte boundaries (fp16 planes: 8 elements, fp32: 4 elements)
@@ -1022,47 +624,13 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     }
     if (args->seg[0].c0 != 0) return TISE_ERR_INVALID_ARG;
     if (tn & 512) return tise_conv_pipe_launch(args, tn & 255, stream);   // persistent 3-stage kernel, weights [tap][Cin_pad]
-    const bool glds = (tn & (16 | 128)) != 0, glds3 = (tn & 32) != 0, gldsb = (tn & 64) != 0;
+    const bool glds = (tn & (16 | 128)) != 0;
     // fast path: K order (tap, full 32-channel block) then paired 16-channel tails (see the kernel); Kpad says which
     const int fast_kpad = (args->KH * args->KW * (args->Cin / 32) + ((args->Cin & 16) ? (args->KH * args->KW + 1) / 2 : 0)) * 32;
     const bool fast = (tn & 128) != 0 && args->Cin % 16 == 0 && args->Kpad == fast_kpad && args->M < 0x7fffff00LL;
-    if (tn & 256) {                                    // window kernel: stride 1, weights packed [tap][Cin_pad]
-        const int t = tn & 15;
-        if (args->SH != 1 || args->SW != 1 || args->KH * args->KW > 32 || t < 1 || t > 5) return TISE_ERR_INVALID_ARG;
-        const int ncb = (args->Cin + 31) / 32;
-        const int R = CS_BM + (args->KH - 1) * args->W + (args->KW - 1);
-        const int R16 = (R + 15) & ~15;
-        const int bnw = 32 * t;
-        // two window buffers (prefetch the next channel block) only while two workgroups still fit a CU
-        const int nwin = (ncb > 1 && 2 * (size_t)R16 * 128 + 2 * (size_t)bnw * 128 <= 80 * 1024) ? 2 : 1;
-        size_t lds = (size_t)nwin * R16 * 128 + 2 * (size_t)bnw * 128;
-        const size_t tb = (size_t)CS_BM * (bnw * 2 + 16);
-        if (lds < tb) lds = tb;
-        if (lds > 160 * 1024) return TISE_ERR_UNSUPPORTED;
-        const long long mg = (long long)args->N * args->H * args->W;
-        const long long tl = ((mg + CS_BM - 1) / CS_BM) * ((args->Cout + bnw - 1) / bnw);
-        if (tl > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
-        hipStream_t stw = (hipStream_t)stream;
-#define CW_LAUNCH(T)                                                                                          \
-        {                                                                                                     \
-            if (lds > 48 * 1024)                                                                              \
-                TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_win_kernel<T>),    \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
-            hipLaunchKernelGGL(conv_split_win_kernel<T>, dim3((unsigned)tl), dim3(256), lds, stw, *args, R16, ncb, nwin); \
-        }
-        switch (t) {
-            case 1: CW_LAUNCH(1) break;
-            case 2: CW_LAUNCH(2) break;
-            case 3: CW_LAUNCH(3) break;
-            case 4: CW_LAUNCH(4) break;
-            default: CW_LAUNCH(5) break;
-        }
-        TISE_LAUNCH_CHECK();
-        return TISE_OK;
-    }
     tn &= 15;
     const int bn = 32 * tn;
-    const int bm = glds3 ? 256 : CS_BM;
+    const int bm = CS_BM;
     const long long tiles = ((args->M + bm - 1) / bm) * ((args->Cout + bn - 1) / bn);
     if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)tiles), block(256);
@@ -1074,29 +642,6 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
             case 3: hipLaunchKernelGGL(conv_split_fast_kernel<3>, grid, block, 0, st, *args); break;
             case 4: hipLaunchKernelGGL(conv_split_fast_kernel<4>, grid, block, 0, st, *args); break;
             case 5: hipLaunchKernelGGL(conv_split_fast_kernel<5>, grid, block, 0, st, *args); break;
-            default: return TISE_ERR_INVALID_ARG;
-        }
-        TISE_LAUNCH_CHECK();
-        return TISE_OK;
-    }
-    if (gldsb) {
-        switch (tn) {
-            case 2: hipLaunchKernelGGL(conv_split_gldsb_kernel<2>, grid, block, 0, st, *args); break;
-            case 3: hipLaunchKernelGGL(conv_split_gldsb_kernel<3>, grid, block, 0, st, *args); break;
-            case 4: hipLaunchKernelGGL(conv_split_gldsb_kernel<4>, grid, block, 0, st, *args); break;
-            case 5: hipLaunchKernelGGL(conv_split_gldsb_kernel<5>, grid, block, 0, st, *args); break;
-            default: return TISE_ERR_INVALID_ARG;
-        }
-        TISE_LAUNCH_CHECK();
-        return TISE_OK;
-    }
-    if (glds3) {
-        const dim3 block512(512);
-        switch (tn) {
-            case 2: hipLaunchKernelGGL(conv_split_glds3_kernel<2>, grid, block512, 0, st, *args); break;
-            case 3: hipLaunchKernelGGL(conv_split_glds3_kernel<3>, grid, block512, 0, st, *args); break;
-            case 4: hipLaunchKernelGGL(conv_split_glds3_kernel<4>, grid, block512, 0, st, *args); break;
-            case 5: hipLaunchKernelGGL(conv_split_glds3_kernel<5>, grid, block512, 0, st, *args); break;
             default: return TISE_ERR_INVALID_ARG;
         }
         TISE_LAUNCH_CHECK();
@@ -1124,3 +669,5 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
+
+TISE_DEFINE_SPLIT_FLAG_READER(tise_internal_split_flag_conv_split)

@@ -107,6 +107,7 @@ typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void split_store4(float4 v, _Float16* hi_p, _Float16* lo_p) {
+    tise_flag_split_overflow(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
     half4v h, l;
     h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
     l[0] = (_Float16)((v.x - (float)h[0]) * 2048.f); l[1] = (_Float16)((v.y - (float)h[1]) * 2048.f);
@@ -239,12 +240,15 @@ __global__ __launch_bounds__(256) void stem_conv3x3s2_split_kernel(const float* 
             }
         }
         half8v h, l;
+        float vmax = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float v = fmaxf(acc[c] + bias[cg + c], 0.f);
+            vmax = fmaxf(vmax, v);
             h[c] = (_Float16)v;
             l[c] = (_Float16)((v - (float)h[c]) * 2048.f);
         }
+        tise_flag_split_overflow(vmax);
         _Float16* d = out + p * 32 + cg;
         *reinterpret_cast<half8v*>(d) = h;
         *reinterpret_cast<half8v*>(d + out_plane) = l;
@@ -286,12 +290,15 @@ __global__ __launch_bounds__(256) void stem_conv3x3s2_split_u8_kernel(const uint
             }
         }
         half8v h, l;
+        float vmax = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float v = fmaxf(acc[c] + bias[cg + c], 0.f);
+            vmax = fmaxf(vmax, v);
             h[c] = (_Float16)v;
             l[c] = (_Float16)((v - (float)h[c]) * 2048.f);
         }
+        tise_flag_split_overflow(vmax);
         _Float16* d = out + p * 32 + cg;
         *reinterpret_cast<half8v*>(d) = h;
         *reinterpret_cast<half8v*>(d + out_plane) = l;
@@ -450,3 +457,5 @@ int tise_split_mean_nhwc(const void* x_dev, int64_t x_plane, int n, int hw, int 
 }
 
 }  // extern "C"
+
+TISE_DEFINE_SPLIT_FLAG_READER(tise_internal_split_flag_trunk_ops)

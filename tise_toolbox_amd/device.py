@@ -104,6 +104,25 @@ def resize_u8_only(src_u8, out_hw=(299, 299), out=None):
     return u8
 
 
+def read_split_overflow():
+    """Read-and-clear the range guard of the split-fp16 activation format (csrc/common.h): True when any kernel
+    since the last read converted a value above the fp16 range (65504) or a NaN into split planes.  Synchronises
+    the current stream."""
+    flag = ctypes.c_int(0)
+    _lib.call("tise_split_overflow_check", ctypes.byref(flag), _stream())
+    return bool(flag.value)
+
+
+def check_split_overflow(what="InceptionV3 trunk", flag=None):
+    """Raise when the range guard fired: the hi plane would hold +inf and every later layer would be silently wrong."""
+    if flag is None:
+        flag = read_split_overflow()
+    if flag:
+        raise FloatingPointError(
+            f"{what}: an activation exceeded the fp16 range of the split-precision format (|v| > 65504) or was NaN; "
+            "run with TISE_CONV=miopen (fp32 convolutions) for these weights / inputs")
+
+
 class StatsAccumulator:
     """fp64 running {n, sum x, sum x x^T} on the device (tise_stats_* in include/tise_hip.h)."""
 

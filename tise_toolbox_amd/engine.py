@@ -226,11 +226,24 @@ class RealismEngine:
         if self.is_acc is not None:
             tdist.all_reduce_sum_(self.is_acc.acc)
 
+    def check_numerics(self, collective=True):
+        """Raise if the split-fp16 trunk met a value outside its range since the last check (device.check_split_overflow).
+        ``collective``: under torchrun all ranks agree on the flag first (call it from every rank)."""
+        from .trunk import SplitTrunk
+        if isinstance(self.fused, SplitTrunk):
+            flag = device.read_split_overflow()
+            if collective and tdist.world_size() > 1:                   # every rank must raise, or the others hang in the next collective
+                t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=self.device)
+                flag = bool(tdist.all_reduce_sum_(t).item() > 0)
+            device.check_split_overflow(flag=flag)
+
     def statistics(self):
         """(mu, sigma) fp64 CUDA tensors of everything accumulated (after reduce())."""
+        self.check_numerics()
         return self.stats.finalize()
 
     def inception_score(self):
+        self.check_numerics()
         mean, std, _ = self.is_acc.finalize()
         return mean, std
 

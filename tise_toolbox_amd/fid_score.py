@@ -127,6 +127,7 @@ def get_activations(images, model, batch_size=64, dims=2048, cuda=True, verbose=
         pred_dev[start:end] = _forward_batch(engine, model, batch).reshape(batch_size, -1)   # :113
     if verbose:
         print(" done")                                    # :116
+    engine.check_numerics(collective=False)               # split-fp16 range guard (no silent inf / NaN features)
     return pred_dev.cpu().numpy().astype(np.float64)      # :98 pred_arr is float64
 
 
@@ -192,6 +193,7 @@ def calculate_activation_statistics(images, model, batch_size=64, dims=2048, cud
         if i >= n_batches:
             break
         stats.update(_forward_batch(engine, model, batch))
+    engine.check_numerics()                               # split-fp16 range guard (no silent inf / NaN features)
     tdist.all_reduce_sum_(stats.buffer())
     if tdist.world_size() > 1 and stats.count() == 0:     # identical on every rank (read after the all-reduce)
         raise ZeroDivisionError("no complete batch in the image set (global N < batch size)")

@@ -90,6 +90,7 @@ def inception_score(imgs, cuda=True, batch_size=32, resize=False, splits=1, weig
             feats, logits = eng._trunk(x.contiguous(memory_format=torch.channels_last), prenormalized=True)
         eng.is_acc.update(logits, base)
         base += logits.shape[0]
+    eng.check_numerics()                                                      # split-fp16 range guard
     tdist.all_reduce_sum_(eng.is_acc.acc)
     mean, std, _ = eng.is_acc.finalize()
     return np.float64(mean), np.float64(std)
