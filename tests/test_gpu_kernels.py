@@ -619,6 +619,9 @@ def test_conv_split_dynamic_range_and_heavy_tails_vs_fp64(dev, case):
     chan = torch.exp(torch.empty(Cout).uniform_(float(np.log(1e-4)), 0.0, generator=g))    # per-channel scale, 4 decades
     w = (t * chan.view(-1, 1, 1, 1) / (Cin * kh * kw) ** 0.5).to(dev)
     b = (torch.randn(Cout, generator=g) * chan).to(dev)
+    # the OUTPUT is the next layer's activation: bring its maximum to 3e4 as well (inside the fp16 range)
+    peak = torch.relu(torch.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), 1, pad)).max().item()
+    w, b = w * (3e4 / peak), b * (3e4 / peak)
     device.read_split_overflow()
     conv = SplitConv(w, b, (1, 1), pad, dev)
     oh, ow = conv.out_hw(H, W)
@@ -661,7 +664,7 @@ def test_split_overflow_guard_fires_and_clears(dev):
     conv(split(x), [(0, 64, out, 0, 0)])                       # 32 * 300 = 9 600: fine
     assert not device.read_split_overflow() and float(merge(out).max()) == 9600.0
     conv(split(x * 8), [(0, 64, out, 0, 0)])                   # 76 800 > 65 504
-    assert torch.isinf(merge(out)).any()
+    assert not torch.isfinite(merge(out)).all()                # hi = +inf, lo = -inf: the planes merge to NaN
     assert device.read_split_overflow()
     assert not device.read_split_overflow()                    # read-and-clear
     with pytest.raises(FloatingPointError, match="fp16 range"):
@@ -697,7 +700,9 @@ def test_split_trunk_with_uncalibrated_checkpoint_matches_fp32_trunk(dev, tmp_pa
     sd = net.state_dict()
     for k in sd:
         if k.endswith("bn.weight") or k.endswith("bn.bias"):
-            sd[k] = sd[k] * torch.exp(0.7 * torch.randn(sd[k].shape, generator=g))
+            # exp(s z - s^2): E[f^2] = 1, so the layer-to-layer signal power is preserved on average while single
+            # channels run 0.1x .. 4x their calibrated scale
+            sd[k] = sd[k] * torch.exp(0.7 * torch.randn(sd[k].shape, generator=g) - 0.49)
     path = tmp_path / "perturbed_inception.pth"
     torch.save(sd, path)
     imgs = torch.from_numpy(_cases.smooth_images(12, 256, 256, seed=8)).to(dev)

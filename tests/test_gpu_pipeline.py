@@ -178,7 +178,7 @@ def test_cli_end_to_end(setup, tmp_path, capsys):
     np.testing.assert_allclose(g2["sigma"], sig_d, rtol=0, atol=1e-12 * np.abs(sig_d).max())
     # and the saved file feeds the .npz branch
     v3 = fid_score.main(["--batch-size", "5", "--path1", str(so), "--path2", str(gdir), "--num-workers", "0", "--synthetic-weights"])
-    assert abs(v3) <= 1e-6
+    assert abs(v3) <= 1e-4                               # FID(X, X) on rank-20 covariances: rounding of the zero eigenvalues
     with pytest.raises(SystemExit):
         fid_score.main(["--path2", str(gdir), "--synthetic-weights"])                       # neither --path1 nor --save-stats
 
