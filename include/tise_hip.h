@@ -208,8 +208,10 @@ int tise_split_mean_nhwc(const void* x_dev, int64_t x_plane, int n, int hw, int 
  * img_emb: (n, d); txt_emb: a table of DISTINCT caption embeddings (rows, d); txt_index: (n, c) int32 rows of
  * that table, candidate 0 = the true caption (NULL: item i's candidates are table rows i*c .. i*c+c-1).
  * dtype 0 = fp32, 1 = fp16 embeddings; normalize != 0 divides by both norms (cosine), 0 takes the dot product
- * of already normalised features as CLIP.forward does.  top1_out[i] = first argmax_j of
- * logit_scale * <img_i, txt_j>; p0_out (nullable) = softmax over the c candidates, entry 0.
+ * of already normalised features as CLIP.forward does.  Every intermediate CLIP.forward stores (normalised and
+ * scaled image features, logits) and the softmax output are rounded to the embeddings' dtype, fp32 arithmetic
+ * inside, as torch does for the fp16 model clip.load serves on a GPU: top1_out[i] = FIRST maximum of the rounded
+ * softmax (np.argmax of the reference: near-ties go to candidate 0), p0_out (nullable) = its entry 0.  c <= 1024.
  * ------------------------------------------------------------------------------------------ */
 int tise_cosine_top1(const void* img_emb_dev, const void* txt_emb_dev, const int32_t* txt_index_dev, int64_t n, int c,
                      int d, int dtype, int normalize, float logit_scale, int32_t* top1_out_dev, float* p0_out_dev,

@@ -28,6 +28,27 @@ def clip_logits(img_emb, txt_emb, logit_scale=100.0, normalize=True):
     return logit_scale * (t @ a)
 
 
+def clip_forward_probs(img_emb, txt_emb, logit_scale=100.0, normalize=True, dtype=np.float16):
+    """What the reference scripts compare (RP_coco.py:72-78, PA.py:37-42): CLIP.forward's
+    `logit_scale * image_features @ text_features.t()` (third-party `clip` @ git master, model.py; Python evaluates it
+    as (logit_scale * image_features) @ text_features.t()) followed by `.softmax(dim=-1).cpu().numpy()[0]`, with every
+    stored tensor in the model's dtype -- fp16 for the model clip.load serves on a GPU, fp32 on the CPU path -- and
+    fp32 arithmetic inside each op (torch's opmath for half tensors; accumulation order of the GEMM unspecified:
+    float64 here).  Returns the probabilities as `dtype`: np.argmax of them is the first maximum of ROUNDED values."""
+    a = np.asarray(img_emb, dtype=dtype)
+    t = np.asarray(txt_emb, dtype=dtype)
+    if normalize:                                           # x / x.norm(dim=1, keepdim=True) in the model's dtype
+        na = np.sqrt((a.astype(np.float64) ** 2).sum()).astype(np.float32).astype(dtype)             # the norm is a tensor too
+        nt = np.sqrt((t.astype(np.float64) ** 2).sum(-1, keepdims=True)).astype(np.float32).astype(dtype)
+        a = (a.astype(np.float32) / na.astype(np.float32)).astype(dtype)
+        t = (t.astype(np.float32) / nt.astype(np.float32)).astype(dtype)
+    a = (np.float32(logit_scale) * a.astype(np.float32)).astype(dtype)
+    logits = (t.astype(np.float64) @ a.astype(np.float64)).astype(np.float32).astype(dtype)
+    z = logits.astype(np.float64) - float(logits.max())
+    e = np.exp(z)
+    return (e / e.sum()).astype(np.float32).astype(dtype)
+
+
 def softmax(x):
     x = np.asarray(x, dtype=np.float64)
     e = np.exp(x - x.max())

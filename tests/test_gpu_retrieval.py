@@ -13,16 +13,18 @@ from oracle import rp_oracle
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_top1(img, txt, index, normalize, scale):
+def _oracle_top1(img, txt, index, normalize, scale, dtype):
+    """rp_oracle.clip_forward_probs per item: probabilities rounded as CLIP.forward + softmax round them."""
     n = img.shape[0]
     top1, p0, margin = np.zeros(n, np.int64), np.zeros(n), np.zeros(n)
     for i in range(n):
         cand = txt[index[i]] if index is not None else txt[i * (txt.shape[0] // n):(i + 1) * (txt.shape[0] // n)]
-        lg = rp_oracle.clip_logits(img[i], cand, scale, normalize)
-        top1[i] = int(np.argmax(lg))
-        p0[i] = rp_oracle.softmax(lg)[0]
-        s = np.sort(lg)
-        margin[i] = s[-1] - s[-2] if len(s) > 1 else np.inf
+        pr = rp_oracle.clip_forward_probs(img[i], cand, scale, normalize, dtype)
+        top1[i] = int(np.argmax(pr))
+        p0[i] = float(pr[0])
+        lg = rp_oracle.clip_logits(img[i].astype(np.float64), cand.astype(np.float64), scale, normalize)
+        sl = np.sort(lg)
+        margin[i] = sl[-1] - sl[-2] if len(sl) > 1 else np.inf
     return top1, p0, margin
 
 
@@ -50,14 +52,17 @@ def test_cosine_top1_matches_fp64_oracle(cuda_device, dtype, d, c, use_index, no
     tt = torch.from_numpy(txt).to(cuda_device).to(dtype)
     tidx = torch.from_numpy(index).to(cuda_device) if index is not None else None
     top1, p0 = device.cosine_top1(ti, tt, tidx, normalize=normalize, logit_scale=100.0)
-    # the oracle sees exactly the values the kernel sees (the fp16 rounding is part of the input, not of the kernel)
-    want1, wantp, margin = _oracle_top1(ti.float().cpu().numpy().astype(np.float64), tt.float().cpu().numpy().astype(np.float64),
-                                        index, normalize, 100.0)
+    # the oracle sees exactly the values the kernel sees and rounds like CLIP.forward (fp16 model / fp32 model)
+    npdt = np.float16 if dtype == torch.float16 else np.float32
+    want1, wantp, margin = _oracle_top1(ti.cpu().numpy(), tt.cpu().numpy(), index, normalize, 100.0, npdt)
     got1 = top1.cpu().numpy()
     bad = got1 != want1
-    assert not np.any(bad & (margin > 1e-4)), (int(bad.sum()), margin[bad][:5])     # index work: exact away from ties
-    assert bad.sum() <= 2
-    assert np.abs(p0.cpu().numpy() - wantp).max() <= 2e-5
+    # index work: exact, except where the GEMM's accumulation order decides a rounding (one ulp of the logit dtype)
+    ulp = 0.07 if dtype == torch.float16 else 1e-4
+    assert not np.any(bad & (margin > ulp)), (int(bad.sum()), margin[bad][:5])
+    assert bad.sum() <= (12 if dtype == torch.float16 else 2), int(bad.sum())
+    perr = np.abs(p0.cpu().numpy() - wantp)
+    assert np.quantile(perr, 0.99) <= (2e-3 if dtype == torch.float16 else 2e-6) and perr.max() <= (0.05 if dtype == torch.float16 else 2e-5)
     again, _ = device.cosine_top1(ti, tt, tidx, normalize=normalize, logit_scale=100.0)
     assert torch.equal(again, top1)
     if c > 1 and use_index:
@@ -136,3 +141,103 @@ def test_rp_cli_end_to_end_with_stand_in_towers(cuda_device, tmp_path):
     if min(margins) > 1e-3:
         m2, s2, _ = rp_oracle.rp_score(success, RP_coco.shuffled_ids(len(items), 4))
         assert (m2, s2) == (mean, std)
+
+
+def test_fp16_near_ties_resolve_like_clip_forward(cuda_device):
+    """with the fp16 model the reference compares fp16 softmax outputs and np.argmax takes the FIRST
+    maximum, so a distractor whose logit exceeds the true caption's by less than the fp16 rounding still loses.
+    Constructed items: img = e0; true caption = cos t, distractor j = cos(t) + delta_j with |delta| from far below to
+    far above the fp16 spacing of logits near 30 (0.0156 at scale 100)."""
+    from tise_toolbox_amd import device
+    d, c = 512, 8
+    deltas = np.array([0.0, 1e-6, 3e-5, 6e-5, 1e-4, 3e-4, 1e-3, 3e-3])       # cosine differences (x100 = logit differences)
+    n = len(deltas)
+    img = np.zeros((n, d), np.float32); img[:, 0] = 1.0
+    txt = np.zeros((n * c, d), np.float32)
+    for i, dl in enumerate(deltas):
+        base = 0.3
+        for j in range(c):
+            cos = base if j == 0 else (base + dl if j == 3 else base - 0.05 * j)
+            txt[i * c + j, 0] = cos
+            txt[i * c + j, 1] = np.sqrt(1.0 - cos * cos)
+    ti = torch.from_numpy(img).to(cuda_device).half()
+    tt = torch.from_numpy(txt).to(cuda_device).half()
+    top1, p0 = device.cosine_top1(ti, tt, None, normalize=False, logit_scale=100.0)
+    want = [int(np.argmax(rp_oracle.clip_forward_probs(ti[i].cpu().numpy(), tt[i * c:(i + 1) * c].cpu().numpy(), 100.0, False, np.float16)))
+            for i in range(n)]
+    assert top1.cpu().tolist() == want
+    assert want[0] == 0 and want[1] == 0 and want[-1] == 3                   # ties go to index 0; a clear margin does not
+    exact = [int(np.argmax(rp_oracle.clip_logits(ti[i].float().cpu().numpy(), tt[i * c:(i + 1) * c].float().cpu().numpy(), 100.0, False)))
+             for i in range(n)]
+    assert exact != want                                                       # fp64 logits WOULD flip some of them
+
+
+def _pa_fixture(tmp_path, n_per_phrase=(7, 5, 9)):
+    from PIL import Image
+    rng = np.random.default_rng(2)
+    phrases = ["on top of", "under", "left of"]
+    data = {}
+    for p, n in zip(phrases, n_per_phrase):
+        (tmp_path / "images" / p).mkdir(parents=True)
+        data[p] = []
+        for i in range(n):
+            cid = 30 + i
+            data[p].append({"caption_id": cid, "caption": f"a cup {p} a table {i}", "false_caption": f"a table {p} a cup {i}"})
+            Image.fromarray(rng.integers(0, 256, (50, 70, 3), dtype=np.uint8)).save(tmp_path / "images" / p / f"{cid}.png")
+    pkl = tmp_path / "pa.pkl"
+    pickle.dump(data, open(pkl, "wb"))
+    return data, pkl
+
+
+def test_pa_cli_end_to_end_and_two_ranks(cuda_device, tmp_path):
+    """PA.py drop-in (positional_alignment/PA.py): pickle + image_dir/<phrase>/<id>.png -> `PA = value`; the value is
+    the oracle's on the same embeddings (fp16 CLIP.forward rounding), and a 2-rank run (items sharded, per-phrase
+    {success, total} all-reduced) writes the same text."""
+    from tise_toolbox_amd import PA, clip_model
+    from tise_toolbox_amd.weights import SYNTHETIC_TAG
+    from tests.test_gpu_pipeline import _run_ranks
+    data, pkl = _pa_fixture(tmp_path)
+    out = tmp_path / "pa.txt"
+    argv = ["--image_dir", str(tmp_path / "images"), "--pa_input_file", str(pkl), "--saved_file_path", str(out),
+            "--gpu_id", "0", "--synthetic-weights", "--batch-size", "4"]
+    val = PA.main(argv)
+    assert out.read_text() == f"PA = {val}" + SYNTHETIC_TAG
+    model = clip_model.build_clip().to(cuda_device).half()
+    scale = float(model.logit_scale.detach().exp())
+    scores = []
+    for p, items in data.items():
+        caps = [c for it in items for c in (it["caption"], it["false_caption"])]
+        from tise_toolbox_amd.RP_coco import embed_texts
+        txt = embed_texts(model, clip_model.HashTokenizer(), caps, cuda_device, 8).cpu().numpy()
+        img = PA._embed_paths(model, [str(tmp_path / "images" / p / f"{it['caption_id']}.png") for it in items], cuda_device, 8, workers=0).cpu().numpy()
+        ok = [float(rp_oracle.clip_forward_probs(img[i], txt[2 * i:2 * i + 2], scale, False, np.float16)[0] > 0.6) for i in range(len(items))]
+        scores.append(sum(ok) / len(ok))
+    assert abs(val - float(np.mean(scores))) <= 1e-12
+    out2 = tmp_path / "pa2.txt"
+    res = _run_ranks(2, argv[:5] + [str(out2)] + argv[6:], tmp_path, module="tise_toolbox_amd.PA")
+    assert all(rc == 0 for rc, _ in res), res
+    assert out2.read_text() == out.read_text()
+    with pytest.raises(RuntimeError, match="no parameters for CLIP"):
+        PA.main(argv[:-3])
+
+
+def test_rp_cli_two_ranks_equals_one(cuda_device, tmp_path):
+    """Item-sharded RP under 2 ranks (gloo rendezvous on this box's GPU; nccl = RCCL on a node): same seed, same text."""
+    from PIL import Image
+    from tise_toolbox_amd import RP_coco
+    from tests.test_gpu_pipeline import _run_ranks
+    rng = np.random.default_rng(1)
+    words = ["a", "red", "bus", "dog", "on", "the", "grass", "two", "people", "near", "table"]
+    img_dir = tmp_path / "images"; img_dir.mkdir()
+    items = []
+    for i in range(27):
+        items.append({"caption_id": 500 + i, "caption": " ".join(rng.choice(words, 5)) + f" {i}",
+                      "mismatched_captions": [" ".join(rng.choice(words, 5)) + f" m{i}_{j}" for j in range(5)]})
+        Image.fromarray(rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)).save(img_dir / f"{500 + i}.png")
+    pkl = tmp_path / "rp.pkl"; pickle.dump(items, open(pkl, "wb"))
+    o1, o2 = tmp_path / "one.txt", tmp_path / "two.txt"
+    base = ["--image_dir", str(img_dir), "--rp_input_file", str(pkl), "--seed", "9", "--batch-size", "8", "--synthetic-weights"]
+    RP_coco.main(base + ["--saved_file_path", str(o1)])
+    res = _run_ranks(2, base + ["--saved_file_path", str(o2)], tmp_path, module="tise_toolbox_amd.RP_coco")
+    assert all(rc == 0 for rc, _ in res), res
+    assert o1.read_text() == o2.read_text()

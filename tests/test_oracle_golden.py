@@ -176,3 +176,23 @@ def test_pa_oracle_matches_reference_script_run(golden_dir):
     g = json.load(open(os.path.join(golden_dir, "pa_stub.json")))
     pa, per = rp_oracle.pa_score({p: np.array(g["logits"][p]) for p in g["phrases"]})
     assert f"PA = {pa}" == g["expected_text"]
+
+
+@pytest.mark.parametrize("name", ["rp_stub_57x10.npz", "rp_stub_40x100.npz"])
+def test_rp_item_shards_add_up_to_the_reference_text(golden_dir, name):
+    """Data-parallel RP: per-bin {success, count} of item shards, summed, reproduce the text the
+    reference script wrote (the all-reduce is a sum of these (10, 2) arrays)."""
+    from oracle import rp_oracle
+    from tise_toolbox_amd import RP_coco, dist as tdist
+    g = np.load(os.path.join(golden_dir, name))
+    success = rp_oracle.rp_success_from_logits(g["logits"])
+    perm = g["perm"].tolist()
+    n = len(success)
+    for world in (1, 2, 3, 8):
+        total = np.zeros((10, 2))
+        for r in range(world):
+            lo, hi = tdist.shard_range(n, r, world)
+            total += RP_coco.bin_sums(success[lo:hi], lo, perm)
+        assert total[:, 1].sum() == n
+        mean, std, _ = RP_coco.r_precision_from_bin_sums(total)
+        assert f"R-precision: {mean} +- {std}" == str(g["expected_text"]), world

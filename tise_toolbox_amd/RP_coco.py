@@ -10,6 +10,11 @@ Same CLI (RP_coco.py:17-25: --image_dir --rp_input_file --saved_file_path --gpu_
     3. csrc/retrieval.hip scores all items at once against int32 index lists into the text table.
 The shuffle that forms the bins is unseeded in the reference (:43); `--seed` makes it reproducible (default: unseeded
 like the reference).  The towers are clip_model.py (see its header: scaffolding on library kernels, parity unpinned).
+
+Data parallel (SURVEY 8e "RP"): under torchrun the ITEMS are sharded -- rank r embeds the images and the distinct
+captions of its contiguous item range and scores them -- the bins come from one permutation every rank shares (rank
+0's seed is broadcast when --seed is not given), and the only exchange is one all-reduce(SUM) of the per-bin
+{success, count} pairs (160 bytes).
 """
 import argparse
 import os
@@ -19,7 +24,7 @@ import random
 import numpy as np
 import torch
 
-from . import _lib, clip_model, device, weights as tweights
+from . import _lib, clip_model, device, dist as tdist, weights as tweights
 
 
 def parse_args(argv=None):
@@ -77,6 +82,24 @@ def r_precision_from_success(success, perm, num_bins=10):
     return np.mean(scores), np.std(scores), scores
 
 
+def bin_sums(success, item_base, perm, num_bins=10):
+    """Per-bin [successes, count] (num_bins, 2) float64 of the items item_base .. item_base + len(success) - 1 under
+    the GLOBAL permutation `perm`: additive over item shards; scores = sums[:, 0] / sums[:, 1] (RP_coco.py:79)."""
+    bin_of = np.empty(len(perm), dtype=np.int64)
+    for b, ids in enumerate(make_bins(len(perm), perm, num_bins)):
+        bin_of[np.asarray(ids, dtype=np.int64)] = b
+    sums = np.zeros((num_bins, 2), dtype=np.float64)
+    mine = bin_of[item_base:item_base + len(success)]
+    np.add.at(sums[:, 0], mine, np.asarray(success, dtype=np.float64))
+    np.add.at(sums[:, 1], mine, 1.0)
+    return sums
+
+
+def r_precision_from_bin_sums(sums):
+    scores = [int(s) * 1.0 / int(c) for s, c in sums]               # success_count * 1.0 / len(b)   (:79)
+    return np.mean(scores), np.std(scores), scores
+
+
 def r_precision(img_emb, txt_emb, txt_index, perm, normalize=True, logit_scale=100.0, num_bins=10):
     """Embeddings on the GPU -> (mean, std, bin scores); the scoring runs in csrc/retrieval.hip."""
     top1, _ = device.cosine_top1(img_emb, txt_emb, txt_index, normalize=normalize, logit_scale=logit_scale, want_p0=False)
@@ -119,7 +142,9 @@ def main(argv=None):
     args = parse_args(argv)
     if not torch.cuda.is_available():
         raise _lib.TiseLibraryError("RP_coco needs an MI355X: there is no CPU path")
-    dev = torch.device(f"cuda:{args.gpu_id}")
+    rank, world, local_rank = tdist.init_from_env()
+    dev = torch.device(f"cuda:{local_rank}" if world > 1 else f"cuda:{args.gpu_id}")
+    torch.cuda.set_device(dev)
     wpath, tag = tweights.resolve(args.weights, args.synthetic_weights, "clip")
     if wpath is not None and not args.vocab:
         raise RuntimeError("real CLIP weights need the BPE vocabulary: pass --vocab bpe_simple_vocab_16e6.txt.gz")
@@ -127,19 +152,35 @@ def main(argv=None):
     tokenizer = clip_model.BPETokenizer(args.vocab) if args.vocab else clip_model.HashTokenizer()
     with open(args.rp_input_file, "rb") as f:
         rp_input = pickle.load(f)
-    captions, index = caption_table(rp_input)
-    txt = embed_texts(model, tokenizer, captions, dev, args.batch_size)
-    img = embed_images(model, args.image_dir, [it["caption_id"] for it in rp_input], dev, args.batch_size)
-    perm = shuffled_ids(len(rp_input), args.seed)
-    scale = float(model.logit_scale.detach().exp())
-    # features are already normalised in the model's dtype, as CLIP.forward does before the matmul
-    mean, std, scores = r_precision(img, txt, torch.from_numpy(index).to(dev), perm, normalize=False, logit_scale=scale)
-    for bin_idx, s in enumerate(scores):
-        print(f"Bin: {bin_idx}, RP: {s}")
-    print(f"R-precision: {mean} +- {std}{tag}")
-    if args.saved_file_path is not None:
-        with open(args.saved_file_path, "w") as f:
-            f.write(f"R-precision: {mean} +- {std}{tag}")
+    n_items = len(rp_input)
+    seed = args.seed
+    if world > 1:                                           # one permutation for all ranks
+        t = torch.tensor([seed if seed is not None else random.randrange(2 ** 31)], dtype=torch.int64, device=dev)
+        torch.distributed.broadcast(t, src=0)
+        seed = int(t.item())
+        tdist.broadcast_module_(model)
+    perm = shuffled_ids(n_items, seed)
+    lo, hi = tdist.shard_range(n_items, rank, world)
+    mine = rp_input[lo:hi]
+    sums = np.zeros((10, 2), dtype=np.float64)
+    if mine:
+        captions, index = caption_table(mine)
+        txt = embed_texts(model, tokenizer, captions, dev, args.batch_size)
+        img = embed_images(model, args.image_dir, [it["caption_id"] for it in mine], dev, args.batch_size)
+        scale = float(model.logit_scale.detach().exp())
+        # features are already normalised in the model's dtype, as CLIP.forward does before the matmul
+        top1, _ = device.cosine_top1(img, txt, torch.from_numpy(index).to(dev), normalize=False, logit_scale=scale, want_p0=False)
+        sums = bin_sums((top1 == 0).cpu().numpy(), lo, perm)
+    acc = torch.from_numpy(sums).to(dev)
+    tdist.all_reduce_sum_(acc)                              # per-bin {success, count}: the only exchange
+    mean, std, scores = r_precision_from_bin_sums(acc.cpu().numpy())
+    if tdist.is_main():
+        for bin_idx, s in enumerate(scores):
+            print(f"Bin: {bin_idx}, RP: {s}")
+        print(f"R-precision: {mean} +- {std}{tag}")
+        if args.saved_file_path is not None:
+            with open(args.saved_file_path, "w") as f:
+                f.write(f"R-precision: {mean} +- {std}{tag}")
     return mean, std
 
 
