@@ -439,3 +439,32 @@ def test_split_trunk_vs_exact_fp32_convs_3000_images(cuda_device, monkeypatch):
     print(cc)
     assert cc["dfid"] <= 1e-3 and cc["dis"] <= 1e-4 and cc["dis_std"] <= 1e-4
     assert cc["max_feature_err_rel"] <= 1e-4
+
+
+def test_u8_cache_feed_is_bit_identical_to_png_decoding(setup, tmp_path):
+    """--u8-cache: first run decodes into <dir>/.tise_u8_cache.npy, later runs read it through the
+    double-buffered pinned host->device loader; same FID to the last bit as the DataLoader path, the cache file is
+    never mistaken for an image, and a changed directory invalidates it."""
+    from PIL import Image
+    from tise_toolbox_amd import fid_score, img_data
+    gdir, rdir = tmp_path / "gen", tmp_path / "ref"
+    gdir.mkdir(); rdir.mkdir()
+    for i in range(23):
+        Image.fromarray(setup["gen"][i]).save(gdir / f"{i:05d}.png")
+    for i in range(17):
+        Image.fromarray(setup["ref"][i]).save(rdir / f"{i:05d}.png")
+    argv = ["--batch-size", "4", "--path1", str(rdir), "--path2", str(gdir), "--num-workers", "2", "--synthetic-weights"]
+    plain = fid_score.main(argv)
+    first = fid_score.main(argv + ["--u8-cache"])                     # builds both caches
+    assert (gdir / fid_score.U8_CACHE_NAME).exists() and (rdir / fid_score.U8_CACHE_NAME).exists()
+    assert np.load(gdir / fid_score.U8_CACHE_NAME, mmap_mode="r").shape == (23, 256, 256, 3)
+    again = fid_score.main(argv + ["--u8-cache"])                     # reads them
+    assert plain == first == again
+    assert len(img_data.get_filenames(str(gdir))) == 23               # the cache is not walked as an image
+    Image.fromarray(setup["gen"][30]).save(gdir / "extra.png")        # directory changed -> cache rebuilt
+    changed = fid_score.main(argv + ["--u8-cache"])
+    assert np.load(gdir / fid_score.U8_CACHE_NAME, mmap_mode="r").shape[0] == 24
+    assert changed == fid_score.main(argv)
+    loader = img_data.U8CacheLoader(str(gdir / fid_score.U8_CACHE_NAME), 5, setup["dev"], rows=(5, 20))
+    got = torch.cat([b.clone() for b in loader])
+    assert len(loader) == 3 and torch.equal(got.cpu(), torch.from_numpy(np.load(gdir / fid_score.U8_CACHE_NAME)[5:20]))

@@ -56,6 +56,9 @@ def _build_parser():
     parser.add_argument("--synthetic-weights", action="store_true",
                         help="seeded stand-in parameters (plumbing / throughput only; results are tagged)")
     parser.add_argument("--seed", type=int, default=0, help="seed of the --synthetic-weights parameters")
+    parser.add_argument("--u8-cache", action="store_true",
+                        help="decode each image directory once into <dir>/.tise_u8_cache.npy and feed later runs (and "
+                             "all ranks) from it over a double-buffered pinned host->device pipeline")
     parser.add_argument("--per-class", action="store_true",
                         help="O-FID extension: one FID per object class ({stem}_{class}_{k}.png crops)")
     parser.add_argument("--save-stats", type=str, default="", help="write mu/sigma of --path2 to this .npz")
@@ -205,8 +208,14 @@ def calculate_activation_statistics(images, model, batch_size=64, dims=2048, cud
     return mu.cpu().numpy(), sigma.cpu().numpy()
 
 
-def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers=8):
-    """fid_score.py:199-220: an .npz holds (mu, sigma); a directory is walked and pushed through the net."""
+U8_CACHE_NAME = ".tise_u8_cache.npy"
+
+
+def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers=8, u8_cache=False):
+    """fid_score.py:199-220: an .npz holds (mu, sigma); a directory is walked and pushed through the net.
+    ``u8_cache``: decode the directory ONCE into ``<path>/.tise_u8_cache.npy`` ((N,H,W,3) uint8, walk order) and feed
+    later runs -- and every rank of a data-parallel run -- from it through a double-buffered pinned host->device
+    pipeline (img_data.U8CacheLoader) instead of PNG-decoding DataLoader workers."""
     if path.endswith(".npz"):
         f = np.load(path, allow_pickle=True)              # :201-203
         m, s = f["mu"][:], f["sigma"][:]
@@ -214,6 +223,16 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
         return m, s
     files = img_data.get_filenames(path)                  # os.walk order (img_data.py:27-35)
     rank, world, _ = tdist.env_world()
+    if u8_cache:
+        cache = os.path.join(path, U8_CACHE_NAME)          # the name holds neither "png" nor "jpg": never walked
+        if tdist.is_main() and not (os.path.exists(cache) and np.load(cache, mmap_mode="r").shape[0] == len(files)):
+            img_data.build_u8_cache(files, cache, num_workers)
+        tdist.barrier()
+        n_used = tdist.n_used_images(len(files), batch_size)
+        lo, hi = tdist.shard_range(n_used // batch_size, rank, world)
+        engine = _engine_for(model, dims)
+        loader = img_data.U8CacheLoader(cache, batch_size, engine.device, rows=(lo * batch_size, hi * batch_size))
+        return calculate_activation_statistics(loader, model, batch_size, dims, cuda)
     shard, _ = tdist.shard_files(files, batch_size, rank, world)       # drop_last=True (:215-217), whole batches
     dataset = img_data.Dataset(path, transform=None, file_names=shard)
     dataloader = torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=False, drop_last=True,
@@ -230,7 +249,7 @@ def _build_model(dims, weights, num_classes, seed):
 
 
 def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_classes=1000, seed=0,
-                              save_stats="", num_workers=8):
+                              save_stats="", num_workers=8, u8_cache=False):
     """Calculates the FID of two paths (fid_score.py:223-238).  ``weights=None`` = seeded stand-in parameters (the
     CLI only allows that behind --synthetic-weights)."""
     for p in paths:
@@ -238,7 +257,7 @@ def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_c
             raise RuntimeError("Invalid path: %s" % p)    # :225-227
     _check_cuda(cuda)
     model = _build_model(dims, weights, num_classes, seed)
-    m1, s1 = _compute_statistics_of_path(paths[0], model, batch_size, dims, cuda, num_workers)
+    m1, s1 = _compute_statistics_of_path(paths[0], model, batch_size, dims, cuda, num_workers, u8_cache)
     # the first side's covariance is complete: factor it on a side stream while the second side's images are decoded
     # and pushed through the network (Tr sqrtm(S1 S2) is symmetric in its arguments; csrc/frechet.hip)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -246,7 +265,7 @@ def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_c
     use_pf = tuple(np.shape(s1)) == (dims, dims) and tuple(np.shape(m1)) == (dims,)
     if use_pf:
         solver.prefactor(torch.as_tensor(np.ascontiguousarray(s1, dtype=np.float64), device=dev))
-    m2, s2 = _compute_statistics_of_path(paths[1], model, batch_size, dims, cuda, num_workers)
+    m2, s2 = _compute_statistics_of_path(paths[1], model, batch_size, dims, cuda, num_workers, u8_cache)
     if save_stats and tdist.is_main():
         np.savez(save_stats, mu=np.asarray(m2), sigma=np.asarray(s2))
     if not use_pf or np.shape(m1) != np.shape(m2) or np.shape(s1) != np.shape(s2):
@@ -259,7 +278,7 @@ def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_c
 
 
 def save_statistics_of_path(path, out_npz, batch_size, cuda, dims, weights=None, num_classes=1000, seed=0,
-                            num_workers=8):
+                            num_workers=8, u8_cache=False):
     """STATS-ONLY mode: the step BEFORE the reference path -- write the ``.npz {mu, sigma}`` that
     ``_compute_statistics_of_path`` (fid_score.py:200-203) reads (the reference ships such files,
     download_evaluation_data.py:11-12, but no script that makes them).  No Frechet distance is solved."""
@@ -267,7 +286,7 @@ def save_statistics_of_path(path, out_npz, batch_size, cuda, dims, weights=None,
         raise RuntimeError("Invalid path: %s" % path)
     _check_cuda(cuda)
     model = _build_model(dims, weights, num_classes, seed)
-    mu, sigma = _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers)
+    mu, sigma = _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers, u8_cache)
     if tdist.is_main():
         np.savez(out_npz, mu=np.asarray(mu), sigma=np.asarray(sigma))
     return mu, sigma
@@ -350,7 +369,7 @@ def main(argv=None):
         if tdist.is_main():
             print([args.path2])
         mu, sigma = save_statistics_of_path(args.path2, args.save_stats, args.batch_size, args.gpu, args.dims, wpath,
-                                            args.num_classes, args.seed, args.num_workers)
+                                            args.num_classes, args.seed, args.num_workers, args.u8_cache)
         if tdist.is_main():
             print(f"statistics of {args.path2} -> {args.save_stats}{tag}")
         return None
@@ -371,8 +390,8 @@ def main(argv=None):
                     f.write("\n".join(lines))
             print("\n".join(lines))
         return per
-    fid_value = calculate_fid_given_paths(paths, args.batch_size, args.gpu, args.dims, wpath,
-                                          args.num_classes, args.seed, args.save_stats, args.num_workers).item()
+    fid_value = calculate_fid_given_paths(paths, args.batch_size, args.gpu, args.dims, wpath, args.num_classes,
+                                          args.seed, args.save_stats, args.num_workers, args.u8_cache).item()
     if tdist.is_main():
         if args.saved_file:
             with open(args.saved_file, "w") as f:
