@@ -146,30 +146,33 @@ def test_rp_cli_end_to_end_with_stand_in_towers(cuda_device, tmp_path):
 def test_fp16_near_ties_resolve_like_clip_forward(cuda_device):
     """with the fp16 model the reference compares fp16 softmax outputs and np.argmax takes the FIRST
     maximum, so a distractor whose logit exceeds the true caption's by less than the fp16 rounding still loses.
-    Constructed items: img = e0; true caption = cos t, distractor j = cos(t) + delta_j with |delta| from far below to
-    far above the fp16 spacing of logits near 30 (0.0156 at scale 100)."""
+    Constructed items (all inputs exactly representable in fp16): img = (1, 1, 0, ...), true caption (b, 0, ...),
+    distractor 3 = (b, e, ...): its logit is larger by 100 e, from 1e-4 to 0.4, around the fp16 spacing of logits
+    near 30 (0.0156)."""
     from tise_toolbox_amd import device
-    d, c = 512, 8
-    deltas = np.array([0.0, 1e-6, 3e-5, 6e-5, 1e-4, 3e-4, 1e-3, 3e-3])       # cosine differences (x100 = logit differences)
-    n = len(deltas)
-    img = np.zeros((n, d), np.float32); img[:, 0] = 1.0
+    d, c = 64, 8
+    es = [0.0, 2.0 ** -20, 2.0 ** -18, 2.0 ** -16, 2.0 ** -14, 2.0 ** -12, 2.0 ** -10, 2.0 ** -8]
+    n = len(es)
+    b = float(np.float16(0.3))
+    img = np.zeros((n, d), np.float32); img[:, 0] = 1.0; img[:, 1] = 1.0
     txt = np.zeros((n * c, d), np.float32)
-    for i, dl in enumerate(deltas):
-        base = 0.3
+    for i, e in enumerate(es):
         for j in range(c):
-            cos = base if j == 0 else (base + dl if j == 3 else base - 0.05 * j)
-            txt[i * c + j, 0] = cos
-            txt[i * c + j, 1] = np.sqrt(1.0 - cos * cos)
+            txt[i * c + j, 0] = b if j in (0, 3) else float(np.float16(b - 0.05 * j))
+        txt[i * c + 3, 1] = e
     ti = torch.from_numpy(img).to(cuda_device).half()
     tt = torch.from_numpy(txt).to(cuda_device).half()
+    assert torch.equal(tt.float().cpu(), torch.from_numpy(txt))              # nothing lost in the inputs
     top1, p0 = device.cosine_top1(ti, tt, None, normalize=False, logit_scale=100.0)
     want = [int(np.argmax(rp_oracle.clip_forward_probs(ti[i].cpu().numpy(), tt[i * c:(i + 1) * c].cpu().numpy(), 100.0, False, np.float16)))
             for i in range(n)]
+    exact = [int(np.argmax(rp_oracle.clip_logits(img[i], txt[i * c:(i + 1) * c], 100.0, False))) for i in range(n)]
     assert top1.cpu().tolist() == want
-    assert want[0] == 0 and want[1] == 0 and want[-1] == 3                   # ties go to index 0; a clear margin does not
-    exact = [int(np.argmax(rp_oracle.clip_logits(ti[i].float().cpu().numpy(), tt[i * c:(i + 1) * c].float().cpu().numpy(), 100.0, False)))
-             for i in range(n)]
-    assert exact != want                                                       # fp64 logits WOULD flip some of them
+    assert exact == [0] + [3] * (n - 1)                                       # in exact arithmetic every e > 0 wins
+    assert want[:4] == [0, 0, 0, 0] and want[-3:] == [3, 3, 3]                # below half an fp16 ulp of the logit: tie -> 0
+    # the fp32 model (CPU path of the reference) resolves all of them
+    top1_32, _ = device.cosine_top1(ti.float(), tt.float(), None, normalize=False, logit_scale=100.0)
+    assert top1_32.cpu().tolist() == exact
 
 
 def _pa_fixture(tmp_path, n_per_phrase=(7, 5, 9)):
