@@ -763,24 +763,42 @@ __global__ __launch_bounds__(1024) void gershgorin_kernel(const double* __restri
     }
 }
 
-// number of eigenvalues of T that are < x  (LAPACK dlaebz-style Sturm count)
-__device__ __forceinline__ int sturm_count(const double* __restrict__ td, const double* __restrict__ te, int n, double x,
-                                           double pivmin) {
-    double q = td[0] - x;
-    int cnt = 0;
-    if (q <= pivmin) { ++cnt; q = fmin(q, -pivmin); }
+// number of eigenvalues of T that are < x  (LAPACK dlaebz-style Sturm count), for NP shifts at once: the recurrence
+//     q_i = d_i - x - e_{i-1}^2 / q_{i-1}
+// is one long dependent chain per shift (n steps); a lane can carry NP independent chains (default 1: see
+// launch_bisect) and the division is a v_rcp_f64 plus one Newton step (3 dependent instructions instead of the
+// ~10 of the correctly rounded division: 2.65 -> 1.83 ms at n = 2048, same eigenvalues to the last digit printed;
+// the count is insensitive to the last bit of q except when q is within rounding of zero, where pivmin decides).
+template <int NP>
+__device__ __forceinline__ void sturm_count_multi(const double* __restrict__ td, const double* __restrict__ te, int n,
+                                                  const double (&x)[NP], double pivmin, int (&cnt)[NP]) {
+    double q[NP];
+    const double d0 = td[0];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        q[u] = d0 - x[u];
+        cnt[u] = 0;
+        if (q[u] <= pivmin) { ++cnt[u]; q[u] = fmin(q[u], -pivmin); }
+    }
     for (int i = 1; i < n; ++i) {
         const double e = te[i - 1];
-        q = td[i] - (e * e) / q - x;
-        if (q <= pivmin) { ++cnt; q = fmin(q, -pivmin); }
+        const double e2 = e * e, di = td[i];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            double r = __builtin_amdgcn_rcp(q[u]);
+            r = fma(fma(-q[u], r, 1.0), r, r);
+            q[u] = (di - x[u]) - e2 * r;
+            if (q[u] <= pivmin) { ++cnt[u]; q[u] = fmin(q[u], -pivmin); }
+        }
     }
-    return cnt;
 }
 
-// One wave per eigenvalue, 64-way multisection: every lane evaluates the Sturm count at its own shift
-// inside the current bracket, a ballot picks the sub-interval that contains the m-th eigenvalue.  6 bits per
-// pass instead of 1 => ~9 passes over the tridiagonal recurrence instead of ~55, and n waves instead of n
-// threads keep every CU busy.  td/te are read at wave-uniform addresses (scalar loads).
+// One wave per eigenvalue, (64 NP)-way multisection: every lane evaluates the Sturm count at NP shifts of its own
+// inside the current bracket (probe index = u * 64 + lane, i.e. 64 NP equally spaced shifts), ballots pick
+// the sub-interval that contains the m-th eigenvalue.  8 bits per pass instead of 1 => ~7 passes over the
+// tridiagonal recurrence instead of ~55, and n waves instead of n threads keep every CU busy.  td/te are read at
+// wave-uniform addresses (scalar loads).
+template <int BIS_NP>
 __global__ __launch_bounds__(256) void bisect_kernel(const double* __restrict__ td, const double* __restrict__ te, int n,
                                                      const FrState* __restrict__ st, double* __restrict__ eig) {
     const int lane = threadIdx.x & 63;
@@ -791,21 +809,25 @@ __global__ __launch_bounds__(256) void bisect_kernel(const double* __restrict__ 
     // absolute accuracy eps * ||T|| is all the trace of the square root needs (and all that the
     // tridiagonalisation preserved)
     const double tol = 2.220446049250313e-16 * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin;
+    constexpr int NPROBE = 64 * BIS_NP;
     for (int it = 0; it < 40; ++it) {
         const double width = hi - lo;
         if (!(width > tol)) break;
-        const double x = lo + width * ((double)(lane + 1) * (1.0 / 65.0));
-        const int cnt = sturm_count(td, te, n, x, pivmin);
-        const unsigned long long mask = __ballot(cnt >= m + 1);     // monotone in the lane index
-        double nlo, nhi;
-        if (mask == 0ull) {                      // eigenvalue above every probe
-            nlo = __shfl(x, 63, 64);
-            nhi = hi;
-        } else {
-            const int first = __ffsll((long long)mask) - 1;
-            nhi = __shfl(x, first, 64);
-            nlo = first > 0 ? __shfl(x, first - 1, 64) : lo;
+        double x[BIS_NP];
+        int cnt[BIS_NP];
+#pragma unroll
+        for (int u = 0; u < BIS_NP; ++u) x[u] = lo + width * ((double)(u * 64 + lane + 1) * (1.0 / (NPROBE + 1)));
+        sturm_count_multi<BIS_NP>(td, te, n, x, pivmin, cnt);
+        // first probe (in index order u * 64 + lane) whose count reaches m + 1; counts are monotone in the probe index
+        int first = NPROBE;
+#pragma unroll
+        for (int u = BIS_NP - 1; u >= 0; --u) {
+            const unsigned long long mask = __ballot(cnt[u] >= m + 1);
+            if (mask != 0ull) first = u * 64 + (__ffsll((long long)mask) - 1);
         }
+        // x of probe j: every lane can compute it (same formula)
+        const double nhi = first < NPROBE ? lo + width * ((double)(first + 1) * (1.0 / (NPROBE + 1))) : hi;
+        const double nlo = first > 0 ? lo + width * ((double)first * (1.0 / (NPROBE + 1))) : lo;
         if (!(nhi - nlo < width)) break;         // no progress at the resolution of the doubles
         lo = nlo;
         hi = nhi;
@@ -902,6 +924,16 @@ int run_pchol(tise_frechet* h, const double* S, double off, int* rank_out, hipSt
     return TISE_OK;
 }
 
+void launch_bisect(tise_frechet* h, int n, hipStream_t st) {
+    // chains per lane: measured 1.83 / 2.61 / 4.15 ms for 1 / 2 / 4 at n = 2048 (profiles/r02i_bisect_np.txt): with two
+    // waves per SIMD the recurrence is bound by fp64 issue, not by its latency, so extra chains only add work
+    static const int np = getenv("TISE_BISECT_NP") ? atoi(getenv("TISE_BISECT_NP")) : 1;
+    const dim3 grid(ceil_div(n, 4)), block(256);
+    if (np == 1) hipLaunchKernelGGL(bisect_kernel<1>, grid, block, 0, st, h->td, h->te, n, h->st, h->eig);
+    else if (np == 4) hipLaunchKernelGGL(bisect_kernel<4>, grid, block, 0, st, h->td, h->te, n, h->st, h->eig);
+    else hipLaunchKernelGGL(bisect_kernel<2>, grid, block, 0, st, h->td, h->te, n, h->st, h->eig);
+}
+
 // eigenvalues of the symmetric n x n matrix in h->m (ld = n, destroyed) -> h->eig[0..n)
 int run_eigvalsh_inplace(tise_frechet* h, int n, hipStream_t st) {
     if (n <= 0) return TISE_OK;
@@ -931,7 +963,7 @@ int run_eigvalsh_inplace(tise_frechet* h, int n, hipStream_t st) {
         TISE_LAUNCH_CHECK();
         if (h->profiling) TISE_HIP_CHECK(hipEventRecord(h->ev[3], st));
         hipLaunchKernelGGL(gershgorin_kernel, dim3(1), dim3(1024), 0, st, h->td, h->te, n, h->st);
-        hipLaunchKernelGGL(bisect_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, st, h->td, h->te, n, h->st, h->eig);
+        launch_bisect(h, n, st);
         TISE_LAUNCH_CHECK();
         return TISE_OK;
     }
@@ -959,7 +991,7 @@ int run_eigvalsh_inplace(tise_frechet* h, int n, hipStream_t st) {
         TISE_LAUNCH_CHECK();
         if (h->profiling) TISE_HIP_CHECK(hipEventRecord(h->ev[3], st));
         hipLaunchKernelGGL(gershgorin_kernel, dim3(1), dim3(1024), 0, st, h->td, h->te, n, h->st);
-        hipLaunchKernelGGL(bisect_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, st, h->td, h->te, n, h->st, h->eig);
+        launch_bisect(h, n, st);
         TISE_LAUNCH_CHECK();
         return TISE_OK;
     }
@@ -976,7 +1008,7 @@ int run_eigvalsh_inplace(tise_frechet* h, int n, hipStream_t st) {
     hipLaunchKernelGGL(sytrd_last_kernel, dim3(1), dim3(64), 0, st, A, n, h->td);
     if (h->profiling) TISE_HIP_CHECK(hipEventRecord(h->ev[3], st));
     hipLaunchKernelGGL(gershgorin_kernel, dim3(1), dim3(1024), 0, st, h->td, h->te, n, h->st);
-    hipLaunchKernelGGL(bisect_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, st, h->td, h->te, n, h->st, h->eig);
+    launch_bisect(h, n, st);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
