@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Three forward passes of the split-precision trunk at batch 500 for rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes;
-prints the algorithmic bytes of the conv launches of one pass (input + output activations + weights)."""
+"""Three forward passes of the split-precision trunk at batch 500 for rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
+and the SQ_* issue counters); prints -- and writes to gpurun_out/conv_traffic_layers.json -- the algorithmic bytes of
+the conv launches of one pass (input + output activations + weights).  Condensed by tools/conv_pmc_summary.py."""
 import json
 import os
 import sys
@@ -40,6 +41,9 @@ SplitConv.__call__ = orig
 for _ in range(2):
     trunk(x)
 torch.cuda.synchronize()
+out_dir = os.path.join(ROOT, "gpurun_out")
+os.makedirs(out_dir, exist_ok=True)
+json.dump({"per_launch": detail}, open(os.path.join(out_dir, "conv_traffic_layers.json"), "w"))
 print(json.dumps({"per_launch": detail}))
 print(json.dumps({"conv_launches_per_forward": len(one), "algorithmic_bytes_per_forward": sum(one),
                   "algorithmic_bytes_per_launch_avg": sum(one) / len(one)}))

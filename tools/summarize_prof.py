@@ -4,7 +4,7 @@
 usage: summarize_prof.py <dir with *_kernel_stats.csv and *_kernel_trace.csv, or a rocpd *_results.db> <out.md> [K steps]
 Two tables: (1) the library's hand-written kernels over the whole run (calls, total, avg, min, max);
 (2) steady-state per-step breakdown of the LAST K steps of the timed loop (window from the K-th last
-resize kernel to the first pchol_init after it), which excludes MIOpen's find-mode trial kernels."""
+resize kernel to the first stats_finalize after the last one), which excludes warm-up and the once-per-job tail."""
 import collections
 import csv
 import glob
@@ -62,7 +62,9 @@ def main():
     res = [i for i, r in enumerate(tr) if "resize_bilinear" in r[2]]
     if len(res) >= K:
         i0 = res[-K]
-        ends = [i for i, r in enumerate(tr) if i > i0 and "pchol_init" in r[2]]
+        # end of the loop: the (mu, sigma) finalisation after the LAST resize (round 2: the pivoted Cholesky of the
+        # reference side runs on a side stream DURING the loop, so pchol_* no longer marks the end)
+        ends = [i for i, r in enumerate(tr) if i > res[-1] and "stats_finalize" in r[2]]
         i1 = ends[0] if ends else len(tr)
         win = tr[i0:i1]
         span = (win[-1][1] - win[0][0]) / 1e6
