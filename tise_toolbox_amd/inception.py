@@ -247,6 +247,11 @@ def seeded_init_(net, seed=0, calibration="fid"):
     for m in bns:
         m.momentum = 1.0                     # running stats := statistics of this one batch
     was_training = net.training
+    # ONE host thread for the two calibration passes: the rounding of oneDNN's convolutions depends on how the work is
+    # split over threads, and torchrun sets OMP_NUM_THREADS=1 -- without this a 1-process and an N-process run of the
+    # same job would get stand-in weights that differ in the last bits (FID differing by ~3e-6)
+    n_threads = torch.get_num_threads()
+    torch.set_num_threads(1)
     net.train()
     _trunk_forward(net, x)
     # bring pool3 to the magnitude of real InceptionV3 features (mean ~0.25) so that FID values -- and
@@ -260,6 +265,7 @@ def seeded_init_(net, seed=0, calibration="fid"):
     for m, mom in zip(bns, old):
         m.momentum = mom
     net.fc.bias.copy_(-(net.fc.weight @ feats.mean(0)))
+    torch.set_num_threads(n_threads)
     if was_training:
         net.train()
     _SEEDED_CACHE[key] = {k: v.clone() for k, v in net.state_dict().items()}
