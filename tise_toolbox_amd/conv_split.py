@@ -137,6 +137,12 @@ class SplitConv:
             tails[:, :ntaps] = w3[:, :, nfull * 32:]
             self.w = split(torch.cat([full, tails.reshape(self.cout_pad, -1)], 1)).to(device).contiguous()
             self.kpad = self.w.shape[2]
+        # the default kernel reads the weights as ONE 128-byte line per (cout, 32-wide K block): [hi 32 | lo 32]
+        # (conv_split_fast_kernel: 128-byte LDS-DMA rows); the planar (2, Cout_pad, Kpad) copy serves "reg" / "glds"
+        self.w_fast = None
+        if self.pipe_cfg is None:
+            hi, lo = self.w[0], self.w[1]
+            self.w_fast = torch.stack([hi.reshape(self.cout_pad, -1, 32), lo.reshape(self.cout_pad, -1, 32)], 2).contiguous()
         sc = torch.zeros(self.cout_pad, dtype=torch.float32)
         sc[:cout] = 1.0 / pre
         bs = torch.zeros(self.cout_pad, dtype=torch.float32)
@@ -157,7 +163,8 @@ class SplitConv:
         oh, ow = self.out_hw(h, w)
         a = ConvArgs()
         a.x = x.data_ptr(); a.x_plane = x.stride(0)
-        a.w = self.w.data_ptr(); a.w_plane = self.w.stride(0)
+        wt = self.w_fast if (self.variant == "fast" and self.w_fast is not None) else self.w
+        a.w = wt.data_ptr(); a.w_plane = self.w.stride(0)
         a.scale = self.scale.data_ptr(); a.bias = self.bias.data_ptr()
         a.N, a.H, a.W, a.Cin = n, h, w, self.cin
         a.KH, a.KW, a.SH, a.SW, a.PH, a.PW = self.kh, self.kw, self.stride[0], self.stride[1], self.padding[0], self.padding[1]

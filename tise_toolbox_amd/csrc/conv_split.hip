@@ -444,17 +444,21 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         iw0[jj] = (int)ow * p.SW - p.PW;
         img[jj] = xg + (long long)n * p.H * p.W * p.Cin;
     }
-    // weight pointers of this wave's TN DMA pieces (advance 32 halfs per step)
+    // weight pointers of this wave's TN DMA pieces.  The weights are packed [cout][k / 32][hi 32 | lo 32] for this kernel
+    // (conv_split.py): a (cout, K-step) row is ONE 128-byte line, a piece = 8 couts x 128 B -- the LDS-DMA path moves
+    // 128-byte rows at 38 B/clk/CU against 30 for the 64-byte rows of the pixel operand (profiles/
+    // r01g_glds_rate_microbench.txt), and the weights are half of a 128-cout step's bytes.  LDS rows are 128 B too; the
+    // ds_read_b128 fragments stay conflict-free with the chunk index XOR-ed with (row >> 1) & 7 (eight rows of one
+    // parity x eight chunk slots, two parities: the 16 lanes of a b128 group hit 16 distinct 16-byte bank groups).
     const _Float16* pb[TN];
     int pb_off[TN];
 #pragma unroll
     for (int i = 0; i < TN; ++i) {
-        const int q = wave * TN + i;
-        const int plane = q >= 2 * TN ? 1 : 0;
-        const int rb = q - plane * 2 * TN;
-        pb[i] = reinterpret_cast<const _Float16*>(p.w) + (plane ? p.w_plane : 0) +
-                (long long)(n0 + rb * 16 + (lane >> 2)) * p.Kpad + cl * 8;
-        pb_off[i] = 2 * A_PLANE + plane * B_PLANE + rb * 1024;
+        const int q = wave * TN + i;                                   // 8-cout block of the tile
+        const int r = q * 8 + (lane >> 3);                             // cout row within the tile
+        const int c = (lane & 7) ^ ((r >> 1) & 7);                     // logical chunk: 0-3 hi, 4-7 lo
+        pb[i] = reinterpret_cast<const _Float16*>(p.w) + (long long)(n0 + r) * (2 * p.Kpad) + c * 8;
+        pb_off[i] = 2 * A_PLANE + q * 1024;
     }
     // pixel-operand pointers for the current tap: ALWAYS loadable (the zero page when the tap falls outside the
     // image or the row outside M) with a per-lane advance of 64 bytes or 0, so that a K-step issues its DMA
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
             const _Float16* sw_ = pb[i];                                                                   \
             unsigned char* dw_ = lds + (STAGEOFF) + pb_off[i];                                             \
             __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)dw_, 16, 0, 0);                               \
-            pb[i] += CS_BK;                                                                                \
+            pb[i] += 2 * CS_BK;                              /* next K-step: 128 bytes further */          \
         }                                                                                                  \
         ++istep;                                             /* the step whose pointers are prepared now */ \
         if (istep >= nA) {                                   /* wave-uniform */                            \
@@ -533,6 +537,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     const int fswz = ((lane & 31) >> 2) & 3;
     const int fo0 = (lane & 31) * 64 + (((lane >> 5)) ^ fswz) * 16;
     const int fo1 = (lane & 31) * 64 + ((2 + (lane >> 5)) ^ fswz) * 16;
+    // weight fragments: 128-byte rows, hi chunk 2*s + (lane >> 5), lo chunk = hi chunk + 4, both XOR (row >> 1) & 7
+    const int bswz = ((lane & 31) >> 1) & 7;
+    const int fb0 = (lane & 31) * 128 + (((lane >> 5)) ^ bswz) * 16;
+    const int fb1 = (lane & 31) * 128 + ((2 + (lane >> 5)) ^ bswz) * 16;
     const unsigned char* fa = lds + wave * 32 * 64;
 
 // One K-step of MFMAs.  All fragment reads of the step are written first and the MFMAs after them; the
@@ -547,9 +555,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
             fa_[s][0] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + fo);                           \
             fa_[s][1] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + A_PLANE + fo);                 \
             _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
-                const unsigned char* bp = lds + (STAGEOFF) + 2 * A_PLANE + t * 32 * 64 + fo;               \
-                fb_[s][t][0] = *reinterpret_cast<const half8_t*>(bp);                                      \
-                fb_[s][t][1] = *reinterpret_cast<const half8_t*>(bp + B_PLANE);                            \
+                const int fbo = s ? fb1 : fb0;                                                             \
+                const unsigned char* bb = lds + (STAGEOFF) + 2 * A_PLANE + t * 32 * 128;                   \
+                fb_[s][t][0] = *reinterpret_cast<const half8_t*>(bb + fbo);                                \
+                fb_[s][t][1] = *reinterpret_cast<const half8_t*>(bb + (fbo ^ 64));                         \
             }                                                                                              \
         }                                                                                                  \
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \

@@ -27,6 +27,7 @@ Deviations from the reference, all deliberate (SURVEY.md notes N3-N5):
 """
 import os
 import sys
+import time
 import warnings
 from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
 
@@ -232,7 +233,15 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
         lo, hi = tdist.shard_range(n_used // batch_size, rank, world)
         engine = _engine_for(model, dims)
         loader = img_data.U8CacheLoader(cache, batch_size, engine.device, rows=(lo * batch_size, hi * batch_size))
-        return calculate_activation_statistics(loader, model, batch_size, dims, cuda)
+        t0 = time.perf_counter()
+        out = calculate_activation_statistics(loader, model, batch_size, dims, cuda)
+        wall = time.perf_counter() - t0
+        n_img = len(loader) * batch_size
+        if tdist.is_main() and n_img:
+            print(f"[tise] u8 cache feed: {n_img} images in {wall:.2f} s ({n_img / wall:.0f} images/s on this rank); host side "
+                  f"(page cache -> pinned buffer -> H2D enqueue) {loader.h2d_seconds:.2f} s, the rest is the device pipeline",
+                  file=sys.stderr)
+        return out
     shard, _ = tdist.shard_files(files, batch_size, rank, world)       # drop_last=True (:215-217), whole batches
     dataset = img_data.Dataset(path, transform=None, file_names=shard)
     dataloader = torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=False, drop_last=True,
