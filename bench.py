@@ -7,13 +7,13 @@
 
 The JOB is BASELINE.json's metric: IS* + FID of ONE set of K*500 synthetic uint8 256x256x3 images (30 000 at the
 default K = 60) that are already resident in HBM, against pre-computed reference statistics.  A STEP is 1/K of the
-job = one pass of the hot path over 500 images:
+job = the hot path over 500 images (the device runs them in batches of 1000, see DEVICE_BATCH):
     resize 256->299 (PIL-exact, csrc/resize.hip) -> InceptionV3 trunk (hand-written split-fp16 MFMA convolutions,
     csrc/conv_split.hip / conv_pipe.hip / trunk_ops.hip) + fc -> fp64 covariance/mean accumulation (csrc/stats.hip)
     -> IS* split sums (csrc/is_score.hip).
 With N GPUs the SAME job is sharded (STRONG scaling, SURVEY.md section 8(d) "Config 3"): rank r takes the
 contiguous index range dist.shard_range(K*500, r, N) (3 750 images at N = 8) and runs it in device batches that
-divide its range (500 / 500 / 500 / 750 at N = 1 / 2 / 4 / 8).  After the loop the timed region contains, once: the
+divide its range (1000 / 1000 / 750 / 750 images at N = 1 / 2 / 4 / 8; a step stays 1/K of the job = 500 images).  After the loop the timed region contains, once: the
 all-reduce of the sufficient statistics over RCCL, the finalisation of (mu, sigma), the Frechet distance
 (csrc/frechet.hip, solved redundantly on every rank) and the IS* finalisation.  value = K*500 / max-over-ranks
 seconds; `allreduce_ms` and `finalize_ms` are reported separately.  `--scaling weak` gives every rank its own
@@ -52,6 +52,8 @@ PEAK_HBM_GBS = 8000.0
 PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: "Peak BF16/FP16 MFMA ~2.5 PF dense"
 GLOBAL_STEP_IMAGES = 500
+DEVICE_BATCH = 1000        # images per device batch when it divides a rank's share (tools/batch_sweep.sh: 500 / 750 / 1000 / 1500
+                           # -> 20.04 / 20.07 / 20.27 / 20.22 k images/s on one box: fewer launch gaps and tile tails per image)
 
 
 def synth_images_device(lo, hi, device, seed=0, shift=0.0, hw=256):
@@ -88,9 +90,9 @@ def synth_images_device(lo, hi, device, seed=0, shift=0.0, hw=256):
     return out
 
 
-def rank_batch(n_rank, preferred=GLOBAL_STEP_IMAGES, cap=750):
+def rank_batch(n_rank, preferred=DEVICE_BATCH, cap=DEVICE_BATCH):
     """Device batch of a rank: `preferred` when it divides the rank's image count, otherwise the largest divisor
-    <= cap (3 750 images at 8 GPUs -> 750); a count without a usable divisor runs `preferred` with a short tail."""
+    <= cap (7 500 / 3 750 images at 4 / 8 GPUs -> 750); a count without a usable divisor runs `preferred` with a short tail."""
     if n_rank <= 0:
         return preferred
     if n_rank % preferred == 0 or n_rank < preferred:
@@ -219,6 +221,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=GLOBAL_STEP_IMAGES, help="images per step (job = steps x batch images)")
+    ap.add_argument("--device-batch", type=int, default=0, help="images per device batch (0: chosen by rank_batch)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--ref-images", type=int, default=3000)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline AND parity (both need the CPU oracle)")
@@ -246,7 +249,7 @@ def main():
         n_total = K * B * world
         lo, hi = rank * K * B, (rank + 1) * K * B
     n_rank = hi - lo
-    rb = rank_batch(n_rank, B)
+    rb = args.device_batch if args.device_batch > 0 else rank_batch(n_rank)
     chunks = [(a, min(a + rb, n_rank)) for a in range(0, n_rank, rb)]
 
     # ---- inputs resident in HBM before the timed region ------------------------------------------

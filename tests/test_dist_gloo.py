@@ -101,11 +101,11 @@ def test_shard_files_global_drop_last():
 
 def test_bench_strong_scaling_shards_cover_the_job_once():
     """bench.py --scaling strong (SURVEY 8(d) Config 3): ONE 30k set, contiguous 30000/N images per rank, device
-    batches that divide a rank's range (500/500/500/750 at 1/2/4/8 GPUs)."""
+    batches that divide a rank's range (1000/1000/750/750 at 1/2/4/8 GPUs)."""
     sys.path.insert(0, ROOT)
     import bench
     from tise_toolbox_amd import dist as tdist
-    want_batch = {1: 500, 2: 500, 4: 500, 8: 750}
+    want_batch = {1: 1000, 2: 1000, 4: 750, 8: 750}
     for world in (1, 2, 3, 4, 8):
         covered = []
         for r in range(world):
@@ -118,4 +118,4 @@ def test_bench_strong_scaling_shards_cover_the_job_once():
             covered += [(lo + a, lo + b) for a, b in chunks]
         assert covered[0][0] == 0 and covered[-1][1] == 30000
         assert all(x[1] == y[0] for x, y in zip(covered[:-1], covered[1:]))
-    assert bench.rank_batch(1250) == 625 and bench.rank_batch(100) == 100
+    assert bench.rank_batch(1250) == 625 and bench.rank_batch(100) == 100 and bench.rank_batch(10000) == 1000
