@@ -136,7 +136,11 @@ def cpu_reference_pass(gen_u8, ref_u8, n_job, dims=2048, workers=8):
     from oracle import fid_oracle, inception_oracle, is_oracle, resize_oracle
     from tise_toolbox_amd.inception import build_inception3
     from tests import _cases
-    threads = torch.get_num_threads()
+    # torch's CPU convolutions are fastest well below the host's thread count (this pool's 128-thread hosts:
+    # 94 / 52 / 35 / 30 ms per image at 128 / 64 / 32 / 16 threads, batch 50): the baseline gets the better setting
+    all_threads = torch.get_num_threads()
+    threads = min(32, all_threads)
+    torch.set_num_threads(threads)
     sd = {k: v.float() for k, v in build_inception3(seed=0).state_dict().items()}
     n = gen_u8.shape[0]
     bs = 50
@@ -197,6 +201,7 @@ def cpu_reference_pass(gen_u8, ref_u8, n_job, dims=2048, workers=8):
     lg = np.random.default_rng(0).standard_normal((n_job, 1000)).astype(np.float32)
     t_is, _ = _median_time(lambda: is_oracle.inception_score_from_logits(lg, is_oracle.T_COCO, 10, "coco", dtype=np.float32),
                            repeats=3, warmup=1)
+    torch.set_num_threads(all_threads)
     n_used = (n // bs) * bs
     per_img_dec, per_img_fwd = t_dec / n_used, t_fwd / n
     # the reference overlaps the loader workers with the forward pass: per image the slower of the two stages

@@ -29,6 +29,8 @@ def setup(cuda_device):
     gen = _cases.smooth_images(N_GEN, 256, 256, seed=0)
     ref = _cases.smooth_images(N_REF, 256, 256, seed=1, shift=0.15)
 
+    torch.set_num_threads(min(16, torch.get_num_threads()))    # CPU oracle forward: 3x faster at 16 threads than at 128
+
     def oracle_feats(imgs):
         xs = np.stack([resize_oracle.to_tensor(resize_oracle.resize_bilinear_u8(im, 299, 299)) for im in imgs])
         feats, logits = [], []
@@ -394,6 +396,7 @@ def test_baseline_config0_1k_vs_1k_random_pngs(cuda_device, tmp_path):
     got = fid_score.main(["--batch-size", "50", "--path1", str(tmp_path / "ref"), "--path2", str(tmp_path / "gen"),
                           "--saved_file", str(out), "--num-workers", "8", "--synthetic-weights"])
     sd = {k: v.float() for k, v in build_inception3(seed=0).state_dict().items()}
+    torch.set_num_threads(min(16, torch.get_num_threads()))    # the CPU forward is 3x faster at 16 threads than at 128
 
     def oracle_stats(root):
         files = img_data.get_filenames(str(root))

@@ -122,7 +122,7 @@ def test_rp_cli_end_to_end_with_stand_in_towers(cuda_device, tmp_path):
     out = tmp_path / "rp.txt"
     mean, std = RP_coco.main(["--image_dir", str(img_dir), "--rp_input_file", str(pkl), "--saved_file_path", str(out),
                               "--gpu_id", str(cuda_device.index or 0), "--seed", "4", "--batch-size", "8",
-                              "--synthetic-weights"])
+                              "--num-workers", "0", "--synthetic-weights"])
     from tise_toolbox_amd.weights import SYNTHETIC_TAG
     assert open(out).read() == f"R-precision: {mean} +- {std}" + SYNTHETIC_TAG
     # oracle on the same embeddings
@@ -202,7 +202,7 @@ def test_pa_cli_end_to_end_and_two_ranks(cuda_device, tmp_path):
     data, pkl = _pa_fixture(tmp_path)
     out = tmp_path / "pa.txt"
     argv = ["--image_dir", str(tmp_path / "images"), "--pa_input_file", str(pkl), "--saved_file_path", str(out),
-            "--gpu_id", "0", "--synthetic-weights", "--batch-size", "4"]
+            "--gpu_id", "0", "--num-workers", "0", "--synthetic-weights", "--batch-size", "4"]
     val = PA.main(argv)
     assert out.read_text() == f"PA = {val}" + SYNTHETIC_TAG
     model = clip_model.build_clip().to(cuda_device).half()
@@ -221,7 +221,7 @@ def test_pa_cli_end_to_end_and_two_ranks(cuda_device, tmp_path):
     assert all(rc == 0 for rc, _ in res), res
     assert out2.read_text() == out.read_text()
     with pytest.raises(RuntimeError, match="no parameters for CLIP"):
-        PA.main(argv[:-3])
+        PA.main([a for a in argv if a != "--synthetic-weights"])
 
 
 def test_rp_cli_two_ranks_equals_one(cuda_device, tmp_path):
@@ -239,7 +239,8 @@ def test_rp_cli_two_ranks_equals_one(cuda_device, tmp_path):
         Image.fromarray(rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)).save(img_dir / f"{500 + i}.png")
     pkl = tmp_path / "rp.pkl"; pickle.dump(items, open(pkl, "wb"))
     o1, o2 = tmp_path / "one.txt", tmp_path / "two.txt"
-    base = ["--image_dir", str(img_dir), "--rp_input_file", str(pkl), "--seed", "9", "--batch-size", "8", "--synthetic-weights"]
+    base = ["--image_dir", str(img_dir), "--rp_input_file", str(pkl), "--seed", "9", "--batch-size", "8", "--num-workers", "0",
+            "--synthetic-weights"]
     RP_coco.main(base + ["--saved_file_path", str(o1)])
     res = _run_ranks(2, base + ["--saved_file_path", str(o2)], tmp_path, module="tise_toolbox_amd.RP_coco")
     assert all(rc == 0 for rc, _ in res), res

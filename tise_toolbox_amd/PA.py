@@ -33,6 +33,7 @@ def parse_args(argv=None):
     parser.add_argument("--synthetic-weights", action="store_true",
                         help="seeded stand-in towers + word-hash tokenizer (plumbing / throughput only; results are tagged)")
     parser.add_argument("--batch-size", default=256, type=int)
+    parser.add_argument("--num-workers", default=8, type=int, help="image-decoding DataLoader workers")
     return parser.parse_args(argv)
 
 
@@ -93,7 +94,7 @@ def main(argv=None):
                             for it in mine], dtype=np.int32)
         txt = embed_texts(model, tokenizer, list(table), dev, args.batch_size)
         img = _embed_paths(model, [os.path.join(args.image_dir, phrase, str(it["caption_id"]) + ".png") for it in mine],
-                           dev, args.batch_size)
+                           dev, args.batch_size, args.num_workers)
         ok = pa_successes(img, txt, torch.from_numpy(index).to(dev), scale)
         sums[pi, 0] = ok.double().sum()
         sums[pi, 1] = float(len(mine))

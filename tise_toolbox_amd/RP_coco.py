@@ -39,6 +39,7 @@ def parse_args(argv=None):
                         help="seeded stand-in towers + word-hash tokenizer (plumbing / throughput only; results are tagged)")
     parser.add_argument("--seed", default=None, type=int, help="seed of the bin shuffle (reference: unseeded)")
     parser.add_argument("--batch-size", default=256, type=int)
+    parser.add_argument("--num-workers", default=8, type=int, help="image-decoding DataLoader workers")
     return parser.parse_args(argv)
 
 
@@ -166,7 +167,7 @@ def main(argv=None):
     if mine:
         captions, index = caption_table(mine)
         txt = embed_texts(model, tokenizer, captions, dev, args.batch_size)
-        img = embed_images(model, args.image_dir, [it["caption_id"] for it in mine], dev, args.batch_size)
+        img = embed_images(model, args.image_dir, [it["caption_id"] for it in mine], dev, args.batch_size, args.num_workers)
         scale = float(model.logit_scale.detach().exp())
         # features are already normalised in the model's dtype, as CLIP.forward does before the matmul
         top1, _ = device.cosine_top1(img, txt, torch.from_numpy(index).to(dev), normalize=False, logit_scale=scale, want_p0=False)
