@@ -587,19 +587,37 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     // ablation switches for tools/conv_ablate.py (bits above the segment count; never set by the product path):
     // 0x100 no DMA after the first stage, 0x200 no fragment reads / MFMAs, 0x400 no epilogue
     const bool ab_dma = !(p.nseg & 0x100), ab_mma = !(p.nseg & 0x200);
+    // measurement switch 0x800 (tools/conv_stamps.py): workgroup 0 writes s_memtime stamps of its first 96 K-steps to the
+    // int buffer passed in seg[3].dst -- per step: loop top | DMA landed | barrier passed | DMA issued | MFMAs issued
+    const bool dbg = (p.nseg & 0x800) && blockIdx.x == 0;
+    int* dbuf = reinterpret_cast<int*>(p.seg[3].dst);
+#define CF_STAMP(STEP, K)                                                                                  \
+    if (dbg && lane == 0 && (STEP) < 96) dbuf[wave * 512 + (STEP) * 5 + (K)] = (int)__builtin_readcyclecounter();
+    if (dbg && lane == 0) dbuf[wave * 512 + 480] = (int)(__builtin_amdgcn_s_memrealtime());
     CF_TAP()
     CF_ISSUE(0)
     int step = 0;
     for (; step + 1 < nsteps; step += 2) {
+        CF_STAMP(step, 0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CF_STAMP(step, 1)
         __syncthreads();
+        CF_STAMP(step, 2)
         if (ab_dma) CF_ISSUE(STAGE)                           // step+1 -> stage 1
+        CF_STAMP(step, 3)
         if (ab_mma) CF_COMPUTE(0)
+        CF_STAMP(step, 4)
+        CF_STAMP(step + 1, 0)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CF_STAMP(step + 1, 1)
         __syncthreads();
+        CF_STAMP(step + 1, 2)
         if (step + 2 < nsteps && ab_dma) CF_ISSUE(0)          // step+2 -> stage 0
+        CF_STAMP(step + 1, 3)
         if (ab_mma) CF_COMPUTE(STAGE)
+        CF_STAMP(step + 1, 4)
     }
+    if (dbg && lane == 0) dbuf[wave * 512 + 481] = (int)(__builtin_amdgcn_s_memrealtime());
     if (step < nsteps) {                                      // odd tail: its data sits in stage 0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""In-kernel stamps of the persistent conv kernel: where one K-step's cycles go (waves 0 and 4 of workgroup 0)."""
+"""In-kernel stamps of the default conv kernel (conv_split_fast_kernel): where one K-step's cycles go, waves 0-3 of
+workgroup 0.   usage: conv_stamps.py [H,Cin,Cout,kh,kw,stride]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, ctypes
@@ -9,20 +10,19 @@ from tise_toolbox_amd import _lib
 
 dev = torch.device("cuda:0")
 H, Cin, Cout, kh, kw, st, pad = 35, 288, 384, 3, 3, 2, (0, 0)
-if len(sys.argv) > 2:
-    H, Cin, Cout, kh, kw, st = [int(v) for v in sys.argv[2].split(",")]
+if len(sys.argv) > 1:
+    H, Cin, Cout, kh, kw, st = [int(v) for v in sys.argv[1].split(",")]
     pad = (kh // 2, kw // 2) if st == 1 else (0, 0)
-cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-flags = int(sys.argv[3], 0) if len(sys.argv) > 3 else 0
+flags = int(sys.argv[2], 0) if len(sys.argv) > 2 else 0
 N = 500
 g = torch.Generator(device="cpu").manual_seed(1)
 w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
 b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
-conv = SplitConv(w, b, (st, st), pad, dev, variant="pipe", pipe_cfg=cfg)
+conv = SplitConv(w, b, (st, st), pad, dev)
 oh, ow = conv.out_hw(H, H)
 x = split((torch.rand((N, H, H, Cin), device=dev) * 3.0))
 out = torch.zeros((2, N, oh, ow, Cout), dtype=torch.float16, device=dev)
-stamp = torch.zeros(1024, dtype=torch.int32, device=dev)
+stamp = torch.zeros(2048, dtype=torch.int32, device=dev)
 for _ in range(3):
     conv(x, [(0, Cout, out, 0, 0)])
 conv.debug_flags = 0x800 | flags
@@ -30,13 +30,16 @@ conv.debug_ptr = stamp.data_ptr()
 conv(x, [(0, Cout, out, 0, 0)])
 torch.cuda.synchronize()
 s = stamp.cpu().numpy().astype(np.int64) & 0xffffffff
-for wv in (0, 1):
+nsteps = min(94, conv.kpad // 32)
+for wv in range(4):
     t = s[wv * 512: wv * 512 + 480].reshape(96, 5)
-    print(f"wave {wv * 4}: step  wait  barrier  issue  compute  | step total   (cycles of s_memtime)")
-    for i in range(2, 40):
-        d = [(t[i, k + 1] - t[i, k]) & 0xffffffff for k in range(4)]
-        tot = (t[i + 1, 0] - t[i, 0]) & 0xffffffff
-        print(f"   {i:3d}  {d[0]:6d} {d[1]:6d} {d[2]:6d} {d[3]:6d}   | {tot:6d}")
-    tt = (t[60, 0] - t[20, 0]) & 0xffffffff
-    rt = (int(s[wv * 512 + 481]) - int(s[wv * 512 + 480])) & 0xffffffff
-    print(f"   mean step (20..60): {tt / 40:.0f} ticks; wall {rt * 10} ns for 40 steps -> {tt / (rt * 10.0):.3f} ticks/ns, {rt * 10 / 40:.0f} ns/step")
+    d = np.array([[(t[i, k + 1] - t[i, k]) & 0xffffffff for k in range(4)] + [(t[i + 1, 0] - t[i, 0]) & 0xffffffff]
+                  for i in range(2, nsteps - 1)], dtype=np.float64)
+    rt = (int(s[wv * 512 + 481]) - int(s[wv * 512 + 480])) & 0xffffffff          # s_memrealtime: 100 MHz
+    span = (t[nsteps - 1, 4] - t[0, 0]) & 0xffffffff
+    print(f"wave {wv}: mean over steps 2..{nsteps - 2}:  wait-DMA {d[:, 0].mean():6.0f}  barrier {d[:, 1].mean():6.0f}  issue-DMA {d[:, 2].mean():6.0f}  "
+          f"issue-reads+MFMAs {d[:, 3].mean():6.0f}  | step {d[:, 4].mean():6.0f} ticks;  K loop {span} ticks in {rt * 10} ns "
+          f"-> {span / max(rt * 10.0, 1):.3f} ticks/ns")
+    if wv == 0:
+        for i in range(0, min(12, len(d))):
+            print("      step", i + 2, " ".join(f"{int(v):6d}" for v in d[i]))
