@@ -218,6 +218,34 @@ int tise_cosine_top1(const void* img_emb_dev, const void* txt_emb_dev, const int
                      void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * (a11, section 8 f3) The CLIP ViT-B/32 towers (third-party `clip`, called per item by text_relevance/RP_coco.py:56-80
+ * and positional_alignment/PA.py:33-43), batched: fp16 tensors, fp32 accumulation and statistics -- the arithmetic of
+ * the fp16 model `clip.load` serves on a GPU.  Row-major matrices with explicit leading dimensions (elements).
+ *   tise_gemm_f16        out[m][n] = act(sum_k a[m][k] w[n][k] + bias[n]) + residual[m][n]     (nn.Linear layout of w;
+ *                        act 0 = none, 1 = QuickGELU x*sigmoid(1.702x); bias / residual nullable; k % 64 == 0,
+ *                        n % 8 == 0, leading dimensions % 8 == 0)
+ *   tise_layernorm_f16   per row over C <= 1024 columns, fp32 mean / variance (clip.model.LayerNorm)
+ *   tise_attention_f16   qkv [batch*seq][3*heads*64] (q | k | v) -> out [batch*seq][heads*64], softmax(q k^T / 8) v per
+ *                        (sequence, head), optional causal mask (text tower); seq <= 80, head_dim == 64
+ *   tise_patchify_f16    image (batch, 3, res, res) NCHW -> [batch*(res/patch)^2][3*patch*patch], columns in the order of
+ *                        conv1.weight.flatten(1): the patch embedding becomes one tise_gemm_f16
+ *   tise_vit_tokens_f16  x[b][0] = class_emb + pos[0]; x[b][1+p] = patch_out[b*n_patches+p] + pos[1+p]
+ *   tise_text_tokens_f16 x[r] = table[tokens[r]] + pos[r % seq]
+ *   tise_gather_rows_f16 out[i] = x[index[i]]   (class token of every image / end-of-text token of every caption)
+ * ------------------------------------------------------------------------------------------ */
+int tise_gemm_f16(const void* a_dev, int64_t lda, const void* w_dev, int64_t ldw, const void* bias_dev, const void* res_dev,
+                  int64_t ldr, void* out_dev, int64_t ldo, int m, int n, int k, int act, void* stream);
+int tise_layernorm_f16(const void* x_dev, int64_t ldx, const void* gamma_dev, const void* beta_dev, void* out_dev, int64_t ldo,
+                       int64_t rows, int C, float eps, void* stream);
+int tise_attention_f16(const void* qkv_dev, int batch, int seq, int heads, int head_dim, int causal, void* out_dev, void* stream);
+int tise_patchify_f16(const void* img_dev, int batch, int res, int patch, void* out_dev, void* stream);
+int tise_vit_tokens_f16(const void* patch_out_dev, const void* class_emb_dev, const void* pos_emb_dev, int batch, int n_patches,
+                        int width, void* x_dev, void* stream);
+int tise_text_tokens_f16(const int32_t* tokens_dev, const void* table_dev, const void* pos_emb_dev, int64_t rows, int seq, int width,
+                         void* x_dev, void* stream);
+int tise_gather_rows_f16(const void* x_dev, const int64_t* index_dev, int64_t n, int width, void* out_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * (a5, convolution) Implicit-GEMM convolution on fp16 MFMA with 3-term split-precision operands.
  * Replaces the Conv2d + BatchNorm(eval) + ReLU of torchvision's BasicConv2d for NHWC tensors held as
  * two fp16 planes (v ~= hi + lo * 2^-11): D = max(scale * conv(x, w) + bias, 0), re-split and written

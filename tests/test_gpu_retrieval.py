@@ -125,14 +125,13 @@ def test_rp_cli_end_to_end_with_stand_in_towers(cuda_device, tmp_path):
                               "--num-workers", "0", "--synthetic-weights"])
     from tise_toolbox_amd.weights import SYNTHETIC_TAG
     assert open(out).read() == f"R-precision: {mean} +- {std}" + SYNTHETIC_TAG
-    # oracle on the same embeddings
-    model = clip_model.build_clip().to(cuda_device).half()
+    # oracle on the same embeddings (the same towers the CLI built: csrc/clip_ops.hip by default)
+    model, scale = RP_coco.build_towers(None, cuda_device)
     caps, index = RP_coco.caption_table(items)
     assert len(caps) < 23 * 7                                         # captions are de-duplicated
     txt = RP_coco.embed_texts(model, clip_model.HashTokenizer(), caps, cuda_device, 8).float().cpu().numpy().astype(np.float64)
     img = RP_coco.embed_images(model, str(img_dir), [it["caption_id"] for it in items], cuda_device, 8, workers=0)
     img = img.float().cpu().numpy().astype(np.float64)
-    scale = float(model.logit_scale.exp())
     success, margins = [], []
     for i in range(len(items)):
         lg = rp_oracle.clip_logits(img[i], txt[index[i]], scale, normalize=False)
@@ -205,8 +204,8 @@ def test_pa_cli_end_to_end_and_two_ranks(cuda_device, tmp_path):
             "--gpu_id", "0", "--num-workers", "0", "--synthetic-weights", "--batch-size", "4"]
     val = PA.main(argv)
     assert out.read_text() == f"PA = {val}" + SYNTHETIC_TAG
-    model = clip_model.build_clip().to(cuda_device).half()
-    scale = float(model.logit_scale.detach().exp())
+    from tise_toolbox_amd.RP_coco import build_towers
+    model, scale = build_towers(None, cuda_device)
     scores = []
     for p, items in data.items():
         caps = [c for it in items for c in (it["caption"], it["false_caption"])]

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib, clip_model, device, dist as tdist, weights as tweights
-from .RP_coco import embed_texts
+from .RP_coco import build_towers, embed_texts
 
 THRESHOLD = 0.6                                                              # PA.py:41
 
@@ -54,7 +54,7 @@ def _embed_paths(model, paths, dev, batch, workers=8):
     loader = torch.utils.data.DataLoader(_Images(paths), batch_size=batch, shuffle=False, num_workers=workers)
     out = []
     for x in loader:
-        f = model.encode_image(x.to(dev).to(next(model.parameters()).dtype))
+        f = model.encode_image(x.to(dev).half())
         out.append(f / f.norm(dim=-1, keepdim=True))
     return torch.cat(out).contiguous()
 
@@ -75,12 +75,10 @@ def main(argv=None):
     wpath, tag = tweights.resolve(args.weights, args.synthetic_weights, "clip")
     if wpath is not None and not args.vocab:
         raise RuntimeError("real CLIP weights need the BPE vocabulary: pass --vocab bpe_simple_vocab_16e6.txt.gz")
-    model = clip_model.build_clip(wpath).to(dev).half()
-    tdist.broadcast_module_(model)
+    model, scale = build_towers(wpath, dev)
     tokenizer = clip_model.BPETokenizer(args.vocab) if args.vocab else clip_model.HashTokenizer()
     with open(args.pa_input_file, "rb") as f:
         data = pickle.load(f)
-    scale = float(model.logit_scale.detach().exp())
     phrases = list(data.keys())                                               # PA.py:48
     sums = torch.zeros((len(phrases), 2), dtype=torch.float64, device=dev)    # {success, total} per phrase
     for pi, phrase in enumerate(phrases):

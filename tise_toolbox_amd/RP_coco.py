@@ -43,6 +43,21 @@ def parse_args(argv=None):
     return parser.parse_args(argv)
 
 
+def build_towers(weights_path, dev):
+    """-> (towers, logit_scale).  ``towers.encode_image`` / ``.encode_text`` in fp16, as the model clip.load serves on a GPU.
+    Default: the hand-written kernels of csrc/clip_ops.hip (clip_hip.HipTowers: 1.2x / 1.8x the library-kernel module
+    on the image / text tower, profiles/r02r_clip_towers.txt); TISE_CLIP=torch runs the module itself on PyTorch-ROCm
+    library kernels (what north_star prescribes for the forward passes; same parameters, same results to fp16 rounding)."""
+    model = clip_model.build_clip(weights_path)
+    scale = float(model.logit_scale.detach().exp())            # clip's convert_weights leaves logit_scale in fp32
+    model = model.to(dev).half()
+    tdist.broadcast_module_(model)
+    if os.environ.get("TISE_CLIP", "hip") == "torch":
+        return model, scale
+    from . import clip_hip
+    return clip_hip.HipTowers(model, dev), scale
+
+
 def make_bins(num_captions, perm, num_bins=10):
     """RP_coco.py:41-52."""
     samples_per_bin = int(len(perm) / num_bins)
@@ -134,7 +149,7 @@ def embed_images(model, image_dir, caption_ids, dev, batch, workers=8):
     loader = torch.utils.data.DataLoader(_Images(image_dir, caption_ids), batch_size=batch, shuffle=False, num_workers=workers)
     out = []
     for x in loader:
-        f = model.encode_image(x.to(dev).to(next(model.parameters()).dtype))
+        f = model.encode_image(x.to(dev).half())
         out.append(f / f.norm(dim=-1, keepdim=True))
     return torch.cat(out).contiguous()
 
@@ -149,7 +164,7 @@ def main(argv=None):
     wpath, tag = tweights.resolve(args.weights, args.synthetic_weights, "clip")
     if wpath is not None and not args.vocab:
         raise RuntimeError("real CLIP weights need the BPE vocabulary: pass --vocab bpe_simple_vocab_16e6.txt.gz")
-    model = clip_model.build_clip(wpath).to(dev).half()                # clip.load on a GPU serves fp16 weights
+    model, scale = build_towers(wpath, dev)                            # clip.load on a GPU serves fp16 weights
     tokenizer = clip_model.BPETokenizer(args.vocab) if args.vocab else clip_model.HashTokenizer()
     with open(args.rp_input_file, "rb") as f:
         rp_input = pickle.load(f)
@@ -159,7 +174,6 @@ def main(argv=None):
         t = torch.tensor([seed if seed is not None else random.randrange(2 ** 31)], dtype=torch.int64, device=dev)
         torch.distributed.broadcast(t, src=0)
         seed = int(t.item())
-        tdist.broadcast_module_(model)
     perm = shuffled_ids(n_items, seed)
     lo, hi = tdist.shard_range(n_items, rank, world)
     mine = rp_input[lo:hi]
@@ -168,7 +182,6 @@ def main(argv=None):
         captions, index = caption_table(mine)
         txt = embed_texts(model, tokenizer, captions, dev, args.batch_size)
         img = embed_images(model, args.image_dir, [it["caption_id"] for it in mine], dev, args.batch_size, args.num_workers)
-        scale = float(model.logit_scale.detach().exp())
         # features are already normalised in the model's dtype, as CLIP.forward does before the matmul
         top1, _ = device.cosine_top1(img, txt, torch.from_numpy(index).to(dev), normalize=False, logit_scale=scale, want_p0=False)
         sums = bin_sums((top1 == 0).cpu().numpy(), lo, perm)

@@ -41,6 +41,14 @@ SIGNATURES = {
                                          POINTER(c_float), c_void_p, c_void_p]),
     "tise_cosine_top1": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                   c_void_p, c_void_p]),
+    "tise_gemm_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
+                               c_int, c_int, c_void_p]),
+    "tise_layernorm_f16": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_float, c_void_p]),
+    "tise_attention_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "tise_patchify_f16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "tise_vit_tokens_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "tise_text_tokens_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    "tise_gather_rows_f16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p]),
     "tise_stats_create": (c_int, [c_int, POINTER(c_void_p)]),
     "tise_stats_destroy": (c_int, [c_void_p]),
     "tise_stats_reset": (c_int, [c_void_p, c_void_p]),

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtise_hip.so")
-SOURCES = ["capi.hip", "stats.hip", "resize.hip", "is_score.hip", "frechet.hip", "trunk_ops.hip", "conv_split.hip", "conv_pipe.hip", "retrieval.hip"]
+SOURCES = ["capi.hip", "stats.hip", "resize.hip", "is_score.hip", "frechet.hip", "trunk_ops.hip", "conv_split.hip", "conv_pipe.hip", "retrieval.hip", "clip_ops.hip"]
 HEADERS = ["common.h", "gemm_tile.h", "conv_epilogue.h", os.path.join("..", "..", "include", "tise_hip.h")]
 
 

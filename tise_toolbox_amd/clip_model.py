@@ -1,4 +1,5 @@
-"""CLIP ViT-B/32 towers for RP-COCO / PA: SCAFFOLDING, not the hand-written path.
+"""CLIP ViT-B/32 for RP-COCO / PA: the module (parameters, tokenizers, preprocessing) and its
+PyTorch-ROCm forward.  The default forward of the CLIs is clip_hip.HipTowers (csrc/clip_ops.hip) built FROM this module.
 
 The reference calls the third-party `clip` package (`clip.load("ViT-B/32")`, text_relevance/RP_coco.py:31,
 positional_alignment/PA.py:30), which is not in /root/reference, not in this image, and whose weights and BPE
@@ -6,10 +7,10 @@ vocabulary cannot be fetched.  This module restates the published architecture (
 patch 32, width 768, 12 layers, 12 heads, 512-d joint space; text: 77 tokens, width 512, 12 layers, 8 heads,
 vocab 49408, QuickGELU, causal mask, features taken at the end-of-text token) with the parameter names of the
 OpenAI checkpoint, so a real `state_dict` loads with `strict=True`; without one the weights are seeded
-stand-ins (throughput and plumbing only).  The towers run on PyTorch-ROCm library kernels (hipBLASLt GEMMs, SDPA):
-PARITY UNPINNED, and NOT part of the hand-written HIP hot path -- what is hand-written for this row is the
-retrieval reduction (csrc/retrieval.hip) and what is pinned is the host logic around the towers
-(tests/golden/rp_stub_*.npz).
+stand-ins (throughput and plumbing only).  This module's own forward runs on PyTorch-ROCm library kernels (hipBLASLt
+GEMMs, SDPA; selected by TISE_CLIP=torch) and is the fp32 reference the hand-written towers are tested against
+(tests/test_gpu_clip.py).  PARITY of either forward against the real `clip` package: UNPINNED; what is pinned for this
+row is the host logic and the retrieval reduction around the towers (tests/golden/rp_stub_*.npz).
 """
 import gzip
 import html

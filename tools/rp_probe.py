@@ -44,4 +44,24 @@ with torch.no_grad():
     torch.cuda.synchronize(); t2 = time.perf_counter()
 print(f"text tower  (library kernels, fp16, batch 2048): {5 * 2048 / (t1 - t0):9.0f} captions/s")
 print(f"image tower (library kernels, fp16, batch 512):  {5 * 512 / (t2 - t1):9.0f} images/s")
+from tise_toolbox_amd import clip_hip
+towers = clip_hip.HipTowers(model)
+with torch.no_grad():
+    for _ in range(2):
+        towers.encode_text(t); towers.encode_image(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5):
+        towers.encode_text(t)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    for _ in range(5):
+        towers.encode_image(x)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+# flop of the GEMMs: image 12 x (4 x 768^2 x 3 [qkv+out] ... ) -- counted exactly below
+def tower_flop(seq, width, layers, extra):
+    per_tok = layers * 2 * (3 * width * width + width * width + 8 * width * width)      # qkv, out, fc, proj
+    return seq * per_tok + extra
+fi = tower_flop(50, 768, 12, 49 * 2 * 3072 * 768 + 2 * 768 * 512)
+ft = tower_flop(77, 512, 12, 2 * 512 * 512)
+print(f"text tower  (csrc/clip_ops.hip, fp16, batch 2048):  {5 * 2048 / (t1 - t0):9.0f} captions/s  = {5 * 2048 * ft / (t1 - t0) / 1e12:6.1f} TFLOP/s in its GEMMs")
+print(f"image tower (csrc/clip_ops.hip, fp16, batch 512):   {5 * 512 / (t2 - t1):9.0f} images/s    = {5 * 512 * fi / (t2 - t1) / 1e12:6.1f} TFLOP/s in its GEMMs")
 print("reference structure: batch 1 image + ~100 captions per item, every caption re-encoded per item")
