@@ -45,7 +45,7 @@ def parse_args(argv=None):
 
 def build_towers(weights_path, dev):
     """-> (towers, logit_scale).  ``towers.encode_image`` / ``.encode_text`` in fp16, as the model clip.load serves on a GPU.
-    Default: the hand-written kernels of csrc/clip_ops.hip (clip_hip.HipTowers: 1.2x / 1.8x the library-kernel module
+    Default: the hand-written kernels of csrc/clip_ops.hip (clip_hip.HipTowers: 1.15x / 1.8x the library-kernel module
     on the image / text tower, profiles/r02r_clip_towers.txt); TISE_CLIP=torch runs the module itself on PyTorch-ROCm
     library kernels (what north_star prescribes for the forward passes; same parameters, same results to fp16 rounding)."""
     model = clip_model.build_clip(weights_path)
