@@ -78,9 +78,10 @@ def main():
                 key = short(n)[:80]
             agg[key] += (e - s) / 1e6
             cnt[key] += 1
-        lines += ["", f"## steady state: last {K} steps of the timed loop", "",
-                  f"window {span:.2f} ms = {span/K:.3f} ms/step; sum of kernel durations {sum(agg.values()):.2f} ms", "",
-                  "| kernel | ms/step | launches/step |", "|---|---:|---:|"]
+        lines += ["", f"## steady state: last {K} device batches of the timed loop (one resize launch = one device batch; bench.py "
+                  "runs 1000 images per device batch, i.e. two 500-image steps)", "",
+                  f"window {span:.2f} ms = {span/K:.3f} ms per device batch; sum of kernel durations {sum(agg.values()):.2f} ms", "",
+                  "| kernel | ms per device batch | launches per device batch |", "|---|---:|---:|"]
         for k, v in agg.most_common(30):
             lines.append(f"| {k} | {v/K:.3f} | {cnt[k]/K:.1f} |")
     open(out, "w").write("\n".join(lines) + "\n")
