@@ -418,12 +418,10 @@ int tise_gemm_f16(const void* a_dev, int64_t lda, const void* w_dev, int64_t ldw
     const long long tiles = (long long)((m + GM_BM - 1) / GM_BM) * ((n + GM_BN - 1) / GM_BN);
     if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
     constexpr int lds = 3 * GM_STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (tise_first_use_on_this_device(attr_set))
         TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(gemm_f16_kernel, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, p);
     TISE_LAUNCH_CHECK();
     return TISE_OK;

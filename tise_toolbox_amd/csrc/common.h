@@ -19,6 +19,16 @@ extern "C" void tise_set_last_hip_error(int e);
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// "done once per device" latch for per-kernel attributes (hipFuncSetAttribute applies to the CURRENT device): one bit
+// per device ordinal, so a process that drives several GPUs sets the attribute on each of them.
+#include <atomic>
+static inline bool tise_first_use_on_this_device(std::atomic<unsigned long long>& mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+    const unsigned long long bit = 1ull << dev;
+    return (mask.fetch_or(bit) & bit) == 0;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -525,11 +525,10 @@ int launch_spec(const ConvArgs* a, hipStream_t st) {
     constexpr int LDS = 3 * STAGE + 4 * 2048 + (CW == 4 ? 4 * conv_epi::Staging<ETW>::BYTES : 0);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     if (a->Cin % 32 != 0 || a->Kpad != a->KH * a->KW * a->Cin || a->M >= 0x7fffff00LL) return TISE_ERR_INVALID_ARG;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (tise_first_use_on_this_device(attr_set)) {
         TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_spec_kernel<WN, TMW, TNW, CW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
     }
     const int tiles_n = (a->Cout + BN - 1) / BN;
     const long long ntiles = ((a->M + BM - 1) / BM) * tiles_n;
