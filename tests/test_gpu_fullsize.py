@@ -1,6 +1,8 @@
 """The hot path's reductions at BASELINE.json's full sizes (30 000 images, d = 2048, C = 1000, 8 ranks x 3 750):
 oracle comparisons where the oracle finishes in seconds, otherwise size-independent properties -- additivity over
 batches and over rank shards (what the all-reduce relies on), invariance to the batching, idempotent finalize."""
+import os
+
 import numpy as np
 import pytest
 import torch
