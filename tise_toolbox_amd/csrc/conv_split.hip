@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs 
 // source pointers are rebuilt only when the tap changes (wave-uniform branch) and otherwise advance by
 // 64 bytes; weight pointers always advance by 64 bytes; the two LDS stages are addressed with compile-time
 // offsets (loop unrolled by two).
-template <int TN>
+template <int TN, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs p) {
     constexpr int BN = 32 * TN;
     constexpr int A_PLANE = CS_BM * 64, B_PLANE = BN * 64;
@@ -542,23 +542,42 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     const int fb0 = (lane & 31) * 128 + (((lane >> 5)) ^ bswz) * 16;
     const int fb1 = (lane & 31) * 128 + ((2 + (lane >> 5)) ^ bswz) * 16;
     const unsigned char* fa = lds + wave * 32 * 64;
+    half8_t h_a0, h_a1, h_b0, h_b1;
 
 // One K-step of MFMAs.  All fragment reads of the step are written first and the MFMAs after them; the
 // sched_group_barrier sequence then tells the scheduler to emit them interleaved (first operand pair, then
 // "next pair of reads + 3 MFMAs" repeatedly), so that LDS latency is covered by the wave's own MFMAs instead
 // of four exposed lgkmcnt(0) waits per step (cdna guide T19).
+// the four fragments the step's first MFMA triple needs are requested BEFORE the step's DMA is issued (CF_HEAD): the
+// ~100-150 cycles of LDS latency then pass under the ~740 cycles the wave spends issuing its global_load_lds
+// instructions (profiles/r02q_conv_kstep_stamps.txt) instead of in front of the first MFMA.
+#define CF_HEAD(STAGEOFF)                                                                                 \
+    {                                                                                                     \
+        h_a0 = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + fo0);                                   \
+        h_a1 = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + A_PLANE + fo0);                         \
+        h_b0 = *reinterpret_cast<const half8_t*>(lds + (STAGEOFF) + 2 * A_PLANE + fb0);                    \
+        h_b1 = *reinterpret_cast<const half8_t*>(lds + (STAGEOFF) + 2 * A_PLANE + (fb0 ^ 64));             \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
 #define CF_COMPUTE(STAGEOFF)                                                                              \
     {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
         half8_t fa_[2][2], fb_[2][TN][2];                                                                  \
         _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
             const int fo = s ? fo1 : fo0;                                                                  \
-            fa_[s][0] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + fo);                           \
-            fa_[s][1] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + A_PLANE + fo);                 \
+            if (s == 0) { fa_[0][0] = h_a0; fa_[0][1] = h_a1; }                                            \
+            else {                                                                                         \
+                fa_[s][0] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + fo);                       \
+                fa_[s][1] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + A_PLANE + fo);             \
+            }                                                                                              \
             _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
                 const int fbo = s ? fb1 : fb0;                                                             \
                 const unsigned char* bb = lds + (STAGEOFF) + 2 * A_PLANE + t * 32 * 128;                   \
-                fb_[s][t][0] = *reinterpret_cast<const half8_t*>(bb + fbo);                                \
-                fb_[s][t][1] = *reinterpret_cast<const half8_t*>(bb + (fbo ^ 64));                         \
+                if (s == 0 && t == 0) { fb_[0][0][0] = h_b0; fb_[0][0][1] = h_b1; }                        \
+                else {                                                                                     \
+                    fb_[s][t][0] = *reinterpret_cast<const half8_t*>(bb + fbo);                            \
+                    fb_[s][t][1] = *reinterpret_cast<const half8_t*>(bb + (fbo ^ 64));                     \
+                }                                                                                          \
             }                                                                                              \
         }                                                                                                  \
         _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \
@@ -570,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
                 acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][0], acc_main[0][t], 0, 0, 0); \
                 acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][1], acc_corr[0][t], 0, 0, 0); \
             }                                                                                              \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);             /* a(s0), b(s0, t0) */              \
+        /* a(s0), b(s0, t0) are already in registers (CF_HEAD) */                                          \
         _Pragma("unroll") for (int i = 0; i < TN - 1; ++i) {                                               \
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         /* b(s0, t i+1) */                  \
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);         /* MFMAs (s0, t i) */               \
@@ -589,10 +608,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     const bool ab_dma = !(p.nseg & 0x100), ab_mma = !(p.nseg & 0x200);
     // measurement switch 0x800 (tools/conv_stamps.py): workgroup 0 writes s_memtime stamps of its first 96 K-steps to the
     // int buffer passed in seg[3].dst -- per step: loop top | DMA landed | barrier passed | DMA issued | MFMAs issued
-    const bool dbg = (p.nseg & 0x800) && blockIdx.x == 0;
+    // (a separate template instance, DBG = true: the product kernel carries none of this)
+    const bool dbg = DBG && (p.nseg & 0x800) && blockIdx.x == 0;
     int* dbuf = reinterpret_cast<int*>(p.seg[3].dst);
 #define CF_STAMP(STEP, K)                                                                                  \
-    if (dbg && lane == 0 && (STEP) < 96) dbuf[wave * 512 + (STEP) * 5 + (K)] = (int)__builtin_readcyclecounter();
+    if (DBG && dbg && lane == 0 && (STEP) < 96) dbuf[wave * 512 + (STEP) * 5 + (K)] = (int)__builtin_readcyclecounter();
     if (dbg && lane == 0) dbuf[wave * 512 + 480] = (int)(__builtin_amdgcn_s_memrealtime());
     CF_TAP()
     CF_ISSUE(0)
@@ -603,6 +623,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         CF_STAMP(step, 1)
         __syncthreads();
         CF_STAMP(step, 2)
+        CF_HEAD(0)
         if (ab_dma) CF_ISSUE(STAGE)                           // step+1 -> stage 1
         CF_STAMP(step, 3)
         if (ab_mma) CF_COMPUTE(0)
@@ -612,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         CF_STAMP(step + 1, 1)
         __syncthreads();
         CF_STAMP(step + 1, 2)
+        CF_HEAD(STAGE)
         if (step + 2 < nsteps && ab_dma) CF_ISSUE(0)          // step+2 -> stage 0
         CF_STAMP(step + 1, 3)
         if (ab_mma) CF_COMPUTE(STAGE)
@@ -621,6 +643,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     if (step < nsteps) {                                      // odd tail: its data sits in stage 0
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        CF_HEAD(0)
         CF_COMPUTE(0)
     }
     __syncthreads();
@@ -662,6 +685,15 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)tiles), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (fast && (args->nseg & 0x800)) {                       // tools/conv_stamps.py: the instrumented instance
+        switch (tn) {
+            case 3: hipLaunchKernelGGL((conv_split_fast_kernel<3, true>), grid, block, 0, st, *args); break;
+            case 4: hipLaunchKernelGGL((conv_split_fast_kernel<4, true>), grid, block, 0, st, *args); break;
+            default: return TISE_ERR_INVALID_ARG;
+        }
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
     if (fast) {
         switch (tn) {
             case 1: hipLaunchKernelGGL(conv_split_fast_kernel<1>, grid, block, 0, st, *args); break;
