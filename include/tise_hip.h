@@ -177,29 +177,31 @@ int tise_avgpool3_bias_relu_nhwc(const float* x_dev, int64_t x_ld, int x_off, in
 int tise_maxpool3s2_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
                          const float* bias_dev, float* out_dev, int64_t out_ld, int out_off, void* stream);
 
-/* Split-fp16 variants of the epilogues (activations as two fp16 planes, v ~= hi + lo * 2^-11, the
- * format tise_conv_split_f16 consumes and produces): out_dev is the hi plane, the lo plane follows
- * out_plane elements later; x of the max pool is such a plane pair too. */
-int tise_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_off, int64_t pixels, int C,
-                              const float* bias_dev, void* out_dev, int64_t out_ld, int out_off,
-                              int64_t out_plane, void* stream);
+/* Split-fp16 activations (v ~= hi + lo * 2^-11, the format tise_conv_split_f16 consumes and produces).
+ * LAYOUT of a split tensor of C channels (C % 16 == 0): NHWC; inside a pixel the channels come in blocks of 32 with
+ * the two halves of a block side by side -- [hi c0..c31 | lo c0..c31][hi c32..c63 | lo c32..c63]... (128 bytes per
+ * block) -- followed, when C % 32 == 16, by one 64-byte block [hi x16 | lo x16].  A pixel is 4*C bytes, the same as
+ * fp32.  `ld` arguments of split tensors are the tensor's channel count C, `off` the first channel of a slice.
+ *
+ * out = split(max(avgpool3x3(stride 1, pad 1, count_include_pad)(x) + bias, 0)): x is raw fp32 (n, h, w, x_ld). */
 int tise_avgpool3_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
                                        const float* bias_dev, void* out_dev, int64_t out_ld, int out_off,
-                                       int64_t out_plane, void* stream);
-int tise_maxpool3s2_split_nhwc(const void* x_dev, int64_t x_ld, int x_off, int64_t x_plane, int n, int h, int w,
-                               int C, void* out_dev, int64_t out_ld, int out_off, int64_t out_plane, void* stream);
+                                       void* stream);
+/* 3x3 / stride 2 max pool, split tensor -> split tensor (channel slice [out_off, out_off + C) of out; C % 8 == 0). */
+int tise_maxpool3s2_split_nhwc(const void* x_dev, int64_t x_ld, int x_off, int n, int h, int w,
+                               int C, void* out_dev, int64_t out_ld, int out_off, void* stream);
 
 /* Stem layer Conv2d_1a_3x3 (3 -> 32, 3x3, stride 2) from the fp32 NHWC input (n, h, w, 3), folded bias +
- * ReLU + fp16 split fused: out planes (n, oh, ow, 32).  w_dev: [kh][kw][cin][cout] fp32 (27 x 32). */
+ * ReLU + fp16 split fused: out = split tensor (n, oh, ow, 32).  w_dev: [kh][kw][cin][cout] fp32 (27 x 32). */
 int tise_stem_conv3x3s2_split(const float* x_dev, int n, int h, int w, const float* w_dev, const float* bias_dev,
-                              void* out_dev, int64_t out_plane, void* stream);
+                              void* out_dev, void* stream);
 /* The same layer from the uint8 NHWC result of tise_resize_bilinear_u8 (called with dst_dev = NULL and u8_out_dev set):
  * lut_dev is the 3 x 256 fp32 table (device copy) that ToTensor + the inception.py:120-124 affine tabulate, applied
  * while loading; bit-identical to the fp32 entry point on the table's values. */
 int tise_stem_conv3x3s2_split_u8(const uint8_t* x_dev, const float* lut_dev, int n, int h, int w, const float* w_dev,
-                                 const float* bias_dev, void* out_dev, int64_t out_plane, void* stream);
-/* Global average of split planes (n, hw, C) -> fp32 (n, C): AdaptiveAvgPool2d((1,1)) of the last block. */
-int tise_split_mean_nhwc(const void* x_dev, int64_t x_plane, int n, int hw, int C, float* out_dev, void* stream);
+                                 const float* bias_dev, void* out_dev, void* stream);
+/* Global average of a split tensor (n, hw, C), C % 32 == 0 -> fp32 (n, C): AdaptiveAvgPool2d((1,1)) of the last block. */
+int tise_split_mean_nhwc(const void* x_dev, int n, int hw, int C, float* out_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (a11, section 8 f3) Top-1 text retrieval for R-precision and the 2-way softmax test of PA.
@@ -247,38 +249,38 @@ int tise_gather_rows_f16(const void* x_dev, const int64_t* index_dev, int64_t n,
 
 /* ------------------------------------------------------------------------------------------
  * (a5, convolution) Implicit-GEMM convolution on fp16 MFMA with 3-term split-precision operands.
- * Replaces the Conv2d + BatchNorm(eval) + ReLU of torchvision's BasicConv2d for NHWC tensors held as
- * two fp16 planes (v ~= hi + lo * 2^-11): D = max(scale * conv(x, w) + bias, 0), re-split and written
+ * Replaces the Conv2d + BatchNorm(eval) + ReLU of torchvision's BasicConv2d for split tensors (layout above;
+ * v ~= hi + lo * 2^-11): D = max(scale * conv(x, w) + bias, 0), re-split and written
  * into up to four destination channel slices (mode 0), or raw fp32 scale*conv (mode 1, pool branch).
  * `args` points to a host-side tise_conv_args (copied into the launch).  `tn` = tile width | kernel variant:
- * the low four bits give the output tile, 128 pixels x 32*tn channels with tn in {1..5} (tn = 1 only with the
- * DMA variants); weights and scale/bias must be padded to a multiple of 32*tn rows and of 32 in K.
- * Variant bits (same arithmetic; 0, 16 and 128 give bit-identical results):
- *   0    operands staged through registers (reference kernel of the tests)
- *   16   direct-to-LDS DMA, two stages (generic K order; also serves M >= 2^31)
- *   128  DMA with the address arithmetic hoisted out of the K loop, K order (tap, 32-channel block) + paired
- *        16-channel tails (the default of the Python layer; falls back to 16 when the packing differs)
- *   512  conv_pipe.hip: the low eight bits select a configuration (33: resident-weights sliding-window kernel
- *        for Cin = 32 3x3 stride 1; 45-47: wave-specialised 256-pixel tiles); weights packed
- *        [cout][tap][Cin rounded up to 32], rows padded to the configuration's tile width.
- *   (Round 1's variants 32 / 64 / 256 and pipe configurations 0-15, 40-44 tied with 128 and were removed.)
+ * the low four bits give the output tile, 128 pixels x 32*tn channels with tn in {1..5}; weights and
+ * scale/bias must be padded to a multiple of 32*tn rows and of 32 in K.
+ * Variant bits (same arithmetic; 16 and 128 give bit-identical results when Cin % 32 == 0):
+ *   16   direct-to-LDS DMA, two stages, addresses recomputed per K-step (generic form: the reference kernel of
+ *        the tests, also serves M >= 2^31); weights fp16 [2][Cout_pad][Kpad] (hi plane, lo plane w_plane further)
+ *        K = (kh, kw, cin) with cin fastest.
+ *   128  DMA with the address arithmetic hoisted out of the K loop (the default of the Python layer; M < 2^31,
+ *        H, W < 16128); weights fp16 [Cout_pad][Kpad / 32][hi x32 | lo x32], K order (tap, 32-channel block) for
+ *        all taps, then -- Cin % 32 == 16 -- the 16-channel tails two taps per 32-wide step.
+ *   512  conv_pipe.hip configuration 33: resident-weights sliding-window kernel for Cin = 32 3x3 stride 1;
+ *        weights as for 16.
+ *   (Round 1's variants 0 / 32 / 64 / 256 and the other pipe configurations tied with 128 and were removed.)
  * Bits 8..11 of args->nseg are measurement switches (tools/conv_ablate.py, tools/conv_stamps.py) and must be
  * zero in product calls.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
-    int c0, c1;             /* output-channel range [c0, c1) of this segment                           */
-    void* dst;              /* mode 0: fp16 hi plane (lo plane at dst + plane elements); mode 1: float* */
-    long long ld;           /* destination elements per pixel                                          */
-    long long plane;        /* elements between the hi and lo planes (mode 0)                          */
-    int off;                /* first destination channel                                               */
+    int c0, c1;             /* output-channel range [c0, c1) of this segment (c0 % 8 == 0)             */
+    void* dst;              /* mode 0: split tensor (layout above); mode 1: float*                     */
+    long long ld;           /* mode 0: channel count C of the destination tensor (a pixel is 4*C bytes);
+                               mode 1: destination floats per pixel                                    */
+    int off;                /* first destination channel (mode 0: % 8 == 0, mode 1: % 4 == 0)          */
     int mode;
 } tise_conv_seg;
 
 typedef struct {
-    const void* x;          /* fp16 [2][N][H][W][Cin]                                                  */
-    long long x_plane;
-    const void* w;          /* fp16 [2][Cout_pad][Kpad], K = (kh, kw, cin) with cin fastest            */
-    long long w_plane;
+    const void* x;          /* split tensor [N][H][W][Cin], layout above                               */
+    const void* w;          /* fp16 weights, K = (kh, kw, cin) in the order described above            */
+    long long w_plane;      /* variants 16 / 512: elements between the hi and lo weight planes         */
     const float* scale;     /* [Cout_pad] un-scaling of the (power-of-two pre-scaled) weights          */
     const float* bias;      /* [Cout_pad]                                                              */
     int N, H, W, Cin, KH, KW, SH, SW, PH, PW, OH, OW;
@@ -290,9 +292,9 @@ typedef struct {
 
 int tise_conv_split_f16(const tise_conv_args* args, int tn, void* stream);
 
-/* Range guard of the split format: every kernel that writes split planes (the convolution epilogues, the stem
+/* Range guard of the split format: every kernel that writes split tensors (the convolution epilogues, the stem
  * convolution, the average-pool tail) raises a per-device flag when a value it converts exceeds the fp16 range
- * (65504; it would become +inf in the hi plane) or is NaN.  Reads the flag into *flag_host (0 / 1), clears it and
+ * (65504; it would become +inf in the hi half) or is NaN.  Reads the flag into *flag_host (0 / 1), clears it and
  * synchronises `stream`.  The Python mirror calls it once per image set and raises FloatingPointError. */
 int tise_split_overflow_check(int* flag_host, void* stream);
 

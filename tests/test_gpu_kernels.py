@@ -387,9 +387,11 @@ def test_fused_trunk_matches_module_graph(dev, dims):
 @pytest.mark.parametrize("shape", [(17, 17, 160, 160, 1, 7, 1, (0, 3)), (35, 35, 48, 64, 5, 5, 1, (2, 2)),
                                    (35, 35, 288, 384, 3, 3, 2, (0, 0)), (9, 9, 80, 192, 3, 3, 1, (0, 0)),
                                    (8, 8, 320, 1344, 1, 1, 1, (0, 0)), (11, 7, 32, 48, 3, 3, 1, (1, 1))])
-def test_conv_split_matches_fp64_conv(dev, shape):
+@pytest.mark.parametrize("variant", ["fast", "glds"])
+def test_conv_split_matches_fp64_conv(dev, shape, variant):
     """3-term split fp16 MFMA conv vs an fp64 convolution: fp32-class accuracy (|err| <= 4e-6 of the
-    output scale), including M/N/K tails, padding, stride, channel counts with Cin % 32 == 16."""
+    output scale), including M/N/K tails, padding, stride, channel counts with Cin % 32 == 16 (input AND
+    destination tensors with a 16-channel tail block), for the default and the generic kernel."""
     from tise_toolbox_amd.conv_split import SplitConv, merge, split
     H, W, Cin, Cout, kh, kw, st, pad = shape
     g = torch.Generator(device="cpu").manual_seed(Cin + Cout)
@@ -397,9 +399,9 @@ def test_conv_split_matches_fp64_conv(dev, shape):
     x = (torch.rand((n, H, W, Cin), generator=g) * 3.0).to(dev)
     w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
     b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
-    conv = SplitConv(w, b, (st, st), pad, dev)
+    conv = SplitConv(w, b, (st, st), pad, dev, variant=variant)
     oh, ow = conv.out_hw(H, W)
-    out = torch.zeros((2, n, oh, ow, Cout + 32), dtype=torch.float16, device=dev)
+    out = torch.zeros((n, oh, ow, 2 * (Cout + 32)), dtype=torch.float16, device=dev)
     raw = torch.zeros((n, oh, ow, 16), dtype=torch.float32, device=dev)
     # three destinations: a shifted slice of a wider tensor, a raw fp32 slice, the rest
     conv(split(x), [(0, 16, out, 16, 0), (16, 32, raw, 0, 1), (32, Cout, out, 64, 0)])
@@ -426,7 +428,7 @@ def test_split_pool_ops(dev):
     assert torch.equal(merge(got), want.contiguous())
     raw = torch.randn((2, 9, 11, 32), generator=g).to(dev)
     bias = torch.randn(32, generator=g).to(dev)
-    out = torch.zeros((2, 2, 9, 11, 64), dtype=torch.float16, device=dev)
+    out = torch.zeros((2, 9, 11, 2 * 64), dtype=torch.float16, device=dev)
     SplitTrunk._avgpool_split(raw, bias, out, 16)
     want = torch.relu(F.avg_pool2d(raw.permute(0, 3, 1, 2), 3, 1, 1) + bias.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
     assert (merge(out)[..., 16:48] - want).abs().max().item() <= 2e-6 * want.abs().max().item()
@@ -446,10 +448,11 @@ def test_split_trunk_matches_module_graph(dev):
     assert err <= 2e-4 * want.abs().max().item(), err
 
 
-@pytest.mark.parametrize("variant", ["reg", "glds", "fast"])
+@pytest.mark.parametrize("variant", ["glds", "fast"])
 def test_conv_split_variants_bitwise_identical_and_repeatable(dev, variant):
-    """All kernel variants implement the same arithmetic in the same order: outputs must be bit-identical to
-    the register-staged kernel, run after run (a DMA/LDS race would show up as a mismatch)."""
+    """Both kernels implement the same arithmetic in the same order when Cin % 32 == 0 (two independent addressing
+    schemes, LDS layouts and weight packings): outputs must be bit-identical to the generic kernel's, run after run
+    (a DMA/LDS race would show up as a mismatch)."""
     from tise_toolbox_amd.conv_split import SplitConv, split
     g = torch.Generator(device="cpu").manual_seed(7)
     for (n, H, W, Cin, Cout, kh, kw, st, pad) in [(37, 17, 17, 128, 192, 7, 1, 1, (3, 0)), (3, 35, 35, 64, 96, 3, 3, 1, (1, 1)),
@@ -457,76 +460,16 @@ def test_conv_split_variants_bitwise_identical_and_repeatable(dev, variant):
         x = (torch.rand((n, H, W, Cin), generator=g) * 2.0).to(dev)
         w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
         b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
-        conv = SplitConv(w, b, (st, st), pad, dev)
         xs = split(x)
-        oh, ow = conv.out_hw(H, W)
-        conv.variant = "reg"
-        ref = torch.zeros((2, n, oh, ow, Cout), dtype=torch.float16, device=dev)
-        conv(xs, [(0, Cout, ref, 0, 0)])
-        conv.variant = variant
+        gen = SplitConv(w, b, (st, st), pad, dev, variant="glds")
+        oh, ow = gen.out_hw(H, W)
+        ref = torch.zeros((n, oh, ow, 2 * Cout), dtype=torch.float16, device=dev)
+        gen(xs, [(0, Cout, ref, 0, 0)])
+        conv = SplitConv(w, b, (st, st), pad, dev, variant=variant)
         for rep in range(6):
             out = torch.full_like(ref, 7.0)
             conv(xs, [(0, Cout, out, 0, 0)])
             assert torch.equal(out, ref), (variant, rep, (n, H, W, Cin, Cout))
-
-
-@pytest.mark.parametrize("case", [(17, 17, 160, 160, 1, 7, 1, (0, 3), 45),
-                                  (35, 35, 288, 384, 3, 3, 2, (0, 0), 45), (9, 9, 64, 80, 1, 1, 1, (0, 0), 46),
-                                  (8, 8, 320, 1344, 1, 1, 1, (0, 0), 47), (13, 13, 96, 208, 1, 1, 1, (0, 0), 47),
-                                  (11, 7, 32, 48, 3, 3, 1, (1, 1), 46)])
-def test_conv_spec_kernels_match_fp64_conv(dev, case):
-    """conv_pipe.hip wave-specialised kernel (eight compute waves, four DMA / descriptor waves, one barrier per K-step):
-    every remaining configuration (45-47, the opt-in TISE_CONV_AUTO table) against fp64, including 1- and 2-step tiles (the service waves then run up to three tiles
-    ahead of the epilogues that read their descriptors), M and Cout tails, three segments, repeatability."""
-    from tise_toolbox_amd.conv_split import SplitConv, merge, split
-    H, W, Cin, Cout, kh, kw, st, pad, cfg = case
-    g = torch.Generator(device="cpu").manual_seed(Cin + Cout + kh + cfg)
-    n = 41
-    x = (torch.rand((n, H, W, Cin), generator=g) * 3.0).to(dev)
-    w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
-    b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
-    conv = SplitConv(w, b, (st, st), pad, dev, variant="pipe", pipe_cfg=cfg)
-    oh, ow = conv.out_hw(H, W)
-    ref_lin = torch.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, st, pad).permute(0, 2, 3, 1)
-    ref = torch.relu(ref_lin + b.double())
-    scale = ref.abs().max().item()
-    first = None
-    for rep in range(3):
-        out = torch.zeros((2, n, oh, ow, Cout + 32), dtype=torch.float16, device=dev)
-        raw = torch.zeros((n, oh, ow, 16), dtype=torch.float32, device=dev)
-        segs = [(0, 16, out, 16, 0), (16, 32, raw, 0, 1)] + ([(32, Cout, out, 64, 0)] if Cout > 32 else [])
-        conv(split(x), segs)
-        got = merge(out)
-        assert (got[..., 16:32].double() - ref[..., 0:16]).abs().max().item() <= 4e-6 * scale
-        if Cout > 32:
-            assert (got[..., 64:].double() - ref[..., 32:]).abs().max().item() <= 4e-6 * scale
-        assert (raw.double() - ref_lin[..., 16:32]).abs().max().item() <= 4e-6 * scale
-        assert got[..., :16].abs().max().item() == 0 and got[..., 32:64].abs().max().item() == 0
-        if first is None:
-            first = (out.clone(), raw.clone())
-        else:
-            assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
-
-
-def test_conv_spec_many_tiles_bitwise_vs_default(dev):
-    """More tiles than compute units through the wave-specialised kernels (the DMA cursor crosses tile boundaries two
-    K-steps ahead of the MFMAs; 256-pixel tiles stage their epilogue in the stage the last step consumed): same K
-    order as the default kernel, so the outputs must be bit-identical, run after run."""
-    from tise_toolbox_amd.conv_split import SplitConv, split
-    g = torch.Generator(device="cpu").manual_seed(13)
-    for (n, H, Cin, Cout, kh, cfg) in [(500, 17, 128, 128, 1, 45), (500, 17, 96, 160, 1, 47), (300, 9, 64, 64, 3, 46),
-                                        (500, 8, 256, 240, 1, 45)]:
-        x = (torch.rand((n, H, H, Cin), generator=g) * 2.0).to(dev)
-        w = (torch.randn((Cout, Cin, kh, kh), generator=g) * (2.0 / (Cin * kh * kh)) ** 0.5).to(dev)
-        b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
-        xs = split(x)
-        ref = torch.zeros((2, n, H, H, Cout), dtype=torch.float16, device=dev)
-        SplitConv(w, b, (1, 1), (kh // 2, kh // 2), dev, variant="fast")(xs, [(0, Cout, ref, 0, 0)])
-        conv = SplitConv(w, b, (1, 1), (kh // 2, kh // 2), dev, variant="pipe", pipe_cfg=cfg)
-        for rep in range(3):
-            out = torch.full_like(ref, 3.0)
-            conv(xs, [(0, Cout, out, 0, 0)])
-            assert torch.equal(out, ref), (cfg, rep)
 
 
 def test_split_trunk_batch_sizes_and_determinism(dev):
@@ -552,7 +495,7 @@ def test_conv_split_rejects_misaligned_segments(dev):
     w = torch.randn((64, 32, 1, 1), device=dev)
     conv = SplitConv(w, torch.zeros(64, device=dev), (1, 1), (0, 0), dev)
     x = split(torch.rand((2, 5, 5, 32), device=dev))
-    out = torch.zeros((2, 2, 5, 5, 80), dtype=torch.float16, device=dev)
+    out = torch.zeros((2, 5, 5, 2 * 80), dtype=torch.float16, device=dev)
     conv(x, [(0, 32, out, 0, 0), (32, 64, out, 40, 0)])                     # fine
     for segs in ([(0, 28, out, 0, 0), (28, 64, out, 32, 0)],               # boundary not a multiple of 8
                  [(0, 32, out, 4, 0), (32, 64, out, 40, 0)],               # destination offset not 16-byte aligned
@@ -583,7 +526,7 @@ def test_conv_win32_sliding_window_kernel(dev, case):
     xs = split(x)
     first = None
     for rep in range(4):
-        out = torch.zeros((2, n, oh, ow, Cout + 32), dtype=torch.float16, device=dev)
+        out = torch.zeros((n, oh, ow, 2 * (Cout + 32)), dtype=torch.float16, device=dev)
         raw = torch.zeros((n, oh, ow, 16), dtype=torch.float32, device=dev)
         segs = [(0, 16, out, 16, 0), (16, 32, raw, 0, 1)] + ([(32, Cout, out, 64, 0)] if Cout > 32 else [])
         conv(xs, segs)
@@ -625,7 +568,7 @@ def test_conv_split_dynamic_range_and_heavy_tails_vs_fp64(dev, case):
     device.read_split_overflow()
     conv = SplitConv(w, b, (1, 1), pad, dev)
     oh, ow = conv.out_hw(H, W)
-    out = torch.zeros((2, n, oh, ow, Cout), dtype=torch.float16, device=dev)
+    out = torch.zeros((n, oh, ow, 2 * Cout), dtype=torch.float16, device=dev)
     conv(split(x), [(0, Cout, out, 0, 0)])
     assert not device.read_split_overflow()
     got = merge(out).double()
@@ -651,7 +594,7 @@ def test_split_format_small_value_floor(dev):
 
 
 def test_split_overflow_guard_fires_and_clears(dev):
-    """A value above 65504 (or a NaN) converted into split planes raises the device flag: conv epilogue, stem, and the
+    """A value above 65504 (or a NaN) converted into a split tensor raises the device flag: conv epilogue, stem, and the
     engine turns it into FloatingPointError instead of silently carrying +inf through the trunk."""
     from tise_toolbox_amd import device
     from tise_toolbox_amd.conv_split import SplitConv, merge, split
@@ -660,20 +603,23 @@ def test_split_overflow_guard_fires_and_clears(dev):
     w = torch.full((64, 32, 1, 1), 1.0, device=dev)
     b = torch.zeros(64, device=dev)
     conv = SplitConv(w, b, (1, 1), (0, 0), dev)
-    out = torch.zeros((2, 2, 9, 9, 64), dtype=torch.float16, device=dev)
+    out = torch.zeros((2, 9, 9, 2 * 64), dtype=torch.float16, device=dev)
     conv(split(x), [(0, 64, out, 0, 0)])                       # 32 * 300 = 9 600: fine
     assert not device.read_split_overflow() and float(merge(out).max()) == 9600.0
     conv(split(x * 8), [(0, 64, out, 0, 0)])                   # 76 800 > 65 504
-    assert not torch.isfinite(merge(out)).all()                # hi = +inf, lo = -inf: the planes merge to NaN
+    assert not torch.isfinite(merge(out)).all()                # hi = +inf, lo = -inf: the halves merge to NaN
     assert device.read_split_overflow()
     assert not device.read_split_overflow()                    # read-and-clear
     with pytest.raises(FloatingPointError, match="fp16 range"):
         conv(split(x * 8), [(0, 64, out, 0, 0)])
         device.check_split_overflow()
-    for variant, cfg in (("reg", None), ("glds", None), ("pipe", 45)):
-        c2 = SplitConv(w, b, (1, 1), (0, 0), dev, variant=variant, pipe_cfg=cfg)
-        c2(split(x * 8), [(0, 64, out, 0, 0)])
-        assert device.read_split_overflow(), variant
+    c2 = SplitConv(w, b, (1, 1), (0, 0), dev, variant="glds")
+    c2(split(x * 8), [(0, 64, out, 0, 0)])
+    assert device.read_split_overflow(), "glds"
+    c3 = SplitConv(torch.full((32, 32, 3, 3), 1.0, device=dev), torch.zeros(32, device=dev), (1, 1), (1, 1), dev, variant="pipe", pipe_cfg=33)
+    out3 = torch.zeros((2, 9, 9, 2 * 32), dtype=torch.float16, device=dev)
+    c3(split(x * 8), [(0, 32, out3, 0, 0)])
+    assert device.read_split_overflow(), "win32"
     # engine level: huge stand-in scale in the first conv -> FloatingPointError at statistics() time
     from tise_toolbox_amd.engine import RealismEngine
     from tise_toolbox_amd.inception import InceptionV3

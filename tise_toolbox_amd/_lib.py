@@ -75,16 +75,14 @@ SIGNATURES = {
                                               c_int64, c_int, c_void_p]),
     "tise_maxpool3s2_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64,
                                       c_int, c_void_p]),
-    "tise_bias_relu_split_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_void_p, c_void_p, c_int64, c_int,
-                                           c_int64, c_void_p]),
     "tise_avgpool3_bias_relu_split_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
-                                                    c_void_p, c_int64, c_int, c_int64, c_void_p]),
-    "tise_maxpool3s2_split_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p,
-                                            c_int64, c_int, c_int64, c_void_p]),
-    "tise_stem_conv3x3s2_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
-    "tise_stem_conv3x3s2_split_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
+                                                    c_void_p, c_int64, c_int, c_void_p]),
+    "tise_maxpool3s2_split_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                            c_int64, c_int, c_void_p]),
+    "tise_stem_conv3x3s2_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "tise_stem_conv3x3s2_split_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p]),
-    "tise_split_mean_nhwc": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "tise_split_mean_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tise_conv_split_f16": (c_int, [c_void_p, c_int, c_void_p]),
     "tise_split_overflow_check": (c_int, [POINTER(c_int), c_void_p]),
     "tise_gemm_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,

@@ -1,7 +1,10 @@
 """Host side of the split-precision fp16-MFMA convolution (csrc/conv_split.hip).
 
-A value v is carried as two fp16 numbers, v ~= hi + lo * 2**-11.  ``split`` / ``merge`` convert between
-fp32 tensors and (2, ...) fp16 plane pairs; ``SplitConv`` packs BatchNorm-folded conv weights once
+A value v is carried as two fp16 numbers, v ~= hi + lo * 2**-11.  A split tensor of C channels is an fp16 tensor
+(..., 2*C): NHWC, inside a pixel the channels in blocks of 32 with the halves side by side -- [hi x32 | lo x32] per
+block, one 128-byte line = one K-step of the convolution -- and a last block [hi x16 | lo x16] when C % 32 == 16
+(csrc/common.h).  ``split`` / ``merge`` convert between fp32 (..., C) and that form, ``new_split`` allocates one;
+``SplitConv`` packs BatchNorm-folded conv weights once
 (power-of-two per-channel scaling so the fp16 halves stay normal, K = (kh, kw, cin) with cin fastest,
 zero padding to the kernel's tile multiples) and launches ``tise_conv_split_f16``.
 """
@@ -17,11 +20,11 @@ LO_SCALE = 2048.0   # 2**11
 
 class ConvSeg(ctypes.Structure):
     _fields_ = [("c0", ctypes.c_int), ("c1", ctypes.c_int), ("dst", ctypes.c_void_p), ("ld", ctypes.c_longlong),
-                ("plane", ctypes.c_longlong), ("off", ctypes.c_int), ("mode", ctypes.c_int)]
+                ("off", ctypes.c_int), ("mode", ctypes.c_int)]
 
 
 class ConvArgs(ctypes.Structure):
-    _fields_ = [("x", ctypes.c_void_p), ("x_plane", ctypes.c_longlong), ("w", ctypes.c_void_p),
+    _fields_ = [("x", ctypes.c_void_p), ("w", ctypes.c_void_p),
                 ("w_plane", ctypes.c_longlong), ("scale", ctypes.c_void_p), ("bias", ctypes.c_void_p),
                 ("N", ctypes.c_int), ("H", ctypes.c_int), ("W", ctypes.c_int), ("Cin", ctypes.c_int),
                 ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("SH", ctypes.c_int), ("SW", ctypes.c_int),
@@ -30,15 +33,61 @@ class ConvArgs(ctypes.Structure):
                 ("nseg", ctypes.c_int), ("seg", ConvSeg * 4)]
 
 
-def split(x):
-    """fp32 tensor -> (2, *x.shape) fp16: plane 0 = hi, plane 1 = (x - hi) * 2**11."""
+def split_planes(x):
+    """fp32 tensor -> (2, *x.shape) fp16: plane 0 = hi, plane 1 = (x - hi) * 2**11 (the weight format of the generic kernel)."""
     hi = x.half()
     lo = ((x - hi.float()) * LO_SCALE).half()
     return torch.stack([hi, lo], 0)
 
 
-def merge(planes):
-    return planes[0].float() + planes[1].float() * (1.0 / LO_SCALE)
+def _interleave(hi, lo):
+    """(..., C) hi / lo -> (..., 2C) in the layout of csrc/common.h."""
+    C = hi.shape[-1]
+    assert C % 16 == 0, "split tensors need C % 16 == 0"
+    full = C & ~31
+    lead = hi.shape[:-1]
+    parts = []
+    if full:
+        blk = torch.stack([hi[..., :full].reshape(*lead, full // 32, 32), lo[..., :full].reshape(*lead, full // 32, 32)], -2)
+        parts.append(blk.reshape(*lead, 2 * full))
+    if C > full:
+        parts.append(torch.cat([hi[..., full:], lo[..., full:]], -1))
+    return torch.cat(parts, -1).contiguous() if len(parts) > 1 else parts[0].contiguous()
+
+
+def split(x):
+    """fp32 (..., C) -> split tensor (..., 2C) fp16."""
+    hi = x.half()
+    lo = ((x - hi.float()) * LO_SCALE).half()
+    return _interleave(hi, lo)
+
+
+def halves(t):
+    """split tensor (..., 2C) -> (hi, lo), each (..., C) fp16."""
+    C = t.shape[-1] // 2
+    full = C & ~31
+    lead = t.shape[:-1]
+    his, los = [], []
+    if full:
+        blk = t[..., :2 * full].reshape(*lead, full // 32, 2, 32)
+        his.append(blk[..., 0, :].reshape(*lead, full))
+        los.append(blk[..., 1, :].reshape(*lead, full))
+    if C > full:
+        his.append(t[..., 2 * full:2 * full + (C - full)])
+        los.append(t[..., 2 * full + (C - full):])
+    return torch.cat(his, -1), torch.cat(los, -1)
+
+
+def merge(t):
+    """split tensor (..., 2C) -> fp32 (..., C)."""
+    hi, lo = halves(t)
+    return hi.float() + lo.float() * (1.0 / LO_SCALE)
+
+
+def new_split(n, h, w, c, device):
+    """Uninitialised split tensor of c channels."""
+    assert c % 16 == 0
+    return torch.empty((n, h, w, 2 * c), dtype=torch.float16, device=device)
 
 
 # relative efficiency of the kernel by tile width (tools/conv_split_probe.py): narrow tiles re-read the
@@ -58,28 +107,8 @@ def pick_tn(cout):
     return best[1]
 
 
-# conv_pipe.hip tile widths by configuration index, and the configuration for a given Cout: least padded work,
-# ties to the wider tile
-PIPE_BN = {33: 32, 45: 128, 46: 96, 47: 128}
-
-
-def pick_pipe_cfg(cout):
-    """Wave-specialised 256-pixel kernel: 96-cout tiles when they waste less padded work than 128-cout tiles."""
-    return 46 if -(-cout // 96) * 96 < -(-cout // 128) * 128 else 45
-
-
-# Optional per-layer kernel choice (TISE_CONV_AUTO=1), from tools/conv_pipe_probe.py on the trunk's shapes at batch 500
-# (medians of three runs, profiles/r01i_conv_spec256_probe.txt): in isolation, on dense random inputs, the
-# wave-specialised 256-pixel kernel of conv_pipe.hip (configuration 45: 4 x 2 compute waves of 64 x 64; 47: 8 x 1 of
-# 32 x 128) is 5-13 % faster than the default kernel on the deep 1x1 layers and on Mixed_6a's 3x3 stride-2 conv.
-# Inside the trunk (ReLU-sparse activations, kernels back to back) the gain shrinks to 1-3 % per layer and the bench
-# shows none (25.73 vs 25.69 ms/step over three alternating runs), so it is OFF by default.
-# Key: (Cin, Cout, KH, KW, stride).  Results are bit-identical either way (same K order).
-AUTO_PIPE_CFG = {
-    (768, 704, 1, 1, 1): 45, (768, 768, 1, 1, 1): 45, (768, 640, 1, 1, 1): 47, (768, 384, 1, 1, 1): 45,
-    (288, 240, 1, 1, 1): 45, (256, 240, 1, 1, 1): 47, (192, 208, 1, 1, 1): 45,
-    (2048, 1344, 1, 1, 1): 47, (1280, 1344, 1, 1, 1): 47, (288, 384, 3, 3, 2): 45,
-}
+# conv_pipe.hip: configuration 33 = resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1), 32 couts per launch
+PIPE_BN = {33: 32}
 
 
 class SplitConv:
@@ -97,19 +126,15 @@ class SplitConv:
         self.padding = tuple(padding)
         self.tn = tn or pick_tn(cout)
         self.pipe_cfg = None
-        # kernel variant: "fast" = LDS-DMA staging with hoisted addressing (default); "glds" = its generic form (any
-        # Cin % 16 == 0 / K order, M >= 2^31); "reg" = register-staged reference kernel (the bitwise baseline of the
-        # tests); "pipe" = conv_pipe.hip configurations (33: Conv2d_2a; 45-47: opt-in table below)
+        # kernel variant: "fast" = LDS-DMA staging with hoisted addressing (default); "glds" = its generic form
+        # (addresses recomputed per K-step, natural K order, any M: the reference kernel of the tests);
+        # "pipe" = conv_pipe.hip configuration 33 (Conv2d_2a)
         self.variant = variant or os.environ.get("TISE_CONV_VARIANT", "fast")
-        if self.variant not in ("fast", "glds", "reg", "pipe"):
-            raise ValueError(f"unknown conv variant {self.variant!r} (round 2 removed glds3 / gldsb / win)")
-        if variant is None and self.variant == "fast" and os.environ.get("TISE_CONV_AUTO", "0") == "1":
-            auto = AUTO_PIPE_CFG.get((cin, cout, kh, kw, self.stride[0]))
-            if auto is not None and self.stride[0] == self.stride[1]:
-                self.variant, pipe_cfg = "pipe", auto
+        if self.variant not in ("fast", "glds", "pipe"):
+            raise ValueError(f"unknown conv variant {self.variant!r} (round 2 removed reg / glds3 / gldsb / win / spec)")
         bn = 32 * self.tn
-        if self.variant == "pipe":                              # persistent 3-stage kernel (conv_pipe.hip)
-            self.pipe_cfg = pick_pipe_cfg(cout) if pipe_cfg is None else pipe_cfg
+        if self.variant == "pipe":                              # resident-weights sliding-window kernel (conv_pipe.hip)
+            self.pipe_cfg = 33 if pipe_cfg is None else pipe_cfg
             bn = PIPE_BN[self.pipe_cfg]
         self.cout_pad = -(-cout // bn) * bn
         self.k = kh * kw * cin
@@ -120,13 +145,8 @@ class SplitConv:
         wk = (w * pre.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(cout, self.k)
         wp = torch.zeros((self.cout_pad, self.kpad), dtype=torch.float32)
         wp[:cout, :self.k] = wk
-        self.w = split(wp).to(device).contiguous()                  # (2, Cout_pad, Kpad) fp16
-        if self.pipe_cfg is not None:                               # conv_pipe.hip: weights packed [tap][Cin rounded up to 32]
-            cin_pad = -(-cin // 32) * 32
-            ww = torch.zeros((self.cout_pad, kh * kw, cin_pad), dtype=torch.float32)
-            ww[:cout, :, :cin] = wk.reshape(cout, kh * kw, cin)
-            self.w = split(ww.reshape(self.cout_pad, -1)).to(device).contiguous()
-        elif self.variant == "fast" and cin % 32 == 16:
+        self.w = split_planes(wp).to(device).contiguous()           # (2, Cout_pad, Kpad) fp16
+        if self.variant == "fast" and cin % 32 == 16:
             # default kernel, Cin = 32 * nfull + 16: K order = (tap, full 32-channel block) for all taps, then the
             # 16-channel tails two taps per 32-wide step (conv_split.hip, conv_split_fast_kernel)
             ntaps, nfull = kh * kw, cin // 32
@@ -135,14 +155,15 @@ class SplitConv:
             full = w3[:, :, :nfull * 32].reshape(self.cout_pad, ntaps * nfull * 32)
             tails = torch.zeros((self.cout_pad, (ntaps + 1) // 2 * 2, 16), dtype=torch.float32)
             tails[:, :ntaps] = w3[:, :, nfull * 32:]
-            self.w = split(torch.cat([full, tails.reshape(self.cout_pad, -1)], 1)).to(device).contiguous()
+            self.w = split_planes(torch.cat([full, tails.reshape(self.cout_pad, -1)], 1)).to(device).contiguous()
             self.kpad = self.w.shape[2]
         # the default kernel reads the weights as ONE 128-byte line per (cout, 32-wide K block): [hi 32 | lo 32]
-        # (conv_split_fast_kernel: 128-byte LDS-DMA rows); the planar (2, Cout_pad, Kpad) copy serves "reg" / "glds"
+        # (conv_split_fast_kernel: 128-byte LDS-DMA rows); the planar (2, Cout_pad, Kpad) form serves "glds" / "pipe"
         self.w_fast = None
-        if self.pipe_cfg is None:
+        if self.variant == "fast":
             hi, lo = self.w[0], self.w[1]
             self.w_fast = torch.stack([hi.reshape(self.cout_pad, -1, 32), lo.reshape(self.cout_pad, -1, 32)], 2).contiguous()
+            self.w = None
         sc = torch.zeros(self.cout_pad, dtype=torch.float32)
         sc[:cout] = 1.0 / pre
         bs = torch.zeros(self.cout_pad, dtype=torch.float32)
@@ -156,15 +177,15 @@ class SplitConv:
         return oh, ow
 
     def __call__(self, x, segs):
-        """x: (2, N, H, W, Cin) fp16 planes.  segs: list of (c0, c1, dst_tensor, dst_off, mode):
-        mode 0 -> dst is a (2, N, OH, OW, C) fp16 plane pair, mode 1 -> dst is a (N, OH, OW, C) fp32 tensor."""
-        assert x.dtype == torch.float16 and x.dim() == 5 and x.shape[4] == self.cin and x.is_contiguous()
-        _, n, h, w, _ = x.shape
+        """x: split tensor (N, H, W, 2*Cin) fp16.  segs: list of (c0, c1, dst_tensor, dst_off, mode):
+        mode 0 -> dst is a split tensor (N, OH, OW, 2*C), mode 1 -> dst is a (N, OH, OW, C) fp32 tensor."""
+        assert x.dtype == torch.float16 and x.dim() == 4 and x.shape[3] == 2 * self.cin and x.is_contiguous()
+        n, h, w, _ = x.shape
         oh, ow = self.out_hw(h, w)
         a = ConvArgs()
-        a.x = x.data_ptr(); a.x_plane = x.stride(0)
-        wt = self.w_fast if (self.variant == "fast" and self.w_fast is not None) else self.w
-        a.w = wt.data_ptr(); a.w_plane = self.w.stride(0)
+        a.x = x.data_ptr()
+        wt = self.w_fast if self.w_fast is not None else self.w
+        a.w = wt.data_ptr(); a.w_plane = 0 if self.w is None else self.w.stride(0)
         a.scale = self.scale.data_ptr(); a.bias = self.bias.data_ptr()
         a.N, a.H, a.W, a.Cin = n, h, w, self.cin
         a.KH, a.KW, a.SH, a.SW, a.PH, a.PW = self.kh, self.kw, self.stride[0], self.stride[1], self.padding[0], self.padding[1]
@@ -177,11 +198,11 @@ class SplitConv:
             s.c0, s.c1, s.off, s.mode = c0, c1, off, mode
             s.dst = dst.data_ptr()
             if mode == 0:
-                assert dst.dtype == torch.float16 and dst.shape[1:4] == (n, oh, ow) and dst.is_contiguous()
-                s.ld, s.plane = dst.shape[4], dst.stride(0)
+                assert dst.dtype == torch.float16 and dst.shape[:3] == (n, oh, ow) and dst.is_contiguous()
+                s.ld = dst.shape[3] // 2
             else:
                 assert dst.dtype == torch.float32 and dst.shape[:3] == (n, oh, ow) and dst.is_contiguous()
-                s.ld, s.plane = dst.shape[3], 0
+                s.ld = dst.shape[3]
         if getattr(self, "debug_ptr", None):                    # tools/conv_stamps.py
             a.seg[3].dst = self.debug_ptr
         timer = SplitConv.timer
@@ -191,7 +212,7 @@ class SplitConv:
         if self.pipe_cfg is not None:
             code = 512 | self.pipe_cfg
         else:
-            code = self.tn | {"reg": 0, "glds": 16, "fast": 128}[self.variant]
+            code = self.tn | {"glds": 16, "fast": 128}[self.variant]
         _lib.call("tise_conv_split_f16", ctypes.byref(a), code,
                   ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         if timer is not None:

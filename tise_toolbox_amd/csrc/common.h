@@ -44,6 +44,21 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 
+// Layout of a split-fp16 activation tensor (v ~= hi + lo * 2^-11) in HBM: NHWC, and inside a pixel the channels in
+// blocks of 32 with the two halves of a block side by side,
+//        [hi c0..c31 | lo c0..c31] [hi c32..c63 | lo c32..c63] ...          128 bytes per block,
+// followed, when C % 32 == 16, by one 64-byte block [hi x16 | lo x16]; a pixel is 4*C bytes.  A K-step of the
+// convolution (32 channels of one filter tap, both halves) is therefore ONE 128-byte line per pixel: the LDS-DMA
+// path moves 128-byte rows at 38 B/clk/CU against 30 for 64-byte rows (profiles/r01g_glds_rate_microbench.txt), the
+// epilogues write whole lines, and the pooling kernels read both halves of a value from the same line.
+// tise_ilv_off: offset in fp16 elements of channel c's hi value inside its pixel; the lo value is tise_ilv_second
+// elements further.
+__host__ __device__ inline int tise_ilv_off(int c, int C) {
+    const int full = C & ~31;
+    return c < full ? (c >> 5) * 64 + (c & 31) : 2 * full + (c - full);
+}
+__host__ __device__ inline int tise_ilv_second(int c, int C) { return c < (C & ~31) ? 32 : 16; }
+
 // Range guard of the split-fp16 activation format (v ~= hi + lo * 2^-11, hi = fp16(v)): a value above the fp16
 // range (65504) would become +inf in the hi plane and poison every later layer without any visible failure.  Every
 // kernel that WRITES split planes keeps the running maximum of what it converts (one v_max per element; all values

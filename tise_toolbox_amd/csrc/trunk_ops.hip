@@ -102,7 +102,10 @@ __global__ __launch_bounds__(256) void maxpool3s2_nhwc_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------------
-// Split-fp16 variants (activations held as two fp16 planes, v ~= hi + lo * 2^-11; conv_split.hip).
+// Split-fp16 variants (activations v ~= hi + lo * 2^-11 in the interleaved layout of common.h: per pixel and
+// 32-channel block one 128-byte line [hi x32 | lo x32]; conv_split.hip).  All channel counts / offsets these kernels
+// see are multiples of 8 that do not straddle a block half, so the hi and the lo run of a thread's channels are
+// contiguous and tise_ilv_off / tise_ilv_second give their places.
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
 typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
@@ -116,28 +119,12 @@ __device__ __forceinline__ void split_store4(float4 v, _Float16* hi_p, _Float16*
     *reinterpret_cast<half4v*>(lo_p) = l;
 }
 
-// fp32 raw conv output (slice) -> max(x + b, 0) -> split planes (stem, after the MIOpen Cin=3 conv)
-__global__ __launch_bounds__(256) void bias_relu_split_kernel(const float* __restrict__ x, int64_t x_ld, int x_off,
-                                                              int64_t pixels, int C4, const float* __restrict__ bias,
-                                                              _Float16* __restrict__ out, int64_t out_ld, int out_off,
-                                                              int64_t out_plane) {
-    const int64_t total = pixels * C4;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = e / C4;
-        const int c4 = (int)(e - p * C4);
-        const float4 v = f4_bias_relu(*reinterpret_cast<const float4*>(x + p * x_ld + x_off + 4 * c4),
-                                      *reinterpret_cast<const float4*>(bias + 4 * c4));
-        _Float16* d = out + p * out_ld + out_off + 4 * c4;
-        split_store4(v, d, d + out_plane);
-    }
-}
-
-// fp32 raw 1x1-conv output (slice) -> 3x3/s1/p1 average (count_include_pad) + bias, ReLU -> split planes
+// fp32 raw 1x1-conv output (slice) -> 3x3/s1/p1 average (count_include_pad) + bias, ReLU -> split tensor slice
 __global__ __launch_bounds__(256) void avgpool3_bias_relu_split_kernel(const float* __restrict__ x, int64_t x_ld,
                                                                        int x_off, int N, int H, int W, int C4,
                                                                        const float* __restrict__ bias,
-                                                                       _Float16* __restrict__ out, int64_t out_ld,
-                                                                       int out_off, int64_t out_plane) {
+                                                                       _Float16* __restrict__ out, int out_C,
+                                                                       int out_off) {
     const int64_t total = (int64_t)N * H * W * C4;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t p = e / C4;
@@ -159,17 +146,17 @@ __global__ __launch_bounds__(256) void avgpool3_bias_relu_split_kernel(const flo
         }
         s.x /= 9.f; s.y /= 9.f; s.z /= 9.f; s.w /= 9.f;
         const float4 v = f4_bias_relu(s, *reinterpret_cast<const float4*>(bias + 4 * c4));
-        _Float16* d = out + p * out_ld + out_off + 4 * c4;
-        split_store4(v, d, d + out_plane);
+        const int ch = out_off + 4 * c4;
+        _Float16* d = out + p * (2 * (int64_t)out_C) + tise_ilv_off(ch, out_C);
+        split_store4(v, d, d + tise_ilv_second(ch, out_C));
     }
 }
 
-// split planes -> 3x3 / stride 2 max pool -> split planes (8 channels = 16 B per thread).  The value
+// split tensor -> 3x3 / stride 2 max pool -> split tensor slice (8 channels = 2 x 16 B per thread).  The value
 // hi + lo*2^-11 is exact in fp32, so the maximum is taken on it and its (hi, lo) pair is passed through.
-__global__ __launch_bounds__(256) void maxpool3s2_split_kernel(const _Float16* __restrict__ x, int64_t x_ld, int x_off,
-                                                               int64_t x_plane, int N, int H, int W, int C8,
-                                                               _Float16* __restrict__ out, int64_t out_ld, int out_off,
-                                                               int64_t out_plane) {
+__global__ __launch_bounds__(256) void maxpool3s2_split_kernel(const _Float16* __restrict__ x, int x_C, int x_off,
+                                                               int N, int H, int W, int C8,
+                                                               _Float16* __restrict__ out, int out_C, int out_off) {
     const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
     const int64_t total = (int64_t)N * OH * OW * C8;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -179,6 +166,7 @@ __global__ __launch_bounds__(256) void maxpool3s2_split_kernel(const _Float16* _
         const int oh = (int)((p / OW) % OH);
         const int64_t n = p / ((int64_t)OW * OH);
         const int64_t base = (n * H + 2 * oh) * W + 2 * ow;
+        const int xo = tise_ilv_off(x_off + 8 * c8, x_C), xs = tise_ilv_second(x_off + 8 * c8, x_C);
         half8v bh, bl;
         float bv[8];
 #pragma unroll
@@ -187,18 +175,19 @@ __global__ __launch_bounds__(256) void maxpool3s2_split_kernel(const _Float16* _
         for (int dh = 0; dh < 3; ++dh)
 #pragma unroll
             for (int dw = 0; dw < 3; ++dw) {
-                const _Float16* q = x + (base + (int64_t)dh * W + dw) * x_ld + x_off + 8 * c8;
+                const _Float16* q = x + (base + (int64_t)dh * W + dw) * (2 * (int64_t)x_C) + xo;
                 const half8v vh = *reinterpret_cast<const half8v*>(q);
-                const half8v vl = *reinterpret_cast<const half8v*>(q + x_plane);
+                const half8v vl = *reinterpret_cast<const half8v*>(q + xs);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float v = (float)vh[i] + (float)vl[i] * (1.f / 2048.f);
                     if (v > bv[i]) { bv[i] = v; bh[i] = vh[i]; bl[i] = vl[i]; }
                 }
             }
-        _Float16* d = out + p * out_ld + out_off + 8 * c8;
+        const int ch = out_off + 8 * c8;
+        _Float16* d = out + p * (2 * (int64_t)out_C) + tise_ilv_off(ch, out_C);
         *reinterpret_cast<half8v*>(d) = bh;
-        *reinterpret_cast<half8v*>(d + out_plane) = bl;
+        *reinterpret_cast<half8v*>(d + tise_ilv_second(ch, out_C)) = bl;
     }
 }
 
@@ -208,11 +197,11 @@ __global__ __launch_bounds__(256) void maxpool3s2_split_kernel(const _Float16* _
 // implicit-GEMM kernel (which needs Cin % 16 == 0), and through MIOpen this layer cost a conv launch, a
 // zero-fill launch and a separate bias/ReLU/split pass; here it is one HBM-bound pass (fp32 FMA chains in
 // (kh, kw, cin) order).  Thread = (output pixel, 8 output channels); four lanes share a pixel so a pixel's
-// 32 channels leave as one 64-byte run per plane.  Weights: w[kh][kw][cin][cout] fp32 in LDS.
+// 32 channels leave as one 128-byte line [hi x32 | lo x32].  Weights: w[kh][kw][cin][cout] fp32 in LDS.
 __global__ __launch_bounds__(256) void stem_conv3x3s2_split_kernel(const float* __restrict__ x, int N, int H, int W,
                                                                    const float* __restrict__ wt,   // [27][32]
                                                                    const float* __restrict__ bias, // [32]
-                                                                   _Float16* __restrict__ out, int64_t out_plane) {
+                                                                   _Float16* __restrict__ out) {
     __shared__ float ws[27 * 32];
     for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = wt[i];
     __syncthreads();
@@ -249,9 +238,9 @@ __global__ __launch_bounds__(256) void stem_conv3x3s2_split_kernel(const float* 
             l[c] = (_Float16)((v - (float)h[c]) * 2048.f);
         }
         tise_flag_split_overflow(vmax);
-        _Float16* d = out + p * 32 + cg;
+        _Float16* d = out + p * 64 + cg;
         *reinterpret_cast<half8v*>(d) = h;
-        *reinterpret_cast<half8v*>(d + out_plane) = l;
+        *reinterpret_cast<half8v*>(d + 32) = l;
     }
 }
 
@@ -260,7 +249,7 @@ __global__ __launch_bounds__(256) void stem_conv3x3s2_split_kernel(const float* 
 __global__ __launch_bounds__(256) void stem_conv3x3s2_split_u8_kernel(const uint8_t* __restrict__ x, const float* __restrict__ lut, int N, int H, int W,
                                                                    const float* __restrict__ wt,   // [27][32]
                                                                    const float* __restrict__ bias, // [32]
-                                                                   _Float16* __restrict__ out, int64_t out_plane) {
+                                                                   _Float16* __restrict__ out) {
     __shared__ float ws[27 * 32];
     __shared__ float lut_s[3 * 256];                         // byte -> network input value per channel (device.make_lut)
     for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = wt[i];
@@ -299,31 +288,32 @@ __global__ __launch_bounds__(256) void stem_conv3x3s2_split_u8_kernel(const uint
             l[c] = (_Float16)((v - (float)h[c]) * 2048.f);
         }
         tise_flag_split_overflow(vmax);
-        _Float16* d = out + p * 32 + cg;
+        _Float16* d = out + p * 64 + cg;
         *reinterpret_cast<half8v*>(d) = h;
-        *reinterpret_cast<half8v*>(d + out_plane) = l;
+        *reinterpret_cast<half8v*>(d + 32) = l;
     }
 }
 
-// split planes (N, HW, C) -> fp32 (N, C) mean over the HW positions (AdaptiveAvgPool2d((1,1)) of the last
-// block): thread = (image, 8 channels), fixed summation order.
-__global__ __launch_bounds__(256) void split_mean_kernel(const _Float16* __restrict__ x, int64_t x_plane, int N, int HW,
+// split tensor (N, HW, C), C % 32 == 0 -> fp32 (N, C) mean over the HW positions (AdaptiveAvgPool2d((1,1)) of the
+// last block): thread = (image, 8 channels), fixed summation order.
+__global__ __launch_bounds__(256) void split_mean_kernel(const _Float16* __restrict__ x, int N, int HW,
                                                          int C8, float* __restrict__ out) {
     const int64_t total = (int64_t)N * C8;
+    const int C = C8 * 8;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t n = e / C8;
         const int c8 = (int)(e - n * C8);
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-        const _Float16* q = x + n * HW * (int64_t)C8 * 8 + c8 * 8;
+        const _Float16* q = x + n * HW * (int64_t)C * 2 + tise_ilv_off(c8 * 8, C);
         for (int s = 0; s < HW; ++s) {
-            const half8v vh = *reinterpret_cast<const half8v*>(q + (int64_t)s * C8 * 8);
-            const half8v vl = *reinterpret_cast<const half8v*>(q + (int64_t)s * C8 * 8 + x_plane);
+            const half8v vh = *reinterpret_cast<const half8v*>(q + (int64_t)s * C * 2);
+            const half8v vl = *reinterpret_cast<const half8v*>(q + (int64_t)s * C * 2 + 32);
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] += (float)vh[i] + (float)vl[i] * (1.f / 2048.f);
         }
-        float* d = out + n * (int64_t)C8 * 8 + c8 * 8;
+        float* d = out + n * (int64_t)C + c8 * 8;
 #pragma unroll
         for (int i = 0; i < 8; ++i) d[i] = acc[i] / (float)HW;
     }
@@ -384,74 +374,61 @@ int tise_maxpool3s2_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int
     return TISE_OK;
 }
 
-int tise_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_off, int64_t pixels, int C, const float* bias_dev,
-                              void* out_dev, int64_t out_ld, int out_off, int64_t out_plane, void* stream) {
-    if (!x_dev || !bias_dev || !out_dev || pixels < 0 || C <= 0 || !aligned4(x_ld, x_off, C) ||
-        !aligned4(out_ld, out_off, C) || x_off + C > x_ld || out_off + C > out_ld)
-        return TISE_ERR_INVALID_ARG;
-    if (pixels == 0) return TISE_OK;
-    hipLaunchKernelGGL(bias_relu_split_kernel, dim3(grid_for(pixels * (C / 4))), dim3(256), 0, (hipStream_t)stream, x_dev,
-                       x_ld, x_off, pixels, C / 4, bias_dev, reinterpret_cast<_Float16*>(out_dev), out_ld, out_off,
-                       out_plane);
-    TISE_LAUNCH_CHECK();
-    return TISE_OK;
-}
-
 int tise_avgpool3_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
                                        const float* bias_dev, void* out_dev, int64_t out_ld, int out_off,
-                                       int64_t out_plane, void* stream) {
+                                       void* stream) {
     if (!x_dev || !bias_dev || !out_dev || n < 0 || h <= 0 || w <= 0 || C <= 0 || !aligned4(x_ld, x_off, C) ||
-        !aligned4(out_ld, out_off, C) || x_off + C > x_ld || out_off + C > out_ld)
+        !aligned4(out_ld, out_off, C) || out_ld % 16 || x_off + C > x_ld || out_off + C > out_ld || out_ld > 0x7fffffff)
         return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
     hipLaunchKernelGGL(avgpool3_bias_relu_split_kernel, dim3(grid_for((int64_t)n * h * w * (C / 4))), dim3(256), 0,
                        (hipStream_t)stream, x_dev, x_ld, x_off, n, h, w, C / 4, bias_dev,
-                       reinterpret_cast<_Float16*>(out_dev), out_ld, out_off, out_plane);
+                       reinterpret_cast<_Float16*>(out_dev), (int)out_ld, out_off);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
 
-int tise_maxpool3s2_split_nhwc(const void* x_dev, int64_t x_ld, int x_off, int64_t x_plane, int n, int h, int w, int C,
-                               void* out_dev, int64_t out_ld, int out_off, int64_t out_plane, void* stream) {
-    if (!x_dev || !out_dev || n < 0 || h < 3 || w < 3 || C <= 0 || C % 8 || x_ld % 8 || x_off % 8 || out_ld % 8 ||
-        out_off % 8 || x_off + C > x_ld || out_off + C > out_ld)
+int tise_maxpool3s2_split_nhwc(const void* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
+                               void* out_dev, int64_t out_ld, int out_off, void* stream) {
+    if (!x_dev || !out_dev || n < 0 || h < 3 || w < 3 || C <= 0 || C % 8 || x_ld % 16 || x_off % 8 || out_ld % 16 ||
+        out_off % 8 || x_off + C > x_ld || out_off + C > out_ld || x_ld > 0x7fffffff || out_ld > 0x7fffffff)
         return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
     hipLaunchKernelGGL(maxpool3s2_split_kernel, dim3(grid_for((int64_t)n * oh * ow * (C / 8))), dim3(256), 0,
-                       (hipStream_t)stream, reinterpret_cast<const _Float16*>(x_dev), x_ld, x_off, x_plane, n, h, w, C / 8,
-                       reinterpret_cast<_Float16*>(out_dev), out_ld, out_off, out_plane);
+                       (hipStream_t)stream, reinterpret_cast<const _Float16*>(x_dev), (int)x_ld, x_off, n, h, w, C / 8,
+                       reinterpret_cast<_Float16*>(out_dev), (int)out_ld, out_off);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
 
 int tise_stem_conv3x3s2_split(const float* x_dev, int n, int h, int w, const float* w_dev, const float* bias_dev,
-                              void* out_dev, int64_t out_plane, void* stream) {
+                              void* out_dev, void* stream) {
     if (!x_dev || !w_dev || !bias_dev || !out_dev || n < 0 || h < 3 || w < 3) return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
     hipLaunchKernelGGL(stem_conv3x3s2_split_kernel, dim3(grid_for((int64_t)n * oh * ow * 4)), dim3(256), 0,
-                       (hipStream_t)stream, x_dev, n, h, w, w_dev, bias_dev, reinterpret_cast<_Float16*>(out_dev), out_plane);
+                       (hipStream_t)stream, x_dev, n, h, w, w_dev, bias_dev, reinterpret_cast<_Float16*>(out_dev));
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
 
 int tise_stem_conv3x3s2_split_u8(const uint8_t* x_dev, const float* lut_dev, int n, int h, int w, const float* w_dev,
-                                 const float* bias_dev, void* out_dev, int64_t out_plane, void* stream) {
+                                 const float* bias_dev, void* out_dev, void* stream) {
     if (!x_dev || !lut_dev || !w_dev || !bias_dev || !out_dev || n < 0 || h < 3 || w < 3) return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
     hipLaunchKernelGGL(stem_conv3x3s2_split_u8_kernel, dim3(grid_for((int64_t)n * oh * ow * 4)), dim3(256), 0,
-                       (hipStream_t)stream, x_dev, lut_dev, n, h, w, w_dev, bias_dev, reinterpret_cast<_Float16*>(out_dev), out_plane);
+                       (hipStream_t)stream, x_dev, lut_dev, n, h, w, w_dev, bias_dev, reinterpret_cast<_Float16*>(out_dev));
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
 
-int tise_split_mean_nhwc(const void* x_dev, int64_t x_plane, int n, int hw, int C, float* out_dev, void* stream) {
-    if (!x_dev || !out_dev || n < 0 || hw <= 0 || C <= 0 || C % 8) return TISE_ERR_INVALID_ARG;
+int tise_split_mean_nhwc(const void* x_dev, int n, int hw, int C, float* out_dev, void* stream) {
+    if (!x_dev || !out_dev || n < 0 || hw <= 0 || C <= 0 || C % 32) return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
     hipLaunchKernelGGL(split_mean_kernel, dim3(grid_for((int64_t)n * (C / 8))), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const _Float16*>(x_dev), x_plane, n, hw, C / 8, out_dev);
+                       reinterpret_cast<const _Float16*>(x_dev), n, hw, C / 8, out_dev);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }

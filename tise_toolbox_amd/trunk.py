@@ -240,8 +240,9 @@ class FusedTrunk:
 
 class SplitTrunk(FusedTrunk):
     """Same graph as ``FusedTrunk`` with every convolution after the Cin=3 stem layer on the hand-written
-    split-precision fp16-MFMA kernel (``csrc/conv_split.hip``): activations travel between layers as two
-    fp16 planes (v ~= hi + lo * 2**-11, 22 mantissa bits), each conv's epilogue applies the folded
+    split-precision fp16-MFMA kernel (``csrc/conv_split.hip``): activations travel between layers as split
+    tensors (v ~= hi + lo * 2**-11, 22 mantissa bits; (N, H, W, 2C) fp16, the halves of every 32-channel block side
+    by side, ``conv_split.py``), each conv's epilogue applies the folded
     BatchNorm scale/bias and ReLU and writes straight into the consumer's channel slice, the pool branch
     gets raw fp32 from the fused 1x1 conv and ``tise_avgpool3_bias_relu_split_nhwc`` finishes it.
     Measured per layer 1.5-2.3x MIOpen's fp32 kernels at a smaller error against an fp64 reference
@@ -265,14 +266,14 @@ class SplitTrunk(FusedTrunk):
         assert tuple(self.stem_w.shape) == (3, 3, 3, 32) and self.c1a.stride == (2, 2) and self.c1a.padding == (0, 0)
         self.sblocks = [(kind, {k: sc(v) for k, v in P.items()}) for kind, P in self.blocks]
 
-    # ---- helpers on split tensors (2, N, H, W, C) fp16 ------------------------------------------------
+    # ---- helpers on split tensors (N, H, W, 2C) fp16 --------------------------------------------------
     @staticmethod
     def _new(n, h, w, c, dev):
-        return torch.empty((2, n, h, w, c), dtype=torch.float16, device=dev)
+        return torch.empty((n, h, w, 2 * c), dtype=torch.float16, device=dev)
 
     def _sconv(self, conv, x, segs=None):
         """Run a SplitConv; with segs None the whole output goes to a fresh packed split tensor."""
-        _, n, h, w, _ = x.shape
+        n, h, w, _ = x.shape
         oh, ow = conv.out_hw(h, w)
         if segs is None:
             out = self._new(n, oh, ow, conv.cout, x.device)
@@ -283,22 +284,22 @@ class SplitTrunk(FusedTrunk):
 
     @staticmethod
     def _maxpool_split(x, out=None, out_off=0):
-        _, n, h, w, c = x.shape
+        n, h, w, c2 = x.shape
+        c = c2 // 2
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
         if out is None:
-            out = torch.empty((2, n, oh, ow, c), dtype=torch.float16, device=x.device)
-        _lib.call("tise_maxpool3s2_split_nhwc", _p(x), c, 0, x.stride(0), n, h, w, c, _p(out), out.shape[4], out_off,
-                  out.stride(0), _stream())
+            out = torch.empty((n, oh, ow, c2), dtype=torch.float16, device=x.device)
+        _lib.call("tise_maxpool3s2_split_nhwc", _p(x), c, 0, n, h, w, c, _p(out), out.shape[3] // 2, out_off, _stream())
         return out
 
     @staticmethod
     def _avgpool_split(raw, bias, out, out_off):
         n, h, w, c = raw.shape
-        _lib.call("tise_avgpool3_bias_relu_split_nhwc", _p(raw), c, 0, n, h, w, c, _p(bias), _p(out), out.shape[4],
-                  out_off, out.stride(0), _stream())
+        _lib.call("tise_avgpool3_bias_relu_split_nhwc", _p(raw), c, 0, n, h, w, c, _p(bias), _p(out), out.shape[3] // 2,
+                  out_off, _stream())
 
     def _sblock_a(self, x, P):
-        _, n, h, w, _ = x.shape
+        n, h, w, _ = x.shape
         f = P["f"]
         pf = f.cout - 176
         dev = x.device
@@ -313,7 +314,8 @@ class SplitTrunk(FusedTrunk):
         return out
 
     def _sblock_b(self, x, P):
-        _, n, h, w, cin = x.shape
+        n, h, w, cin = x.shape
+        cin //= 2
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
         out = self._new(n, oh, ow, 384 + 96 + cin, x.device)
         P["c3"](x, [(0, 384, out, 0, 0)])
@@ -323,7 +325,7 @@ class SplitTrunk(FusedTrunk):
         return out
 
     def _sblock_c(self, x, P):
-        _, n, h, w, _ = x.shape
+        n, h, w, _ = x.shape
         f = P["f"]
         c7 = (f.cout - 384) // 2
         dev = x.device
@@ -341,7 +343,8 @@ class SplitTrunk(FusedTrunk):
         return out
 
     def _sblock_d(self, x, P):
-        _, n, h, w, cin = x.shape
+        n, h, w, cin = x.shape
+        cin //= 2
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
         dev = x.device
         out = self._new(n, oh, ow, 320 + 192 + cin, dev)
@@ -355,7 +358,7 @@ class SplitTrunk(FusedTrunk):
         return out
 
     def _sblock_e(self, x, P):
-        _, n, h, w, _ = x.shape
+        n, h, w, _ = x.shape
         f = P["f"]
         dev = x.device
         out = self._new(n, h, w, 2048, dev)
@@ -378,8 +381,7 @@ class SplitTrunk(FusedTrunk):
         n, h, w, _ = x.shape                                            # Cin = 3 stem layer: direct HIP kernel
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
         a = self._new(n, oh, ow, 32, x.device)
-        _lib.call("tise_stem_conv3x3s2_split", _p(x), n, h, w, _p(self.stem_w), _p(self.c1a.b), _p(a), a.stride(0),
-                  _stream())
+        _lib.call("tise_stem_conv3x3s2_split", _p(x), n, h, w, _p(self.stem_w), _p(self.c1a.b), _p(a), _stream())
         return self._after_stem(a)
 
     @torch.no_grad()
@@ -392,7 +394,7 @@ class SplitTrunk(FusedTrunk):
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
         a = self._new(n, oh, ow, 32, u8_nhwc.device)
         _lib.call("tise_stem_conv3x3s2_split_u8", _p(u8_nhwc), _p(lut_dev), n, h, w, _p(self.stem_w), _p(self.c1a.b), _p(a),
-                  a.stride(0), _stream())
+                  _stream())
         return self._after_stem(a)
 
     def _after_stem(self, a):
@@ -403,7 +405,8 @@ class SplitTrunk(FusedTrunk):
         fn = {"A": self._sblock_a, "B": self._sblock_b, "C": self._sblock_c, "D": self._sblock_d, "E": self._sblock_e}
         for kind, P in self.sblocks:
             a = fn[kind](a, P)
-        _, n, h, w, c = a.shape                                         # merge + global average, one pass
+        n, h, w, c2 = a.shape                                           # merge + global average, one pass
+        c = c2 // 2
         feat = torch.empty((n, c), dtype=torch.float32, device=a.device)
-        _lib.call("tise_split_mean_nhwc", _p(a), a.stride(0), n, h * w, c, _p(feat), _stream())
+        _lib.call("tise_split_mean_nhwc", _p(a), n, h * w, c, _p(feat), _stream())
         return feat.view(n, c, 1, 1)

@@ -21,7 +21,7 @@ for name, H, Cin, Cout, kh, kw, st, pad in LAYERS:
     conv = SplitConv(w, b, (st, st), pad, dev, variant=VARIANT, pipe_cfg=CFG)
     oh, ow = conv.out_hw(H, H)
     x = split((torch.rand((N, H, H, Cin), device=dev) * 3.0))
-    out = torch.zeros((2, N, oh, ow, Cout), dtype=torch.float16, device=dev)
+    out = torch.zeros((N, oh, ow, 2 * Cout), dtype=torch.float16, device=dev)
     line = f"{name:7s} {VARIANT} tn={conv.tn} cfg={conv.pipe_cfg} K={conv.k:5d}"
     for label, flags in (("full", 0), ("noDMA", 0x100), ("noMMA", 0x200), ("noEPI", 0x400), ("noDMA+noEPI", 0x500),
                          ("noMMA+noEPI", 0x600), ("onlyEPI", 0x300), ("nothing", 0x700)):

@@ -19,7 +19,7 @@ for H, Cin, Cout, kh, kw, st, pad in [(17, 768, 768, 1, 1, 1, (0, 0)), (17, 192,
     b = torch.zeros(Cout, device=dev)
     conv = SplitConv(w, b, (st, st), pad, dev)
     oh, ow = conv.out_hw(H, H)
-    out = torch.zeros((2, B, oh, ow, Cout), dtype=torch.float16, device=dev)
+    out = torch.zeros((B, oh, ow, 2 * Cout), dtype=torch.float16, device=dev)
     flop = 3 * 2.0 * B * oh * ow * Cout * Cin * kh * kw
     line = f"{H}x{H}x{Cin}->{Cout} k{kh}x{kw}:"
     base = torch.randn((B, H, H, Cin), generator=g).to(dev)

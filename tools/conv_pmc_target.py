@@ -22,7 +22,7 @@ for name, H, Cin, Cout, kh, kw, st, pad in LAYERS:
     for var, cfg in (("fast", None), ("pipe", 0), ("pipe", 8)):
         conv = SplitConv(w, b, (st, st), pad, dev, variant=var, pipe_cfg=cfg)
         oh, ow = conv.out_hw(H, H)
-        out = torch.empty((2, B, oh, ow, Cout), dtype=torch.float16, device=dev)
+        out = torch.empty((B, oh, ow, 2 * Cout), dtype=torch.float16, device=dev)
         for _ in range(3):
             conv(xs, [(0, Cout, out, 0, 0)])
         torch.cuda.synchronize()

@@ -21,7 +21,7 @@ b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
 conv = SplitConv(w, b, (st, st), pad, dev)
 oh, ow = conv.out_hw(H, H)
 x = split((torch.rand((N, H, H, Cin), device=dev) * 3.0))
-out = torch.zeros((2, N, oh, ow, Cout), dtype=torch.float16, device=dev)
+out = torch.zeros((N, oh, ow, 2 * Cout), dtype=torch.float16, device=dev)
 stamp = torch.zeros(2048, dtype=torch.int32, device=dev)
 for _ in range(3):
     conv(x, [(0, Cout, out, 0, 0)])

@@ -27,7 +27,7 @@ def wrapped(self, xs, segs):
     e0.record()
     r = orig(self, xs, segs)
     e1.record()
-    _, n, h, w, _ = xs.shape
+    n, h, w, _ = xs.shape
     oh, ow = r
     recs.append((e0, e1, f"{h}x{w}x{self.cin}->{self.cout} k{self.kh}x{self.kw} s{self.stride[0]} tn{self.tn}",
                  2.0 * n * oh * ow * self.cout * self.k))

@@ -17,7 +17,7 @@ def stem(xc):
     n, h, w, _ = xc.shape
     oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
     a = t._new(n, oh, ow, 32, xc.device)
-    _lib.call("tise_stem_conv3x3s2_split", _p(xc), n, h, w, _p(t.stem_w), _p(t.c1a.b), _p(a), a.stride(0), _stream())
+    _lib.call("tise_stem_conv3x3s2_split", _p(xc), n, h, w, _p(t.stem_w), _p(t.c1a.b), _p(a), _stream())
     a = t._sconv(t.s2a, a)
     a = t._maxpool_split(t._sconv(t.s2b, a))
     a = t._sconv(t.s3b, a)

@@ -4,8 +4,27 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tise_toolbox_amd.conv_split import SplitConv, split, pick_tn
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from conv_pipe_probe_layers import LAYERS
+from tise_toolbox_amd.inception import InceptionV3
+from tise_toolbox_amd.trunk import SplitTrunk
+
+
+def trunk_layers():
+    """(H, Cin, Cout, kh, kw, stride, pad, count) of every distinct conv launch of a SplitTrunk forward."""
+    seen = {}
+    trunk = SplitTrunk(InceptionV3([3], seed=0), torch.device("cuda:0"))
+    orig = SplitConv.__call__
+
+    def rec(self, xs, segs):
+        key = (xs.shape[1], self.cin, self.cout, self.kh, self.kw, self.stride[0], self.padding)
+        seen[key] = seen.get(key, 0) + 1
+        return orig(self, xs, segs)
+    SplitConv.__call__ = rec
+    trunk(torch.rand((2, 3, 299, 299), device="cuda:0").contiguous(memory_format=torch.channels_last))
+    SplitConv.__call__ = orig
+    return [k + (c,) for k, c in seen.items()]
+
+
+LAYERS = trunk_layers()
 
 dev = torch.device("cuda:0")
 N = 500
@@ -21,7 +40,7 @@ for (H, Cin, Cout, kh, kw, st, pad, cnt) in LAYERS:
             continue
         conv = SplitConv(w, b, (st, st), pad, dev, tn=tn, variant="fast")
         oh, ow = conv.out_hw(H, H)
-        out = torch.zeros((2, N, oh, ow, Cout), dtype=torch.float16, device=dev)
+        out = torch.zeros((N, oh, ow, 2 * Cout), dtype=torch.float16, device=dev)
         for _ in range(3):
             conv(x, [(0, Cout, out, 0, 0)])
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
