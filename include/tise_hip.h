@@ -183,7 +183,8 @@ int tise_maxpool3s2_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int
  * block) -- followed, when C % 32 == 16, by one 64-byte block [hi x16 | lo x16].  A pixel is 4*C bytes, the same as
  * fp32.  `ld` arguments of split tensors are the tensor's channel count C, `off` the first channel of a slice.
  *
- * out = split(max(avgpool3x3(stride 1, pad 1, count_include_pad)(x) + bias, 0)): x is raw fp32 (n, h, w, x_ld). */
+ * out = split(max(avgpool3x3(stride 1, pad 1, count_include_pad)(x) + bias, 0)): x is raw fp32 (n, h, w, x_ld);
+ * C % 8 == 0, x_ld / x_off multiples of 4 floats, bias_dev 16-byte aligned. */
 int tise_avgpool3_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
                                        const float* bias_dev, void* out_dev, int64_t out_ld, int out_off,
                                        void* stream);

@@ -330,7 +330,6 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     const int fb0 = (lane & 31) * 128 + (((lane >> 5)) ^ bswz) * 16;
     const int fb1 = (lane & 31) * 128 + ((2 + (lane >> 5)) ^ bswz) * 16;
     const unsigned char* fa = lds + wave * 32 * 128;
-    constexpr bool HEADED = TN < 5;
     half8_t h_a0, h_a1, h_b0, h_b1;
 
 // One K-step of MFMAs.  All fragment reads of the step are written first and the MFMAs after them; the
@@ -341,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
 // ~100-150 cycles of LDS latency then pass under the ~740 cycles the wave spends issuing its global_load_lds
 // instructions (profiles/r02q_conv_kstep_stamps.txt) instead of in front of the first MFMA.
 #define CF_HEAD(STAGEOFF)                                                                                 \
-    if (HEADED) {                                                                                         \
+    {                                                                                                     \
         h_a0 = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + fb0);                                   \
         h_a1 = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + (fb0 ^ 64));                            \
         h_b0 = *reinterpret_cast<const half8_t*>(lds + (STAGEOFF) + A_BYTES + fb0);                        \
@@ -354,14 +353,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         half8_t fa_[2][2], fb_[2][TN][2];                                                                  \
         _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
             const int fbo = s ? fb1 : fb0;                                                                 \
-            if (HEADED && s == 0) { fa_[0][0] = h_a0; fa_[0][1] = h_a1; }                                  \
+            if (s == 0) { fa_[0][0] = h_a0; fa_[0][1] = h_a1; }                                            \
             else {                                                                                         \
                 fa_[s][0] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + fbo);                      \
                 fa_[s][1] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + (fbo ^ 64));               \
             }                                                                                              \
             _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
                 const unsigned char* bb = lds + (STAGEOFF) + A_BYTES + t * 32 * 128;                       \
-                if (HEADED && s == 0 && t == 0) { fb_[0][0][0] = h_b0; fb_[0][0][1] = h_b1; }              \
+                if (s == 0 && t == 0) { fb_[0][0][0] = h_b0; fb_[0][0][1] = h_b1; }                        \
                 else {                                                                                     \
                     fb_[s][t][0] = *reinterpret_cast<const half8_t*>(bb + fbo);                            \
                     fb_[s][t][1] = *reinterpret_cast<const half8_t*>(bb + (fbo ^ 64));                     \
@@ -377,8 +376,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
                 acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][0], acc_main[0][t], 0, 0, 0); \
                 acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][1], acc_corr[0][t], 0, 0, 0); \
             }                                                                                              \
-        /* a(s0), b(s0, t0) are already in registers (CF_HEAD; TN = 5 has no registers to spare for that) */ \
-        if (!HEADED) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                    \
+        /* a(s0), b(s0, t0) are already in registers (CF_HEAD) */                                          \
         _Pragma("unroll") for (int i = 0; i < TN - 1; ++i) {                                               \
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         /* b(s0, t i+1) */                  \
             __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);         /* MFMAs (s0, t i) */               \

@@ -107,31 +107,22 @@ __global__ __launch_bounds__(256) void maxpool3s2_nhwc_kernel(const float* __res
 // see are multiples of 8 that do not straddle a block half, so the hi and the lo run of a thread's channels are
 // contiguous and tise_ilv_off / tise_ilv_second give their places.
 typedef _Float16 half8v __attribute__((ext_vector_type(8)));
-typedef _Float16 half4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void split_store4(float4 v, _Float16* hi_p, _Float16* lo_p) {
-    tise_flag_split_overflow(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-    half4v h, l;
-    h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-    l[0] = (_Float16)((v.x - (float)h[0]) * 2048.f); l[1] = (_Float16)((v.y - (float)h[1]) * 2048.f);
-    l[2] = (_Float16)((v.z - (float)h[2]) * 2048.f); l[3] = (_Float16)((v.w - (float)h[3]) * 2048.f);
-    *reinterpret_cast<half4v*>(hi_p) = h;
-    *reinterpret_cast<half4v*>(lo_p) = l;
-}
-
-// fp32 raw 1x1-conv output (slice) -> 3x3/s1/p1 average (count_include_pad) + bias, ReLU -> split tensor slice
+// fp32 raw 1x1-conv output (slice) -> 3x3/s1/p1 average (count_include_pad) + bias, ReLU -> split tensor slice.
+// Thread = (pixel, 8 channels): two 16-byte loads per tap, one 16-byte store per half (the pool branch's channel
+// counts are 32, 64 and 192).  Summation order per channel: (dh, dw) row-major, as the 4-channel form had.
 __global__ __launch_bounds__(256) void avgpool3_bias_relu_split_kernel(const float* __restrict__ x, int64_t x_ld,
-                                                                       int x_off, int N, int H, int W, int C4,
+                                                                       int x_off, int N, int H, int W, int C8,
                                                                        const float* __restrict__ bias,
                                                                        _Float16* __restrict__ out, int out_C,
                                                                        int out_off) {
-    const int64_t total = (int64_t)N * H * W * C4;
+    const int64_t total = (int64_t)N * H * W * C8;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = e / C4;
-        const int c4 = (int)(e - p * C4);
+        const int64_t p = e / C8;
+        const int c8 = (int)(e - p * C8);
         const int w = (int)(p % W);
         const int h = (int)((p / W) % H);
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
 #pragma unroll
         for (int dh = -1; dh <= 1; ++dh) {
             const int hh = h + dh;
@@ -140,15 +131,30 @@ __global__ __launch_bounds__(256) void avgpool3_bias_relu_split_kernel(const flo
             for (int dw = -1; dw <= 1; ++dw) {
                 const int ww = w + dw;
                 if (ww < 0 || ww >= W) continue;
-                const float4 v = *reinterpret_cast<const float4*>(x + (p + (int64_t)dh * W + dw) * x_ld + x_off + 4 * c4);
-                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                const float4* q = reinterpret_cast<const float4*>(x + (p + (int64_t)dh * W + dw) * x_ld + x_off + 8 * c8);
+                const float4 v0 = q[0], v1 = q[1];
+                s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+                s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
             }
         }
-        s.x /= 9.f; s.y /= 9.f; s.z /= 9.f; s.w /= 9.f;
-        const float4 v = f4_bias_relu(s, *reinterpret_cast<const float4*>(bias + 4 * c4));
-        const int ch = out_off + 4 * c4;
+        s0.x /= 9.f; s0.y /= 9.f; s0.z /= 9.f; s0.w /= 9.f;      // count_include_pad=True: always / 9
+        s1.x /= 9.f; s1.y /= 9.f; s1.z /= 9.f; s1.w /= 9.f;
+        const float4 r0 = f4_bias_relu(s0, *reinterpret_cast<const float4*>(bias + 8 * c8));
+        const float4 r1 = f4_bias_relu(s1, *reinterpret_cast<const float4*>(bias + 8 * c8 + 4));
+        const float v[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        half8v hi, lo;
+        float vmax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            vmax = fmaxf(vmax, v[i]);
+            hi[i] = (_Float16)v[i];
+            lo[i] = (_Float16)((v[i] - (float)hi[i]) * 2048.f);
+        }
+        tise_flag_split_overflow(vmax);
+        const int ch = out_off + 8 * c8;
         _Float16* d = out + p * (2 * (int64_t)out_C) + tise_ilv_off(ch, out_C);
-        split_store4(v, d, d + tise_ilv_second(ch, out_C));
+        *reinterpret_cast<half8v*>(d) = hi;
+        *reinterpret_cast<half8v*>(d + tise_ilv_second(ch, out_C)) = lo;
     }
 }
 
@@ -246,6 +252,10 @@ __global__ __launch_bounds__(256) void stem_conv3x3s2_split_kernel(const float* 
 
 // The same convolution reading the Pillow-exact uint8 pixels (resize kernel, float output switched off) and applying
 // the 3 x 256 input table itself: 134 MB instead of 536 MB of network input written and read per 500 images.
+// The four lanes of a pixel (a DPP quad) fetch the 3 x 9 input bytes of its window ONCE between them -- lane r < 3
+// reads the 9 bytes of window row r as three aligned dwords -- and pass them round with quad-permute moves: 3 vector
+// memory instructions per lane instead of 27 byte loads (the kernel is bound by its 2.8 GB of output per 1000 images,
+// and 29 memory instructions per 32 output bytes kept the address path busier than the data path).
 __global__ __launch_bounds__(256) void stem_conv3x3s2_split_u8_kernel(const uint8_t* __restrict__ x, const float* __restrict__ lut, int N, int H, int W,
                                                                    const float* __restrict__ wt,   // [27][32]
                                                                    const float* __restrict__ bias, // [32]
@@ -257,27 +267,55 @@ __global__ __launch_bounds__(256) void stem_conv3x3s2_split_u8_kernel(const uint
     __syncthreads();
     const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
     const int64_t total = (int64_t)N * OH * OW * 4;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = e >> 2;
-        const int cg = (int)(e & 3) * 8;
+    const int64_t total_r = (total + 255) & ~(int64_t)255;   // whole workgroups take part in the quad exchange
+    const uint8_t* x_end = x + (int64_t)N * H * W * 3;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total_r; e += (int64_t)gridDim.x * blockDim.x) {
+        const bool live = e < total;
+        const int64_t p = live ? (e >> 2) : 0;
+        const int sub = (int)(e & 3);
+        const int cg = sub * 8;
         const int ow = (int)(p % OW);
         const int oh = (int)((p / OW) % OH);
         const int64_t n = p / ((int64_t)OW * OH);
         const uint8_t* xp = x + ((n * H + 2 * oh) * W + 2 * ow) * 3;
+        // this lane's window row (lane 3 repeats row 2; its copy is not used)
+        const uint8_t* xr = xp + (int64_t)(sub < 3 ? sub : 2) * W * 3;
+        unsigned r0, r1, r2;                                  // the row's 9 bytes: r0 = bytes 0-3, r1 = 4-7, r2 = byte 8
+        {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(xr);
+            const unsigned* q = reinterpret_cast<const unsigned*>(a & ~(uintptr_t)3);
+            if (reinterpret_cast<const uint8_t*>(q) + 12 <= x_end) {
+                const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
+                const int sh = (int)(a & 3) * 8;
+                const unsigned long long lo64 = ((unsigned long long)d1 << 32) | d0, hi64 = ((unsigned long long)d2 << 32) | d1;
+                r0 = (unsigned)(lo64 >> sh);
+                r1 = (unsigned)(hi64 >> sh);
+                r2 = (d2 >> sh) & 0xffu;
+            } else {                                          // the last bytes of the tensor: no read past its end
+                r0 = xr[0] | (xr[1] << 8) | (xr[2] << 16) | ((unsigned)xr[3] << 24);
+                r1 = xr[4] | (xr[5] << 8) | (xr[6] << 16) | ((unsigned)xr[7] << 24);
+                r2 = xr[8];
+            }
+        }
         float acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const uint8_t* xr = xp + (int64_t)kh * W * 3;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {                    // (kw, cin) = 9 contiguous floats of the input row
-                const float v = lut_s[(t % 3) * 256 + xr[t]];   // same value the fp32 path reads: results are bit-identical
-                const float* wr = ws + (kh * 9 + t) * 32 + cg;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
-            }
+#define STEM_ROW(KH, QP)                                                                                   \
+        {                                                                                                  \
+            const unsigned b0 = (unsigned)__builtin_amdgcn_mov_dpp((int)r0, QP, 0xf, 0xf, true);           \
+            const unsigned b1 = (unsigned)__builtin_amdgcn_mov_dpp((int)r1, QP, 0xf, 0xf, true);           \
+            const unsigned b2 = (unsigned)__builtin_amdgcn_mov_dpp((int)r2, QP, 0xf, 0xf, true);           \
+            _Pragma("unroll") for (int t = 0; t < 9; ++t) {      /* (kw, cin) = 9 contiguous bytes of the input row */ \
+                const unsigned byte = t < 4 ? (b0 >> (8 * t)) & 0xffu : (t < 8 ? (b1 >> (8 * (t - 4))) & 0xffu : b2); \
+                const float v = lut_s[(t % 3) * 256 + byte];     /* same value the fp32 path reads: results are bit-identical */ \
+                const float* wr = ws + ((KH) * 9 + t) * 32 + cg;                                           \
+                _Pragma("unroll") for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wr[c], acc[c]);             \
+            }                                                                                              \
         }
+        STEM_ROW(0, 0x00)                                     // quad_perm [0,0,0,0]: row 0 from the quad's lane 0
+        STEM_ROW(1, 0x55)                                     // [1,1,1,1]
+        STEM_ROW(2, 0xaa)                                     // [2,2,2,2]
+#undef STEM_ROW
         half8v h, l;
         float vmax = 0.f;
 #pragma unroll
@@ -287,10 +325,12 @@ __global__ __launch_bounds__(256) void stem_conv3x3s2_split_u8_kernel(const uint
             h[c] = (_Float16)v;
             l[c] = (_Float16)((v - (float)h[c]) * 2048.f);
         }
-        tise_flag_split_overflow(vmax);
-        _Float16* d = out + p * 64 + cg;
-        *reinterpret_cast<half8v*>(d) = h;
-        *reinterpret_cast<half8v*>(d + 32) = l;
+        if (live) {
+            tise_flag_split_overflow(vmax);
+            _Float16* d = out + p * 64 + cg;
+            *reinterpret_cast<half8v*>(d) = h;
+            *reinterpret_cast<half8v*>(d + 32) = l;
+        }
     }
 }
 
@@ -377,12 +417,13 @@ int tise_maxpool3s2_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int
 int tise_avgpool3_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_off, int n, int h, int w, int C,
                                        const float* bias_dev, void* out_dev, int64_t out_ld, int out_off,
                                        void* stream) {
-    if (!x_dev || !bias_dev || !out_dev || n < 0 || h <= 0 || w <= 0 || C <= 0 || !aligned4(x_ld, x_off, C) ||
-        !aligned4(out_ld, out_off, C) || out_ld % 16 || x_off + C > x_ld || out_off + C > out_ld || out_ld > 0x7fffffff)
+    if (!x_dev || !bias_dev || !out_dev || n < 0 || h <= 0 || w <= 0 || C <= 0 || C % 8 || x_ld % 4 || x_off % 4 ||
+        out_off % 8 || out_ld % 16 || x_off + C > x_ld || out_off + C > out_ld || out_ld > 0x7fffffff ||
+        (reinterpret_cast<uintptr_t>(bias_dev) & 15) != 0)
         return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
-    hipLaunchKernelGGL(avgpool3_bias_relu_split_kernel, dim3(grid_for((int64_t)n * h * w * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, x_dev, x_ld, x_off, n, h, w, C / 4, bias_dev,
+    hipLaunchKernelGGL(avgpool3_bias_relu_split_kernel, dim3(grid_for((int64_t)n * h * w * (C / 8))), dim3(256), 0,
+                       (hipStream_t)stream, x_dev, x_ld, x_off, n, h, w, C / 8, bias_dev,
                        reinterpret_cast<_Float16*>(out_dev), (int)out_ld, out_off);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
