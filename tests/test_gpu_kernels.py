@@ -472,6 +472,30 @@ def test_conv_split_variants_bitwise_identical_and_repeatable(dev, variant):
             assert torch.equal(out, ref), (variant, rep, (n, H, W, Cin, Cout))
 
 
+def test_conv_split_tile_width_does_not_change_results(dev):
+    """Every tile width (tn = 1..5) accumulates every output element over K in the same order with the same MFMA
+    sequence: the outputs must be bit-identical -- the tile width is a pure performance choice (conv_split.pick_tn).
+    Includes Cin % 32 == 16 (paired tails) and Cout tails."""
+    from tise_toolbox_amd.conv_split import SplitConv, split
+    g = torch.Generator(device="cpu").manual_seed(21)
+    for (n, H, W, Cin, Cout, kh, kw, st, pad) in [(9, 17, 17, 192, 192, 1, 7, 1, (0, 3)), (5, 35, 35, 48, 64, 5, 5, 1, (2, 2)),
+                                                  (33, 8, 8, 448, 384, 3, 3, 1, (1, 1)), (3, 19, 19, 80, 208, 3, 3, 1, (0, 0))]:
+        x = (torch.rand((n, H, W, Cin), generator=g) * 2.0).to(dev)
+        w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
+        b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+        xs = split(x)
+        ref = None
+        for tn in (1, 2, 3, 4, 5):
+            conv = SplitConv(w, b, (st, st), pad, dev, tn=tn)
+            oh, ow = conv.out_hw(H, W)
+            out = torch.full((n, oh, ow, 2 * Cout), 5.0, dtype=torch.float16, device=dev)
+            conv(xs, [(0, Cout, out, 0, 0)])
+            if ref is None:
+                ref = out
+            else:
+                assert torch.equal(out, ref), (tn, Cin, Cout)
+
+
 def test_split_trunk_batch_sizes_and_determinism(dev):
     """pool3 features must not depend on how images are batched, and must repeat bit for bit."""
     from tise_toolbox_amd.inception import InceptionV3

@@ -96,7 +96,10 @@ _TN_EFF = {1: 0.55, 2: 0.78, 3: 0.90, 4: 1.0, 5: 1.0}
 
 
 def pick_tn(cout):
-    """Tile width 32*tn (tn in 1..5; 1 only exists in the DMA variants): least padded work weighted by the measured tile efficiency."""
+    """Tile width 32*tn (tn in 1..5): least padded work weighted by the measured tile efficiency.  (Timing the
+    candidate widths per layer and input shape at run time -- every width gives the same bits -- picked differently on
+    a quarter of the layers and was 2 % faster summed over isolated launches, tools/tn_sweep.py, but 21.10-21.14 k
+    vs 21.10 k images/s in the bench: not kept.)"""
     best = None
     for tn in (5, 4, 3, 2, 1):
         bn = 32 * tn
@@ -132,11 +135,10 @@ class SplitConv:
         self.variant = variant or os.environ.get("TISE_CONV_VARIANT", "fast")
         if self.variant not in ("fast", "glds", "pipe"):
             raise ValueError(f"unknown conv variant {self.variant!r} (round 2 removed reg / glds3 / gldsb / win / spec)")
-        bn = 32 * self.tn
+        # rows of zero weights / scale / bias up to the widest tile grid any tile width may use
+        self.cout_pad = max(-(-cout // (32 * t)) * 32 * t for t in (1, 2, 3, 4, 5))
         if self.variant == "pipe":                              # resident-weights sliding-window kernel (conv_pipe.hip)
             self.pipe_cfg = 33 if pipe_cfg is None else pipe_cfg
-            bn = PIPE_BN[self.pipe_cfg]
-        self.cout_pad = -(-cout // bn) * bn
         self.k = kh * kw * cin
         self.kpad = -(-self.k // 32) * 32
         w = weight.detach().float().cpu()
@@ -205,6 +207,8 @@ class SplitConv:
                 s.ld = dst.shape[3]
         if getattr(self, "debug_ptr", None):                    # tools/conv_stamps.py
             a.seg[3].dst = self.debug_ptr
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        tn = self.tn
         timer = SplitConv.timer
         if timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -212,9 +216,8 @@ class SplitConv:
         if self.pipe_cfg is not None:
             code = 512 | self.pipe_cfg
         else:
-            code = self.tn | {"glds": 16, "fast": 128}[self.variant]
-        _lib.call("tise_conv_split_f16", ctypes.byref(a), code,
-                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            code = tn | {"glds": 16, "fast": 128}[self.variant]
+        _lib.call("tise_conv_split_f16", ctypes.byref(a), code, stream)
         if timer is not None:
             e1.record()
             timer.append((e0, e1, 2.0 * a.M * self.cout * self.k))

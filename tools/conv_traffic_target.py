@@ -25,11 +25,12 @@ detail = []
 
 def wrapped(self, xs, segs):
     r = orig(self, xs, segs)
-    _, n, h, w, _ = xs.shape
+    n, h, w, _ = xs.shape
     oh, ow = r
-    alg.append(n * h * w * self.cin * 4 + n * oh * ow * self.cout * 4 + self.w.numel() * 2)
+    wn = (self.w_fast if self.w_fast is not None else self.w).numel()
+    alg.append(n * h * w * self.cin * 4 + n * oh * ow * self.cout * 4 + wn * 2)
     detail.append((f"{h}x{w}x{self.cin}->{self.cout} k{self.kh}x{self.kw} s{self.stride[0]} tn{self.tn}", n * h * w * self.cin * 4,
-                   n * oh * ow * self.cout * 4, self.w.numel() * 2))
+                   n * oh * ow * self.cout * 4, wn * 2))
     return r
 
 

@@ -27,7 +27,7 @@ def trunk_layers():
 LAYERS = trunk_layers()
 
 dev = torch.device("cuda:0")
-N = 500
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 tot_cur = tot_best = 0.0
 for (H, Cin, Cout, kh, kw, st, pad, cnt) in LAYERS:
     g = torch.Generator(device="cpu").manual_seed(1)
