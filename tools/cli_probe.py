@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Host-inclusive rate of the drop-in CLI: PNG files on disk -> PIL decode in DataLoader workers -> pinned uint8
 batches over PCIe -> the device path.  Writes N synthetic 256x256 PNGs, saves reference statistics once, then
-times `fid_score` for several worker counts and batch sizes."""
+times `fid_score` for several worker counts and batch sizes, and with --u8-cache (first run: decode once into the
+cache; second run: memory-mapped cache -> pinned double buffer -> side-stream H2D -> device pipeline)."""
 import os, sys, time, tempfile, subprocess
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -33,12 +34,19 @@ if __name__ == "__main__":
     print(f"wrote {N} PNGs in {time.perf_counter() - t0:.1f} s ({sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)) / N / 1e3:.0f} KB each)", flush=True)
     ref = os.path.join(root, "ref.npz")
     env = dict(os.environ)
-    base = [sys.executable, "-m", "tise_toolbox_amd.fid_score", "--path1", ref, "--path2", d, "--saved_file", os.path.join(root, "out.txt")]
-    subprocess.run([sys.executable, "-m", "tise_toolbox_amd.fid_score", "--path1", d, "--path2", d, "--batch-size", "50",
-                    "--save-stats", ref, "--saved_file", os.path.join(root, "o0.txt"), "--num-workers", "32"], check=True,
-                   capture_output=True, env=env)
+    base = [sys.executable, "-m", "tise_toolbox_amd.fid_score", "--synthetic-weights", "--path1", ref, "--path2", d,
+            "--saved_file", os.path.join(root, "out.txt")]
+    subprocess.run([sys.executable, "-m", "tise_toolbox_amd.fid_score", "--synthetic-weights", "--path2", d, "--batch-size", "50",
+                    "--save-stats", ref, "--num-workers", "32"], check=True, capture_output=True, env=env)
     for bs, nw in ((50, 8), (50, 32), (500, 32), (500, 64)):
         t0 = time.perf_counter()
         r = subprocess.run(base + ["--batch-size", str(bs), "--num-workers", str(nw)], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
         print(f"batch {bs:3d} workers {nw:2d}: {dt:6.1f} s wall for {N} images incl. start-up -> {N / dt:7.0f} images/s   {r.stdout.strip().splitlines()[-1] if r.stdout else r.stderr[-200:]}", flush=True)
+    for label in ("first run (builds the cache, 32 workers)", "second run (from the cache)", "third run (from the cache)"):
+        t0 = time.perf_counter()
+        r = subprocess.run(base + ["--batch-size", "500", "--num-workers", "32", "--u8-cache"], capture_output=True, text=True, env=env)
+        dt = time.perf_counter() - t0
+        feed = [ln for ln in r.stderr.splitlines() if "u8 cache feed" in ln]
+        print(f"--u8-cache batch 500, {label}: {dt:6.1f} s wall incl. start-up -> {N / dt:7.0f} images/s   "
+              f"{r.stdout.strip().splitlines()[-1] if r.stdout else r.stderr[-200:]}\n    {feed[-1] if feed else ''}", flush=True)
