@@ -290,7 +290,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
             /* a local on purpose: with array elements as direct builtin arguments hipcc (ROCm 7.2) silently \
                drops the host-side launch stub of this template */                                         \
             const unsigned char* sa = pa[jj];                                                              \
-            __builtin_amdgcn_global_load_lds(sa, (lds_ptr_t)(lds + (STAGEOFF) + (4 * wave + jj) * 1024), 16, 0, 0); \
+            /* measurement switch 0x1000 (instrumented instance only): the pixel operand is fetched every 7th step */ \
+            if (!(DBG && (p.nseg & 0x1000)) || istep % 7 == 0)                                             \
+                __builtin_amdgcn_global_load_lds(sa, (lds_ptr_t)(lds + (STAGEOFF) + (4 * wave + jj) * 1024), 16, 0, 0); \
             pa[jj] = sa + pa_inc[jj];                                                                      \
         }                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                   \

@@ -25,6 +25,21 @@ out = torch.zeros((N, oh, ow, 2 * Cout), dtype=torch.float16, device=dev)
 stamp = torch.zeros(2048, dtype=torch.int32, device=dev)
 for _ in range(3):
     conv(x, [(0, Cout, out, 0, 0)])
+def launch_ms(f, it=10):
+    conv.debug_flags = f
+    conv(x, [(0, Cout, out, 0, 0)])
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(it):
+        conv(x, [(0, Cout, out, 0, 0)])
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / it
+
+
+conv.debug_ptr = stamp.data_ptr()
+print(f"launch: product kernel {launch_ms(0):.3f} ms, instrumented {launch_ms(0x800):.3f} ms, "
+      f"instrumented with the pixel operand fetched every 7th step only (0x1000) {launch_ms(0x1800):.3f} ms, "
+      f"no DMA at all (0x100) {launch_ms(0x900):.3f} ms, no MFMAs (0x200) {launch_ms(0xa00):.3f} ms")
 conv.debug_flags = 0x800 | flags
 conv.debug_ptr = stamp.data_ptr()
 conv(x, [(0, Cout, out, 0, 0)])
