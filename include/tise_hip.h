@@ -227,7 +227,7 @@ int tise_cosine_top1(const void* img_emb_dev, const void* txt_emb_dev, const int
  *   tise_gemm_f16        out[m][n] = act(sum_k a[m][k] w[n][k] + bias[n]) + residual[m][n]     (nn.Linear layout of w;
  *                        act 0 = none, 1 = QuickGELU x*sigmoid(1.702x); bias / residual nullable; k % 64 == 0,
  *                        n % 8 == 0, leading dimensions % 8 == 0)
- *   tise_layernorm_f16   per row over C <= 1024 columns, fp32 mean / variance (clip.model.LayerNorm)
+ *   tise_layernorm_f16   per row over C <= 1024 columns (C, ldx, ldo multiples of 8; 16-byte aligned pointers), fp32 mean / variance (clip.model.LayerNorm)
  *   tise_attention_f16   qkv [batch*seq][3*heads*64] (q | k | v) -> out [batch*seq][heads*64], softmax(q k^T / 8) v per
  *                        (sequence, head), optional causal mask (text tower); seq <= 80, head_dim == 64
  *   tise_patchify_f16    image (batch, 3, res, res) NCHW -> [batch*(res/patch)^2][3*patch*patch], columns in the order of

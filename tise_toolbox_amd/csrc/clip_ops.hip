@@ -3,10 +3,10 @@
 // fp16 tensors, fp32 accumulation / statistics, as the fp16 model `clip.load` serves on a GPU computes.
 //
 //   gemm_f16_kernel      out = act(A W^T + bias) + residual      nn.Linear / the patch-embedding conv / the projections
-//                        256 x 128 x 64 tiles, 8 waves (4 x 2, 64 x 64 per wave), v_mfma_f32_32x32x16_f16, operands
+//                        128 x 128 x 64 tiles, 4 waves (2 x 2, 64 x 64 per wave), v_mfma_f32_32x32x16_f16, operands
 //                        global -> LDS by global_load_lds_dwordx4 in 128-BYTE rows (a K-step of 64 halves is one
-//                        line), three stages with the DMA two steps ahead and a counted vmcnt, XOR-swizzled LDS rows
-//                        (conflict-free ds_read_b128), epilogue staged per wave so that rows leave as full lines.
+//                        line), two stages, two workgroups per CU, XOR-swizzled LDS rows (conflict-free
+//                        ds_read_b128), epilogue staged per wave so that rows leave as full lines.
 //   layernorm_f16_kernel one wave per row, fp32 mean / variance (CLIP's LayerNorm computes in fp32), eps inside sqrt.
 //   attention_f16_kernel one WAVE per (sequence, head): S <= 96 tokens, head dim 64: K Q^T and V^T P^T on the matrix
 //                        cores with operands loaded straight into the MFMA layout, fp32 softmax in registers.
@@ -23,13 +23,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __device__ __attribute__((aligned(128))) unsigned char g_clip_zero_page[128];
 
-#define GM_BM 256
-#define GM_BN 128
 #define GM_BK 64
-#define GM_A_BYTES (GM_BM * 128)
-#define GM_B_BYTES (GM_BN * 128)
-#define GM_STAGE (GM_A_BYTES + GM_B_BYTES)          // 48 KB
-#define GM_NPIECE 6                                  // DMA instructions per wave and K-step: 4 of A, 2 of W
 
 struct GemmArgs {
     const _Float16* a; long long lda;
@@ -40,52 +34,53 @@ struct GemmArgs {
     int M, N, K, act;                                // act: 0 none, 1 QuickGELU (x * sigmoid(1.702 x))
 };
 
-__global__ __launch_bounds__(512, 1) void gemm_f16_kernel(const GemmArgs p) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+// 128 x 128 x 64 tiles: four waves (2 x 2 of 64 x 64), TWO LDS stages of 32 KB, two workgroups per CU -- the structure of
+// the convolution kernel (conv_split.hip).  The first version used 256 x 128 tiles with eight waves and three stages
+// (144 KB of LDS: one workgroup per CU), so the DMA latency in front of a tile's first K-step and its epilogue were
+// fully exposed, and the towers' GEMMs are short: K = 512 / 768 is 8 / 12 K-steps.  With two workgroups per CU the
+// second one computes meanwhile: 5-15 % faster on every tower shape (tools/clip_gemm_probe.py) although a CU now
+// moves 64 KB instead of 48 KB of operands per 128 MFMAs.
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmArgs p) {
+    constexpr int BM = 128, BN = 128;
+    constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128;         // 32 KB
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                   // 4 x 2 waves of 64 x 64
-    const unsigned tiles_n = (unsigned)(p.N + GM_BN - 1) / GM_BN;
+    const int wm = wave >> 1, wn = wave & 1;
+    const unsigned tiles_n = (unsigned)(p.N + BN - 1) / BN;
     const unsigned nwg = gridDim.x;
     unsigned bid = blockIdx.x;
-    {   // the n-tiles of one m-tile on one XCD (workgroup ids are dealt round-robin over the 8 XCDs)
+    {
         const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (int)(bid / tiles_n) * GM_BM;
-    const int n0 = (int)(bid % tiles_n) * GM_BN;
+    const int m0 = (int)(bid / tiles_n) * BM;
+    const int n0 = (int)(bid % tiles_n) * BN;
     const unsigned char* zp = g_clip_zero_page;
-
-    // DMA pieces: 1 KB = 8 rows x 128 B.  LDS row r, 16-byte slot s holds logical chunk s ^ ((r >> 1) & 7).
+    // DMA pieces (8 rows x 128 B): this wave fetches rows 32*wave .. +31 of both operands
     const unsigned char* pa[4];
-    const unsigned char* pw[2];
-    long long ia[4], iw[2];
+    const unsigned char* pw[4];
+    int ia[4], iw[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int r = (4 * wave + g) * 8 + (lane >> 3);        // tile row 0..255
+        const int r = (4 * wave + g) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const bool ok = m0 + r < p.M;
-        pa[g] = ok ? reinterpret_cast<const unsigned char*>(p.a + (long long)(m0 + r) * p.lda + c * 8) : zp;
-        ia[g] = ok ? 128 : 0;
+        const bool oka = m0 + r < p.M, okw = n0 + r < p.N;
+        pa[g] = oka ? reinterpret_cast<const unsigned char*>(p.a + (long long)(m0 + r) * p.lda + c * 8) : zp;
+        ia[g] = oka ? 128 : 0;
+        pw[g] = okw ? reinterpret_cast<const unsigned char*>(p.w + (long long)(n0 + r) * p.ldw + c * 8) : zp;
+        iw[g] = okw ? 128 : 0;
     }
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int r = (2 * wave + g) * 8 + (lane >> 3);        // tile column (weight row) 0..127
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
-        const bool ok = n0 + r < p.N;
-        pw[g] = ok ? reinterpret_cast<const unsigned char*>(p.w + (long long)(n0 + r) * p.ldw + c * 8) : zp;
-        iw[g] = ok ? 128 : 0;
-    }
-#define GM_ISSUE(SOFF)                                                                                    \
+#define GS_ISSUE(SOFF)                                                                                    \
     {                                                                                                     \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
             const unsigned char* s_ = pa[g];                                                               \
-            __builtin_amdgcn_global_load_lds(s_, (lds_ptr_t)(lds + (SOFF) + (4 * wave + g) * 1024), 16, 0, 0);              \
+            __builtin_amdgcn_global_load_lds(s_, (lds_ptr_t)(lds + (SOFF) + (4 * wave + g) * 1024), 16, 0, 0);            \
             pa[g] = s_ + ia[g];                                                                            \
         }                                                                                                  \
-        _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                    \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
             const unsigned char* s_ = pw[g];                                                               \
-            __builtin_amdgcn_global_load_lds(s_, (lds_ptr_t)(lds + (SOFF) + GM_A_BYTES + (2 * wave + g) * 1024), 16, 0, 0);  \
+            __builtin_amdgcn_global_load_lds(s_, (lds_ptr_t)(lds + (SOFF) + A_BYTES + (4 * wave + g) * 1024), 16, 0, 0);  \
             pw[g] = s_ + iw[g];                                                                            \
         }                                                                                                  \
     }
@@ -96,43 +91,67 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_kernel(const GemmArgs p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    // fragment offsets: row (lane & 31) of a 32-row tile, K-slice s (16 halves) -> logical chunks 2s + (lane >> 5)
     const int frow = lane & 31, fsw = (frow >> 1) & 7;
     int fo[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) fo[s] = frow * 128 + (((2 * s + (lane >> 5)) ^ fsw) * 16);
     const unsigned char* fa = lds + (wm * 64) * 128;
-    const unsigned char* fb = lds + GM_A_BYTES + (wn * 64) * 128;
-#define GM_COMPUTE(SOFF)                                                                                  \
+    const unsigned char* fb = lds + A_BYTES + (wn * 64) * 128;
+// the first K-slice's fragments are requested before the step's DMA is issued (LDS latency under the issue phase)
+#define GS_HEAD(SOFF)                                                                                     \
     {                                                                                                     \
-        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                    \
-            half8_t a_[2], b_[2];                                                                          \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
-                a_[i] = *reinterpret_cast<const half8_t*>(fa + (SOFF) + i * 32 * 128 + fo[s]);             \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                  \
-                b_[j] = *reinterpret_cast<const half8_t*>(fb + (SOFF) + j * 32 * 128 + fo[s]);             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                    \
+            h_a[i] = *reinterpret_cast<const half8_t*>(fa + (SOFF) + i * 32 * 128 + fo[0]);                \
+            h_b[i] = *reinterpret_cast<const half8_t*>(fb + (SOFF) + i * 32 * 128 + fo[0]);                \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+#define GS_COMPUTE(SOFF)                                                                                  \
+    {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        half8_t a_[4][2], b_[4][2];                                                                        \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                      \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                \
+                if (s == 0) { a_[0][i] = h_a[i]; b_[0][i] = h_b[i]; }                                      \
+                else {                                                                                     \
+                    a_[s][i] = *reinterpret_cast<const half8_t*>(fa + (SOFF) + i * 32 * 128 + fo[s]);      \
+                    b_[s][i] = *reinterpret_cast<const half8_t*>(fb + (SOFF) + i * 32 * 128 + fo[s]);      \
+                }                                                                                          \
+            }                                                                                              \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                      \
             _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                              \
-                    /* weight fragment first: a lane then holds 4 CONSECUTIVE output columns per register quad */ \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_[j], a_[i], acc[i][j], 0, 0, 0);  \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_[s][j], a_[s][i], acc[i][j], 0, 0, 0); \
+        /* slice s+1's four reads go out under slice s's four MFMAs */                                     \
+        _Pragma("unroll") for (int s = 0; s < 3; ++s) {                                                    \
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                             \
         }                                                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
     }
+    half8_t h_a[2], h_b[2];
     const int nsteps = p.K / GM_BK;
-    GM_ISSUE(0)
-    if (nsteps > 1) GM_ISSUE(GM_STAGE)
-    int soff = 0, soff_issue = 2 * GM_STAGE;
-    for (int step = 0; step < nsteps; ++step) {
-        if (step + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GM_NPIECE) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GS_ISSUE(0)
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (step + 2 < nsteps) GM_ISSUE(soff_issue)
-        GM_COMPUTE(soff)
-        soff = soff + GM_STAGE == 3 * GM_STAGE ? 0 : soff + GM_STAGE;
-        soff_issue = soff_issue + GM_STAGE == 3 * GM_STAGE ? 0 : soff_issue + GM_STAGE;
+        GS_HEAD(0)
+        GS_ISSUE(STAGE)
+        GS_COMPUTE(0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        GS_HEAD(STAGE)
+        if (step + 2 < nsteps) GS_ISSUE(0)
+        GS_COMPUTE(STAGE)
+    }
+    if (step < nsteps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        GS_HEAD(0)
+        GS_COMPUTE(0)
     }
     __syncthreads();
-    // ---- epilogue: bias + activation, fp16, staged per wave (32 rows x 64 columns, pitch 144 B), rows leave as
-    //      128-byte runs (8 lanes x 16 B) with the residual added on the way out
     constexpr int PITCH = 144;
     unsigned char* st = lds + wave * (32 * PITCH);
     const int ncol0 = n0 + wn * 64;
@@ -142,10 +161,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_kernel(const GemmArgs p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int cl = j * 32 + 8 * g + 4 * (lane >> 5);           // column within the wave's 64
+                const int cl = j * 32 + 8 * g + 4 * (lane >> 5);
                 const int n = ncol0 + cl;
                 half4_t h, bq = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-                if (p.bias && n < p.N) bq = *reinterpret_cast<const half4_t*>(p.bias + n);      // N % 8 == 0, n % 4 == 0
+                if (p.bias && n < p.N) bq = *reinterpret_cast<const half4_t*>(p.bias + n);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float v = acc[i][j][4 * g + k] + (float)bq[k];
@@ -171,7 +190,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_kernel(const GemmArgs p) {
     }
 }
 
-// one wave per row: y = (x - mean) / sqrt(var + eps) * gamma + beta, statistics in fp32 (two passes over registers)
+// one wave per row: y = (x - mean) / sqrt(var + eps) * gamma + beta, statistics in fp32 (two passes over registers).
+// 16-byte loads and stores: lane l holds columns 8l .. 8l+7 and 512 + 8l .. (C <= 1024, C % 8 == 0) -- the first
+// version moved 2 bytes per lane and instruction and ran at 2 TB/s.
 __global__ __launch_bounds__(256) void layernorm_f16_kernel(const _Float16* __restrict__ x, long long ldx,
                                                             const _Float16* __restrict__ gamma, const _Float16* __restrict__ beta,
                                                             _Float16* __restrict__ out, long long ldo, int rows, int C, float eps) {
@@ -179,32 +200,42 @@ __global__ __launch_bounds__(256) void layernorm_f16_kernel(const _Float16* __re
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const _Float16* xr = x + (long long)row * ldx;
-    float v[16];                                               // C <= 1024
+    float v[2][8];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int c = lane + 64 * k;
-        v[k] = c < C ? (float)xr[c] : 0.f;
-        s += v[k];
+    for (int k = 0; k < 2; ++k) {
+        const int c = 512 * k + 8 * lane;
+        half8_t h = {};
+        if (c < C) h = *reinterpret_cast<const half8_t*>(xr + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[k][e] = (float)h[e]; s += v[k][e]; }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     const float mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int c = lane + 64 * k;
-        const float d = c < C ? v[k] - mean : 0.f;
-        q += d * d;
+    for (int k = 0; k < 2; ++k) {
+        if (512 * k + 8 * lane < C) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[k][e] - mean; q += d * d; }
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
     const float rstd = rsqrtf(q / (float)C + eps);
     _Float16* o = out + (long long)row * ldo;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int c = lane + 64 * k;
-        if (c < C) o[c] = (_Float16)((v[k] - mean) * rstd * (float)gamma[c] + (float)beta[c]);
+    for (int k = 0; k < 2; ++k) {
+        const int c = 512 * k + 8 * lane;
+        if (c < C) {
+            const half8_t g = *reinterpret_cast<const half8_t*>(gamma + c);
+            const half8_t bb = *reinterpret_cast<const half8_t*>(beta + c);
+            half8_t r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (_Float16)((v[k][e] - mean) * rstd * (float)g[e] + (float)bb[e]);
+            *reinterpret_cast<half8_t*>(o + c) = r;
+        }
     }
 }
 
@@ -415,21 +446,19 @@ int tise_gemm_f16(const void* a_dev, int64_t lda, const void* w_dev, int64_t ldw
     p.res = reinterpret_cast<const _Float16*>(res_dev); p.ldr = ldr;
     p.out = reinterpret_cast<_Float16*>(out_dev); p.ldo = ldo;
     p.M = m; p.N = n; p.K = k; p.act = act;
-    const long long tiles = (long long)((m + GM_BM - 1) / GM_BM) * ((n + GM_BN - 1) / GM_BN);
+    const long long tiles = (long long)((m + 127) / 128) * ((n + 127) / 128);
     if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
-    constexpr int lds = 3 * GM_STAGE;
-    static std::atomic<unsigned long long> attr_set{0};
-    if (tise_first_use_on_this_device(attr_set))
-        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL(gemm_f16_kernel, dim3((unsigned)tiles), dim3(512), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gemm_f16_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
 
 int tise_layernorm_f16(const void* x_dev, int64_t ldx, const void* gamma_dev, const void* beta_dev, void* out_dev, int64_t ldo,
                        int64_t rows, int C, float eps, void* stream) {
-    if (!x_dev || !gamma_dev || !beta_dev || !out_dev || rows < 0 || C <= 0 || C > 1024) return TISE_ERR_INVALID_ARG;
+    if (!x_dev || !gamma_dev || !beta_dev || !out_dev || rows < 0 || C <= 0 || C > 1024 || C % 8 != 0 || ldx % 8 != 0 || ldo % 8 != 0 ||
+        ((reinterpret_cast<uintptr_t>(x_dev) | reinterpret_cast<uintptr_t>(out_dev) | reinterpret_cast<uintptr_t>(gamma_dev) |
+          reinterpret_cast<uintptr_t>(beta_dev)) & 15) != 0)
+        return TISE_ERR_INVALID_ARG;
     if (rows == 0) return TISE_OK;
     if ((rows + 3) / 4 > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(layernorm_f16_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
