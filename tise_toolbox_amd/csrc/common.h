@@ -60,8 +60,8 @@ __host__ __device__ inline int tise_ilv_off(int c, int C) {
 __host__ __device__ inline int tise_ilv_second(int c, int C) { return c < (C & ~31) ? 32 : 16; }
 
 // Range guard of the split-fp16 activation format (v ~= hi + lo * 2^-11, hi = fp16(v)): a value above the fp16
-// range (65504) would become +inf in the hi plane and poison every later layer without any visible failure.  Every
-// kernel that WRITES split planes keeps the running maximum of what it converts (one v_max per element; all values
+// range (65504) would become +inf in the hi half and poison every later layer without any visible failure.  Every
+// kernel that WRITES split tensors keeps the running maximum of what it converts (one v_max per element; all values
 // are post-ReLU, i.e. >= 0) and raises bit 0 of a per-device word when it exceeds the range; the host reads and
 // clears the words with tise_split_overflow_check (capi.hip; the Python mirror raises FloatingPointError).
 // The library is built without relocatable device code, so each translation unit has its OWN word (unnamed

@@ -106,7 +106,7 @@ def resize_u8_only(src_u8, out_hw=(299, 299), out=None):
 
 def read_split_overflow():
     """Read-and-clear the range guard of the split-fp16 activation format (csrc/common.h): True when any kernel
-    since the last read converted a value above the fp16 range (65504) or a NaN into split planes.  Synchronises
+    since the last read converted a value above the fp16 range (65504) or a NaN into a split tensor.  Synchronises
     the current stream."""
     flag = ctypes.c_int(0)
     _lib.call("tise_split_overflow_check", ctypes.byref(flag), _stream())
@@ -114,7 +114,7 @@ def read_split_overflow():
 
 
 def check_split_overflow(what="InceptionV3 trunk", flag=None):
-    """Raise when the range guard fired: the hi plane would hold +inf and every later layer would be silently wrong."""
+    """Raise when the range guard fired: the hi half would hold +inf and every later layer would be silently wrong."""
     if flag is None:
         flag = read_split_overflow()
     if flag:
