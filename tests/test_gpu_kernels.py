@@ -472,6 +472,42 @@ def test_conv_split_variants_bitwise_identical_and_repeatable(dev, variant):
             assert torch.equal(out, ref), (variant, rep, (n, H, W, Cin, Cout))
 
 
+@pytest.mark.parametrize("case", [(17, 17, 192, 192, 1, 7, (0, 3), 3, 37), (35, 35, 96, 96, 3, 3, (1, 1), 3, 9), (8, 8, 448, 384, 3, 3, (1, 1), 4, 70),
+                                  (8, 8, 384, 384, 1, 3, (0, 1), 4, 33), (147, 147, 32, 64, 3, 3, (1, 1), 2, 3), (9, 13, 64, 80, 5, 3, (2, 1), 3, 21),
+                                  (6, 5, 32, 48, 1, 3, (0, 1), 2, 50)])
+def test_conv_rowwin_kernel_matches_fp64_conv(dev, case):
+    """Row-window kernel (the kw taps of a filter row share ONE fetch of the pixel operand, K order (kh, block, kw)):
+    against an fp64 convolution at the default kernel's tolerance -- image-row and image boundaries inside tiles (the
+    zero rows of the window), top / bottom padding (zero-page lines per kh), M and Cout tails, three destination
+    segments incl. raw fp32, rows shorter than 8 pixels -- and bit-identical over repeated runs."""
+    from tise_toolbox_amd.conv_split import SplitConv, merge, split
+    H, W, Cin, Cout, kh, kw, pad, tn, n = case
+    g = torch.Generator(device="cpu").manual_seed(H + Cin + Cout + kw)
+    x = (torch.rand((n, H, W, Cin), generator=g) * 3.0).to(dev)
+    w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
+    b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+    conv = SplitConv(w, b, (1, 1), pad, dev, tn=tn, variant="rowwin")
+    oh, ow = conv.out_hw(H, W)
+    ref_lin = torch.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, pad).permute(0, 2, 3, 1)
+    ref = torch.relu(ref_lin + b.double())
+    scale = ref.abs().max().item()
+    xs = split(x)
+    first = None
+    for rep in range(3):
+        out = torch.zeros((n, oh, ow, 2 * (Cout + 32)), dtype=torch.float16, device=dev)
+        raw = torch.zeros((n, oh, ow, 16), dtype=torch.float32, device=dev)
+        conv(xs, [(0, 16, out, 16, 0), (16, 32, raw, 0, 1), (32, Cout, out, 64, 0)])
+        got = merge(out)
+        assert (got[..., 16:32].double() - ref[..., 0:16]).abs().max().item() <= 4e-6 * scale
+        assert (got[..., 64:].double() - ref[..., 32:]).abs().max().item() <= 4e-6 * scale
+        assert (raw.double() - ref_lin[..., 16:32]).abs().max().item() <= 4e-6 * scale
+        assert got[..., :16].abs().max().item() == 0 and got[..., 32:64].abs().max().item() == 0
+        if first is None:
+            first = (out.clone(), raw.clone())
+        else:
+            assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
+
+
 def test_conv_split_tile_width_does_not_change_results(dev):
     """Every tile width (tn = 1..5) accumulates every output element over K in the same order with the same MFMA
     sequence: the outputs must be bit-identical -- the tile width is a pure performance choice (conv_split.pick_tn).
@@ -484,16 +520,19 @@ def test_conv_split_tile_width_does_not_change_results(dev):
         w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
         b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
         xs = split(x)
-        ref = None
-        for tn in (1, 2, 3, 4, 5):
-            conv = SplitConv(w, b, (st, st), pad, dev, tn=tn)
-            oh, ow = conv.out_hw(H, W)
-            out = torch.full((n, oh, ow, 2 * Cout), 5.0, dtype=torch.float16, device=dev)
-            conv(xs, [(0, Cout, out, 0, 0)])
-            if ref is None:
-                ref = out
-            else:
-                assert torch.equal(out, ref), (tn, Cin, Cout)
+        for variant, tns in (("fast", (1, 2, 3, 4, 5)), ("rowwin", (2, 3, 4))):
+            if variant == "rowwin" and (Cin % 32 or kw < 2):
+                continue
+            ref = None
+            for tn in tns:
+                conv = SplitConv(w, b, (st, st), pad, dev, tn=tn, variant=variant)
+                oh, ow = conv.out_hw(H, W)
+                out = torch.full((n, oh, ow, 2 * Cout), 5.0, dtype=torch.float16, device=dev)
+                conv(xs, [(0, Cout, out, 0, 0)])
+                if ref is None:
+                    ref = out
+                else:
+                    assert torch.equal(out, ref), (variant, tn, Cin, Cout)
 
 
 def test_split_trunk_batch_sizes_and_determinism(dev):

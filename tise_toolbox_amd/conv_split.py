@@ -110,6 +110,13 @@ def pick_tn(cout):
     return best[1]
 
 
+def rowwin_applies(cin, cout, kh, kw, stride, padding, tn):
+    """Layers the row-window kernel serves: stride 1, a filter wider than one pixel that keeps the row length
+    (2 * PW == KW - 1), whole 32-channel blocks, tile widths 2..4 (its LDS budget: two window buffers + two weight
+    stages, two workgroups per CU)."""
+    return (tuple(stride) == (1, 1) and 2 <= kw <= 8 and 2 * padding[1] == kw - 1 and cin % 32 == 0 and tn in (2, 3, 4))
+
+
 # conv_pipe.hip: configuration 33 = resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1), 32 couts per launch
 PIPE_BN = {33: 32}
 
@@ -132,8 +139,12 @@ class SplitConv:
         # kernel variant: "fast" = LDS-DMA staging with hoisted addressing (default); "glds" = its generic form
         # (addresses recomputed per K-step, natural K order, any M: the reference kernel of the tests);
         # "pipe" = conv_pipe.hip configuration 33 (Conv2d_2a)
-        self.variant = variant or os.environ.get("TISE_CONV_VARIANT", "fast")
-        if self.variant not in ("fast", "glds", "pipe"):
+        # "rowwin" = row-window kernel (the kw taps of a filter row share one fetch of the pixel operand); "auto" (the
+        # default) = rowwin where it applies and measured faster (tools/conv_rowwin_probe.py), else fast
+        self.variant = variant or os.environ.get("TISE_CONV_VARIANT", "auto")
+        if self.variant == "auto":
+            self.variant = "rowwin" if rowwin_applies(cin, cout, kh, kw, self.stride, self.padding, self.tn) else "fast"
+        if self.variant not in ("fast", "glds", "pipe", "rowwin"):
             raise ValueError(f"unknown conv variant {self.variant!r} (round 2 removed reg / glds3 / gldsb / win / spec)")
         # rows of zero weights / scale / bias up to the widest tile grid any tile width may use
         self.cout_pad = max(-(-cout // (32 * t)) * 32 * t for t in (1, 2, 3, 4, 5))
@@ -162,7 +173,13 @@ class SplitConv:
         # the default kernel reads the weights as ONE 128-byte line per (cout, 32-wide K block): [hi 32 | lo 32]
         # (conv_split_fast_kernel: 128-byte LDS-DMA rows); the planar (2, Cout_pad, Kpad) form serves "glds" / "pipe"
         self.w_fast = None
-        if self.variant == "fast":
+        if self.variant == "rowwin":
+            # row-window kernel: K order (kh, 32-channel block, kw) -- the kw taps of a (kh, block) group share one window
+            assert cin % 32 == 0 and self.tn in (2, 3, 4)
+            wr = torch.zeros((self.cout_pad, kh, kw, cin // 32, 32), dtype=torch.float32)
+            wr[:cout] = wk.reshape(cout, kh, kw, cin // 32, 32)
+            self.w = split_planes(wr.permute(0, 1, 3, 2, 4).reshape(self.cout_pad, self.k)).to(device).contiguous()
+        if self.variant in ("fast", "rowwin"):
             hi, lo = self.w[0], self.w[1]
             self.w_fast = torch.stack([hi.reshape(self.cout_pad, -1, 32), lo.reshape(self.cout_pad, -1, 32)], 2).contiguous()
             self.w = None
@@ -216,7 +233,7 @@ class SplitConv:
         if self.pipe_cfg is not None:
             code = 512 | self.pipe_cfg
         else:
-            code = tn | {"glds": 16, "fast": 128}[self.variant]
+            code = tn | {"glds": 16, "fast": 128, "rowwin": 64}[self.variant]
         _lib.call("tise_conv_split_f16", ctypes.byref(a), code, stream)
         if timer is not None:
             e1.record()

@@ -450,6 +450,263 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Row-window kernel ("rowwin"): the default kernel for stride-1 layers whose filter is wider than one pixel and keeps
+// the row length (OW == W, i.e. 2 * PW == KW - 1: the 1x7, 1x3 and padded 3x3 layers), Cin % 32 == 0.
+// In the default kernel the KW taps of a filter row fetch the SAME input pixels KW times, each time shifted by one
+// pixel.  Here the K loop runs (kh, 32-channel block, kw) and the pixel operand of a (kh, block) GROUP is fetched
+// once, as a window in "padded-x" coordinates: output pixel i of the tile (row ordinal j = (x0 + i) / W inside the
+// tile) sits at window row i + j * (KW - 1), its tap kw at window row i + j * (KW - 1) + kw; the KW - 1 rows between
+// two image rows are the right padding of one and the left padding of the next and are fetched from the zero page,
+// as are rows whose input line oy + kh - PH lies outside the image.  No masking in registers; the fragment address
+// moves by one row per tap.  The window of the next group is fetched piece by piece during the KW steps of the
+// current one (two window buffers); the weights stream as before (two stages, one K-step ahead).  Pixel-operand DMA
+// per group: 128 + J * (KW - 1) rows (J <= 128 / W + 2 image rows) instead of 128 * KW.
+// K order differs from the default kernel's (tap-major), so results differ from it in the last bits (fp32 summation
+// order); against fp64 both have the same error.
+template <int TN, int NP>
+__global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArgs p, const unsigned inv_wp) {
+    constexpr int BN = 32 * TN;
+    constexpr int A_BYTES = NP * 4 * 1024;                    // window buffer: NP pieces (8 rows x 128 B) per wave
+    constexpr int B_BYTES = BN * 128;
+    constexpr int B0 = 2 * A_BYTES;
+    constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned tiles_n = (unsigned)(p.Cout + BN - 1) / BN;
+    const unsigned nwg = gridDim.x;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const unsigned tile_m = bid / tiles_n;
+    const int tile_n = (int)(bid - tile_m * tiles_n);
+    const long long m0 = (long long)tile_m * CS_BM;
+    const int n0 = tile_n * BN;
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_conv_zero_page);
+    const int pix_bytes = p.Cin * 4;
+    const int Wp = p.W + p.KW - 1;
+    const unsigned row0 = (unsigned)(tile_m * CS_BM) / (unsigned)p.W;      // global output line of the tile's first pixel
+    const int x0 = (int)(tile_m * CS_BM - row0 * (unsigned)p.W);
+    const unsigned img0 = row0 / (unsigned)p.OH;
+    const int oy0 = (int)(row0 - img0 * (unsigned)p.OH);
+    const unsigned nrows_out = (unsigned)p.N * (unsigned)p.OH;
+
+    // window pieces of this wave: piece q = wave + 4 t, window row rho = 8 q + (lane >> 3), 16-byte chunk by piece parity
+    const unsigned char* pbase[NP];                           // source of (row, kh = 0, block 0), this lane's chunk
+    int oyp[NP];                                              // oy - PH + 0x4000 of the row's image line, 0 = zero row
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+        const int q = wave + 4 * t;
+        const int rho = 8 * q + (lane >> 3);
+        const int c = (lane & 7) ^ ((((q & 1) << 2) | (lane >> 4)));
+        const unsigned u = (unsigned)(rho + x0);
+        const unsigned j = (u * inv_wp) >> 16;                // u / Wp (exact for u < 2048: host check)
+        const int xin = (int)(u - j * (unsigned)Wp) - p.PW;
+        unsigned n = img0;
+        int oy = oy0 + (int)j;
+        while (oy >= p.OH) { oy -= p.OH; ++n; }
+        const bool okx = xin >= 0 && xin < p.W && row0 + j < nrows_out;
+        oyp[t] = okx ? oy - p.PH + 0x4000 : 0;
+        pbase[t] = reinterpret_cast<const unsigned char*>(p.x) +
+                   (((long long)n * p.H + (oy - p.PH)) * p.W + xin) * pix_bytes + c * 16;
+    }
+    // weights: as in the default kernel (one scalar base + a 32-bit offset per piece, 128 bytes per K-step)
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (long long)n0 * p.Kpad * 4;
+    unsigned pb[TN];
+    int pb_off[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int q = wave * TN + i;
+        const int r = q * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        pb[i] = (unsigned)r * (unsigned)p.Kpad * 4u + c * 16;
+        pb_off[i] = q * 1024;
+    }
+    // fragment rows: this lane's pixel i = 32 wave + (lane & 31) sits at window row i + j(i) * (KW - 1)
+    int arow;
+    {
+        const int i = wave * 32 + (lane & 31);
+        const unsigned inv_w = 65536u / (unsigned)p.W + 1u;
+        const unsigned ji = ((unsigned)(x0 + i) * inv_w) >> 16;          // (x0 + i) / W, x0 + i < 2 W + 128
+        arow = i + (int)ji * (p.KW - 1);
+    }
+    const int bswz = ((lane & 31) >> 1) & 7;
+    const int fb0 = (lane & 31) * 128 + (((lane >> 5)) ^ bswz) * 16;
+    const int fb1 = (lane & 31) * 128 + ((2 + (lane >> 5)) ^ bswz) * 16;
+
+    float16_t acc_main[1][TN], acc_corr[1][TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc_main[0][t][j] = 0.f; acc_corr[0][t][j] = 0.f; }
+    conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
+    if (tid < BN / 4) {
+        sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + n0 + 4 * tid);
+        bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + n0 + 4 * tid);
+    }
+
+    const int ncblk = p.Cin / CS_BK;
+    const int ngroups = p.KH * ncblk;
+    const int nsteps = ngroups * p.KW;
+    int tmod[NP];                                             // the step of a group at which window piece t of the next group goes out
+#pragma unroll
+    for (int t = 0; t < NP; ++t) tmod[t] = t % p.KW;
+// window piece T of group (GKH, GCB) into window buffer AOFF
+#define RW_A_PIECE(T, GKH, GCB, AOFF)                                                                     \
+    {                                                                                                     \
+        const int iy = oyp[T] - 0x4000 + (GKH);                                                            \
+        const bool ok = (unsigned)iy < (unsigned)p.H;                                                      \
+        const unsigned char* src = pbase[T] + ((GKH) * p.W * pix_bytes + (GCB) * 128);                     \
+        src = ok ? src : zp;                                                                               \
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(lds + (AOFF) + (wave + 4 * (T)) * 1024), 16, 0, 0); \
+    }
+#define RW_B_ISSUE(BOFF)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                       \
+        const unsigned char* sw_ = wbase + pb[i];                                                          \
+        __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)(lds + (BOFF) + pb_off[i]), 16, 0, 0);            \
+        pb[i] += 128;                                                                                      \
+    }
+// one K-step: weights of the next step, a share of the next group's window, then reads + MFMAs
+#define RW_STEP(BCUR, BNEXT)                                                                              \
+    {                                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+        __syncthreads();                                                                                   \
+        const int row = arow + kw;                                                                         \
+        const int aswz = (row >> 1) & 7;                                                                   \
+        const unsigned char* ap = lds + acur + row * 128;                                                  \
+        const int ao0 = (((lane >> 5)) ^ aswz) * 16, ao1 = ((2 + (lane >> 5)) ^ aswz) * 16;                \
+        half8_t fa_[2][2], fb_[2][TN][2];                                                                  \
+        fa_[0][0] = *reinterpret_cast<const half8_t*>(ap + ao0);                                           \
+        fa_[0][1] = *reinterpret_cast<const half8_t*>(ap + (ao0 ^ 64));                                    \
+        fb_[0][0][0] = *reinterpret_cast<const half8_t*>(lds + (BCUR) + fb0);                              \
+        fb_[0][0][1] = *reinterpret_cast<const half8_t*>(lds + (BCUR) + (fb0 ^ 64));                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (step + 1 < nsteps) RW_B_ISSUE(BNEXT)                                                           \
+        if (gnext < ngroups) {                                                                             \
+            _Pragma("unroll") for (int t = 0; t < NP; ++t)                                                 \
+                if (tmod[t] == kw) RW_A_PIECE(t, nkh, ncb, anext)                                          \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
+            const int fbo = s ? fb1 : fb0;                                                                 \
+            if (s == 1) {                                                                                  \
+                fa_[1][0] = *reinterpret_cast<const half8_t*>(ap + ao1);                                   \
+                fa_[1][1] = *reinterpret_cast<const half8_t*>(ap + (ao1 ^ 64));                            \
+            }                                                                                              \
+            _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
+                const unsigned char* bb = lds + (BCUR) + t * 32 * 128;                                     \
+                if (s != 0 || t != 0) {                                                                    \
+                    fb_[s][t][0] = *reinterpret_cast<const half8_t*>(bb + fbo);                            \
+                    fb_[s][t][1] = *reinterpret_cast<const half8_t*>(bb + (fbo ^ 64));                     \
+                }                                                                                          \
+            }                                                                                              \
+        }                                                                                                  \
+        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \
+            _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
+                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][1], fa_[s][0], acc_corr[0][t], 0, 0, 0); \
+                acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][0], acc_main[0][t], 0, 0, 0); \
+                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][1], acc_corr[0][t], 0, 0, 0); \
+            }                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < TN - 1; ++i) {                                               \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                             \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                 \
+        _Pragma("unroll") for (int i = 0; i < TN - 1; ++i) {                                               \
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                             \
+        }                                                                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        ++step;                                                                                            \
+        if (++kw == p.KW) {                                   /* next group */                             \
+            kw = 0;                                                                                        \
+            const int tsw = acur; acur = anext; anext = tsw;                                               \
+            ++gnext;                                                                                       \
+            if (++ncb == ncblk) { ncb = 0; ++nkh; }                                                        \
+        }                                                                                                  \
+    }
+
+    // prologue: the first group's window and the first step's weights
+#pragma unroll
+    for (int t = 0; t < NP; ++t) RW_A_PIECE(t, 0, 0, 0)
+    RW_B_ISSUE(B0)
+    int step = 0, kw = 0, acur = 0, anext = A_BYTES;
+    int gnext = 1, nkh = ncblk > 1 ? 0 : 1, ncb = ncblk > 1 ? 1 : 0;   // the group whose window is fetched during the current one
+    while (step < nsteps) {
+        RW_STEP(B0, B0 + B_BYTES)
+        if (step < nsteps) RW_STEP(B0 + B_BYTES, B0)
+    }
+    __syncthreads();
+    constexpr int ETW = TN > 1 ? 2 : 1;
+    constexpr int EPI0 = 4 * conv_epi::Staging<ETW>::BYTES;
+    static_assert(EPI0 + conv_epi::EpiArea<BN>::BYTES <= LDS_BYTES, "epilogue staging must fit the operand LDS");
+    conv_epi::prepare<BN>(p, lds + EPI0, n0, sc_pre, bs_pre);
+    __syncthreads();
+    conv_epi::store_tiles_desc<TN, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, lds + EPI0, m0 + wave * 32);
+}
+
+template <int TN, int NP>
+static int launch_rowwin(const ConvArgs* args, hipStream_t st) {
+    constexpr int LDS = 2 * NP * 4096 + 2 * 32 * TN * 128;
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+    static std::atomic<unsigned long long> attr_set{0};
+    if (tise_first_use_on_this_device(attr_set)) {
+        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_rowwin_kernel<TN, NP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+    }
+    const int bn = 32 * TN;
+    const long long tiles = ((args->M + CS_BM - 1) / CS_BM) * ((args->Cout + bn - 1) / bn);
+    if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
+    const unsigned wp = (unsigned)(args->W + args->KW - 1);
+    const unsigned inv_wp = 65536u / wp + 1u;
+    hipLaunchKernelGGL((conv_split_rowwin_kernel<TN, NP>), dim3((unsigned)tiles), dim3(256), LDS, st, *args, inv_wp);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+// window pieces per wave a layer needs: rows 128 + J (KW - 1) with J = (W + 126) / W + 1 image rows at most
+static int rowwin_np(const ConvArgs* a) {
+    const int J = (a->W + 126) / a->W + 1;
+    const int rows = 128 + J * (a->KW - 1);
+    return (rows + 31) / 32;
+}
+
+static int launch_rowwin_any(const ConvArgs* a, int tn, hipStream_t st) {
+    if (a->SH != 1 || a->SW != 1 || a->KW < 2 || a->KW > 8 || 2 * a->PW != a->KW - 1 || a->OW != a->W || a->Cin % 32 != 0 ||
+        a->Kpad != a->KH * a->KW * a->Cin || a->M >= 0x7fffff00LL || a->H >= 0x3f00 || a->PH >= 0x100)
+        return TISE_ERR_INVALID_ARG;
+    {   // the multiply-shift divisions of the kernel must be exact over their ranges
+        const unsigned wp = (unsigned)(a->W + a->KW - 1), w = (unsigned)a->W;
+        const unsigned iwp = 65536u / wp + 1u, iw = 65536u / w + 1u;
+        for (unsigned u = 0; u < 512 + w; ++u)
+            if (((u * iwp) >> 16) != u / wp || ((u * iw) >> 16) != u / w) return TISE_ERR_UNSUPPORTED;
+    }
+    const int np = rowwin_np(a);
+    if (np == 5) {
+        switch (tn) {
+            case 2: return launch_rowwin<2, 5>(a, st);
+            case 3: return launch_rowwin<3, 5>(a, st);
+            case 4: return launch_rowwin<4, 5>(a, st);
+            default: return TISE_ERR_INVALID_ARG;
+        }
+    }
+    if (np == 6) {
+        switch (tn) {
+            case 2: return launch_rowwin<2, 6>(a, st);
+            case 3: return launch_rowwin<3, 6>(a, st);
+            case 4: return launch_rowwin<4, 6>(a, st);
+            default: return TISE_ERR_INVALID_ARG;
+        }
+    }
+    return TISE_ERR_UNSUPPORTED;
+}
+
 int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream);   // conv_pipe.hip
 
 extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
@@ -468,6 +725,7 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     }
     if (args->seg[0].c0 != 0) return TISE_ERR_INVALID_ARG;
     if (tn & 512) return tise_conv_pipe_launch(args, tn & 255, stream);   // resident-weights sliding-window kernel
+    if (tn & 64) return launch_rowwin_any(args, tn & 15, (hipStream_t)stream);   // row-window kernel, K order (kh, block, kw)
     const bool glds = (tn & 16) != 0;
     // fast path: K order (tap, full 32-channel block) then paired 16-channel tails (see the kernel); Kpad says which
     const int fast_kpad = (args->KH * args->KW * (args->Cin / 32) + ((args->Cin & 16) ? (args->KH * args->KW + 1) / 2 : 0)) * 32;

@@ -259,7 +259,7 @@ class SplitTrunk(FusedTrunk):
         self.s2a, self.s2b, self.s3b, self.s4a = sc(self.c2a), sc(self.c2b), sc(self.c3b), sc(self.c4a)
         # Conv2d_2a (149^2 x 32 -> 32, 3x3): resident-weights sliding-window kernel (conv_pipe.hip configuration 33),
         # 1.05 vs 1.34 ms at batch 500; for the 64-cout Conv2d_2b it needs two launches and only ties (1.96 vs 1.90)
-        if os.environ.get("TISE_CONV_VARIANT", "fast") == "fast" and os.environ.get("TISE_CONV_WIN32", "1") != "0":
+        if os.environ.get("TISE_CONV_VARIANT", "auto") in ("auto", "fast") and os.environ.get("TISE_CONV_WIN32", "1") != "0":
             self.s2a = SplitConv(self.c2a.w, self.c2a.b, self.c2a.stride, self.c2a.padding, self.device, variant="pipe", pipe_cfg=33)
         # stem weights for the direct kernel: [kh][kw][cin][cout] fp32
         self.stem_w = self.c1a.w.permute(2, 3, 1, 0).contiguous().float()
