@@ -389,10 +389,10 @@ def main():
             # algorithmic work = the convolution's 2*M*N*K flop.  The kernel spends THREE fp16 MFMA flop per
             # algorithmic flop (hi*hi, hi*lo, lo*hi), so its ceiling is the dense fp16 MFMA peak / 3.
             kern["conv_split_fast_kernel"] = {
-                "instances": "all convolution launches of a device batch, as rocprofv3 lists them (conv_split_fast_kernel<TN> + "
-                             "conv_win32_kernel; profiles/r02*_kernel_stats.md)",
-                "clock_note": "in-kernel stamps (profiles/r01g_conv_pipe_stamps.txt): 1.49 GHz while the MFMAs are busy, i.e. "
-                              "~1550 TFLOP/s fp16 actually available; peak below is the 2.4 GHz datasheet figure / 3",
+                "instances": "all convolution launches of a device batch, as rocprofv3 lists them (conv_split_fast_kernel<TN>, "
+                             "conv_split_rowwin_kernel<TN, NP>, conv_win32_kernel; profiles/r02*_kernel_stats.md)",
+                "clock_note": "the image loop runs at 95-97 % of the 1400 W package power limit (profiles/r02w_power_during_bench.txt; "
+                              "in-kernel stamps: 1.34-1.8 GHz while the MFMAs are busy); peak below is the 2.4 GHz datasheet figure / 3",
                 "bound": "mfma", "achieved": conv_flop / (conv_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3.0,
                 "unit": "TFLOP/s", "avg_ms": conv_ms / timed_steps, "avg_launch_ms": conv_ms / n_launch,
                 "launches_per_batch": n_launch / timed_steps, "algorithmic_flop_per_batch": conv_flop / timed_steps,
