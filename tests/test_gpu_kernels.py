@@ -474,12 +474,14 @@ def test_conv_split_variants_bitwise_identical_and_repeatable(dev, variant):
 
 @pytest.mark.parametrize("case", [(17, 17, 192, 192, 1, 7, (0, 3), 3, 37), (35, 35, 96, 96, 3, 3, (1, 1), 3, 9), (8, 8, 448, 384, 3, 3, (1, 1), 4, 70),
                                   (8, 8, 384, 384, 1, 3, (0, 1), 4, 33), (147, 147, 32, 64, 3, 3, (1, 1), 2, 3), (9, 13, 64, 80, 5, 3, (2, 1), 3, 21),
-                                  (6, 5, 32, 48, 1, 3, (0, 1), 2, 50)])
+                                  (6, 5, 32, 48, 1, 3, (0, 1), 2, 50), (73, 73, 80, 192, 3, 3, (0, 0), 3, 2), (35, 35, 48, 64, 5, 5, (2, 2), 2, 7),
+                                  (12, 10, 80, 96, 2, 4, (1, 0), 3, 19), (9, 9, 112, 64, 3, 3, (0, 1), 2, 23)])
 def test_conv_rowwin_kernel_matches_fp64_conv(dev, case):
     """Row-window kernel (the kw taps of a filter row share ONE fetch of the pixel operand, K order (kh, block, kw)):
     against an fp64 convolution at the default kernel's tolerance -- image-row and image boundaries inside tiles (the
-    zero rows of the window), top / bottom padding (zero-page lines per kh), M and Cout tails, three destination
-    segments incl. raw fp32, rows shorter than 8 pixels -- and bit-identical over repeated runs."""
+    zero rows of the window), top / bottom padding (zero-page lines per kh), valid and asymmetric padding, Cin = 32 n + 16
+    (tail groups pairing two taps per step, odd and even KW), M and Cout tails, three destination segments incl. raw
+    fp32, rows shorter than 8 pixels -- and bit-identical over repeated runs."""
     from tise_toolbox_amd.conv_split import SplitConv, merge, split
     H, W, Cin, Cout, kh, kw, pad, tn, n = case
     g = torch.Generator(device="cpu").manual_seed(H + Cin + Cout + kw)
@@ -521,7 +523,7 @@ def test_conv_split_tile_width_does_not_change_results(dev):
         b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
         xs = split(x)
         for variant, tns in (("fast", (1, 2, 3, 4, 5)), ("rowwin", (2, 3, 4))):
-            if variant == "rowwin" and (Cin % 32 or kw < 2):
+            if variant == "rowwin" and kw < 2:
                 continue
             ref = None
             for tn in tns:

@@ -111,10 +111,9 @@ def pick_tn(cout):
 
 
 def rowwin_applies(cin, cout, kh, kw, stride, padding, tn):
-    """Layers the row-window kernel serves: stride 1, a filter wider than one pixel that keeps the row length
-    (2 * PW == KW - 1), whole 32-channel blocks, tile widths 2..4 (its LDS budget: two window buffers + two weight
-    stages, two workgroups per CU)."""
-    return (tuple(stride) == (1, 1) and 2 <= kw <= 8 and 2 * padding[1] == kw - 1 and cin % 32 == 0 and tn in (2, 3, 4))
+    """Layers the row-window kernel serves: stride 1, a filter wider than one pixel, tile widths 2..4 (its LDS budget:
+    two window buffers + two weight stages, two workgroups per CU)."""
+    return tuple(stride) == (1, 1) and 2 <= kw <= 8 and cin % 16 == 0 and cin >= 32 and tn in (2, 3, 4)
 
 
 # conv_pipe.hip: configuration 33 = resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1), 32 couts per launch
@@ -174,11 +173,23 @@ class SplitConv:
         # (conv_split_fast_kernel: 128-byte LDS-DMA rows); the planar (2, Cout_pad, Kpad) form serves "glds" / "pipe"
         self.w_fast = None
         if self.variant == "rowwin":
-            # row-window kernel: K order (kh, 32-channel block, kw) -- the kw taps of a (kh, block) group share one window
-            assert cin % 32 == 0 and self.tn in (2, 3, 4)
-            wr = torch.zeros((self.cout_pad, kh, kw, cin // 32, 32), dtype=torch.float32)
-            wr[:cout] = wk.reshape(cout, kh, kw, cin // 32, 32)
-            self.w = split_planes(wr.permute(0, 1, 3, 2, 4).reshape(self.cout_pad, self.k)).to(device).contiguous()
+            # row-window kernel: K order (kh, 32-channel block, kw) -- the kw taps of a (kh, block) group share one window;
+            # Cin = 32 n + 16: each kh ends with the 16-channel tails, two taps per 32-wide step
+            assert cin % 16 == 0 and self.tn in (2, 3, 4)
+            nfull, tail = cin // 32, cin % 32
+            w4 = torch.zeros((self.cout_pad, kh, kw, cin), dtype=torch.float32)
+            w4[:cout] = wk.reshape(cout, kh, kw, cin)
+            per_kh = []
+            for a in range(kh):
+                if nfull:
+                    full = w4[:, a, :, :nfull * 32].reshape(self.cout_pad, kw, nfull, 32).permute(0, 2, 1, 3)
+                    per_kh.append(full.reshape(self.cout_pad, nfull * kw * 32))
+                if tail:
+                    tl = torch.zeros((self.cout_pad, (kw + 1) // 2 * 2, 16), dtype=torch.float32)
+                    tl[:, :kw] = w4[:, a, :, nfull * 32:]
+                    per_kh.append(tl.reshape(self.cout_pad, -1))
+            self.w = split_planes(torch.cat(per_kh, 1)).to(device).contiguous()
+            self.kpad = self.w.shape[2]
         if self.variant in ("fast", "rowwin"):
             hi, lo = self.w[0], self.w[1]
             self.w_fast = torch.stack([hi.reshape(self.cout_pad, -1, 32), lo.reshape(self.cout_pad, -1, 32)], 2).contiguous()

@@ -451,17 +451,21 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
 
 
 // ------------------------------------------------------------------------------------------------
-// Row-window kernel ("rowwin"): the default kernel for stride-1 layers whose filter is wider than one pixel and keeps
-// the row length (OW == W, i.e. 2 * PW == KW - 1: the 1x7, 1x3 and padded 3x3 layers), Cin % 32 == 0.
+// Row-window kernel ("rowwin"): the default kernel for stride-1 layers whose filter is wider than one pixel (the 1x7,
+// 1x3, 3x3 and 5x5 layers, padded or not).
 // In the default kernel the KW taps of a filter row fetch the SAME input pixels KW times, each time shifted by one
 // pixel.  Here the K loop runs (kh, 32-channel block, kw) and the pixel operand of a (kh, block) GROUP is fetched
-// once, as a window in "padded-x" coordinates: output pixel i of the tile (row ordinal j = (x0 + i) / W inside the
-// tile) sits at window row i + j * (KW - 1), its tap kw at window row i + j * (KW - 1) + kw; the KW - 1 rows between
-// two image rows are the right padding of one and the left padding of the next and are fetched from the zero page,
-// as are rows whose input line oy + kh - PH lies outside the image.  No masking in registers; the fragment address
-// moves by one row per tap.  The window of the next group is fetched piece by piece during the KW steps of the
-// current one (two window buffers); the weights stream as before (two stages, one K-step ahead).  Pixel-operand DMA
-// per group: 128 + J * (KW - 1) rows (J <= 128 / W + 2 image rows) instead of 128 * KW.
+// once, as a window in "padded-x" coordinates: output pixel i of the tile (row ordinal j = (x0 + i) / OW inside the
+// tile) sits at window row i + j * (KW - 1), its tap kw at window row i + j * (KW - 1) + kw; a row ordinal owns
+// OW + KW - 1 = W + 2 PW window rows: PW of left padding, the W input pixels, PW of right padding (zero page), and
+// rows whose input line oy + kh - PH lies outside the image come from the zero page as well.  No masking in
+// registers; the fragment address moves by one row per tap.  The window of the next group is fetched piece by piece
+// during the steps of the current one (two window buffers); the weights stream as before (two stages, one K-step
+// ahead).  Pixel-operand DMA per group: 128 + J * (KW - 1) rows (J <= 128 / OW + 2 image rows) instead of 128 * KW.
+// Cin = 32 n + 16: each kh ends with a TAIL group of the last 16 channels whose steps pair two taps -- K-slice 0
+// reads tap 2p at the window row of tap 2p, K-slice 1 tap 2p + 1 one row further, both from the 16-channel columns
+// (chunks 0-1 hi, 4-5 lo of the row; the rest of a tail row is fetched from the zero page) -- so the tail costs
+// ceil(KW / 2) steps per kh, like the default kernel's paired tails.
 // K order differs from the default kernel's (tap-major), so results differ from it in the last bits (fp32 summation
 // order); against fp64 both have the same error.
 template <int TN, int NP>
@@ -488,21 +492,25 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
     const int n0 = tile_n * BN;
     const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_conv_zero_page);
     const int pix_bytes = p.Cin * 4;
-    const int Wp = p.W + p.KW - 1;
-    const unsigned row0 = (unsigned)(tile_m * CS_BM) / (unsigned)p.W;      // global output line of the tile's first pixel
-    const int x0 = (int)(tile_m * CS_BM - row0 * (unsigned)p.W);
+    const int Wp = p.OW + p.KW - 1;                           // window rows per image row = W + 2 PW
+    const unsigned row0 = (unsigned)(tile_m * CS_BM) / (unsigned)p.OW;     // global output line of the tile's first pixel
+    const int x0 = (int)(tile_m * CS_BM - row0 * (unsigned)p.OW);
     const unsigned img0 = row0 / (unsigned)p.OH;
     const int oy0 = (int)(row0 - img0 * (unsigned)p.OH);
     const unsigned nrows_out = (unsigned)p.N * (unsigned)p.OH;
 
     // window pieces of this wave: piece q = wave + 4 t, window row rho = 8 q + (lane >> 3), 16-byte chunk by piece parity
-    const unsigned char* pbase[NP];                           // source of (row, kh = 0, block 0), this lane's chunk
+    const unsigned char* pbase[NP];                           // source of (row, kh = 0, block 0, chunk 0)
     int oyp[NP];                                              // oy - PH + 0x4000 of the row's image line, 0 = zero row
+    // every piece of a wave has the wave's parity (q = wave + 4 t), so a lane fetches ONE logical chunk in all of them
+    const int cch = (lane & 7) ^ ((((wave & 1) << 2) | (lane >> 4)));
+    const int full_off = cch * 16;                            // byte offset of that chunk inside a full block's line
+    const int tail_off = (cch >> 2) * 32 + (cch & 1) * 16;    // ... inside the 64-byte tail block [hi x16 | lo x16]
+    const bool tail_has = (cch & 3) < 2;                      // chunks 2, 3, 6, 7 of a tail row are zeros
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
         const int q = wave + 4 * t;
         const int rho = 8 * q + (lane >> 3);
-        const int c = (lane & 7) ^ ((((q & 1) << 2) | (lane >> 4)));
         const unsigned u = (unsigned)(rho + x0);
         const unsigned j = (u * inv_wp) >> 16;                // u / Wp (exact for u < 2048: host check)
         const int xin = (int)(u - j * (unsigned)Wp) - p.PW;
@@ -512,7 +520,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
         const bool okx = xin >= 0 && xin < p.W && row0 + j < nrows_out;
         oyp[t] = okx ? oy - p.PH + 0x4000 : 0;
         pbase[t] = reinterpret_cast<const unsigned char*>(p.x) +
-                   (((long long)n * p.H + (oy - p.PH)) * p.W + xin) * pix_bytes + c * 16;
+                   (((long long)n * p.H + (oy - p.PH)) * p.W + xin) * pix_bytes;
     }
     // weights: as in the default kernel (one scalar base + a 32-bit offset per piece, 128 bytes per K-step)
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (long long)n0 * p.Kpad * 4;
@@ -530,8 +538,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
     int arow;
     {
         const int i = wave * 32 + (lane & 31);
-        const unsigned inv_w = 65536u / (unsigned)p.W + 1u;
-        const unsigned ji = ((unsigned)(x0 + i) * inv_w) >> 16;          // (x0 + i) / W, x0 + i < 2 W + 128
+        const unsigned inv_w = 65536u / (unsigned)p.OW + 1u;
+        const unsigned ji = ((unsigned)(x0 + i) * inv_w) >> 16;          // (x0 + i) / OW, x0 + i < OW + 128
         arow = i + (int)ji * (p.KW - 1);
     }
     const int bswz = ((lane & 31) >> 1) & 7;
@@ -549,18 +557,22 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
         bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + n0 + 4 * tid);
     }
 
-    const int ncblk = p.Cin / CS_BK;
-    const int ngroups = p.KH * ncblk;
-    const int nsteps = ngroups * p.KW;
-    int tmod[NP];                                             // the step of a group at which window piece t of the next group goes out
+    const int ncblk = p.Cin / CS_BK;                          // full 32-channel blocks
+    const int has_tail = (p.Cin & 16) ? 1 : 0;
+    const int gpk = ncblk + has_tail;                         // groups per kh; group index gpk - 1 is the tail when has_tail
+    const int tail_steps = (p.KW + 1) / 2;
+    const int ngroups = p.KH * gpk;
+    const int nsteps = p.KH * (ncblk * p.KW + has_tail * tail_steps);
+    int tmodf[NP], tmodt[NP];                                 // the step of a full / tail group at which window piece t of the next group goes out
 #pragma unroll
-    for (int t = 0; t < NP; ++t) tmod[t] = t % p.KW;
+    for (int t = 0; t < NP; ++t) { tmodf[t] = t % p.KW; tmodt[t] = t % tail_steps; }
 // window piece T of group (GKH, GCB) into window buffer AOFF
 #define RW_A_PIECE(T, GKH, GCB, AOFF)                                                                     \
     {                                                                                                     \
         const int iy = oyp[T] - 0x4000 + (GKH);                                                            \
-        const bool ok = (unsigned)iy < (unsigned)p.H;                                                      \
-        const unsigned char* src = pbase[T] + ((GKH) * p.W * pix_bytes + (GCB) * 128);                     \
+        const bool gt_ = has_tail && (GCB) == ncblk;            /* the group is a tail group (wave-uniform) */ \
+        const bool ok = (unsigned)iy < (unsigned)p.H && (!gt_ || tail_has);                                \
+        const unsigned char* src = pbase[T] + ((GKH) * p.W * pix_bytes + (GCB) * 128 + (gt_ ? tail_off : full_off)); \
         src = ok ? src : zp;                                                                               \
         __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(lds + (AOFF) + (wave + 4 * (T)) * 1024), 16, 0, 0); \
     }
@@ -575,10 +587,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
     {                                                                                                     \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
         __syncthreads();                                                                                   \
-        const int row = arow + kw;                                                                         \
-        const int aswz = (row >> 1) & 7;                                                                   \
+        /* K-slice 0 / 1: full group: the two 16-channel halves of tap kw's row; tail group: taps 2 kw and 2 kw + 1 */ \
+        const int row = arow + (cur_tail ? 2 * kw : kw);                                                   \
+        const int row1 = row + cur_tail;                                                                   \
         const unsigned char* ap = lds + acur + row * 128;                                                  \
-        const int ao0 = (((lane >> 5)) ^ aswz) * 16, ao1 = ((2 + (lane >> 5)) ^ aswz) * 16;                \
+        const unsigned char* ap1 = lds + acur + row1 * 128;                                                \
+        const int ao0 = (((lane >> 5)) ^ ((row >> 1) & 7)) * 16;                                           \
+        const int ao1 = (((cur_tail ? 0 : 2) + (lane >> 5)) ^ ((row1 >> 1) & 7)) * 16;                     \
         half8_t fa_[2][2], fb_[2][TN][2];                                                                  \
         fa_[0][0] = *reinterpret_cast<const half8_t*>(ap + ao0);                                           \
         fa_[0][1] = *reinterpret_cast<const half8_t*>(ap + (ao0 ^ 64));                                    \
@@ -588,14 +603,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
         if (step + 1 < nsteps) RW_B_ISSUE(BNEXT)                                                           \
         if (gnext < ngroups) {                                                                             \
             _Pragma("unroll") for (int t = 0; t < NP; ++t)                                                 \
-                if (tmod[t] == kw) RW_A_PIECE(t, nkh, ncb, anext)                                          \
+                if ((cur_tail ? tmodt[t] : tmodf[t]) == kw) RW_A_PIECE(t, nkh, ncb, anext)                 \
         }                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
             const int fbo = s ? fb1 : fb0;                                                                 \
             if (s == 1) {                                                                                  \
-                fa_[1][0] = *reinterpret_cast<const half8_t*>(ap + ao1);                                   \
-                fa_[1][1] = *reinterpret_cast<const half8_t*>(ap + (ao1 ^ 64));                            \
+                fa_[1][0] = *reinterpret_cast<const half8_t*>(ap1 + ao1);                                  \
+                fa_[1][1] = *reinterpret_cast<const half8_t*>(ap1 + (ao1 ^ 64));                           \
             }                                                                                              \
             _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
                 const unsigned char* bb = lds + (BCUR) + t * 32 * 128;                                     \
@@ -624,11 +639,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
         __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         ++step;                                                                                            \
-        if (++kw == p.KW) {                                   /* next group */                             \
+        if (++kw == (cur_tail ? tail_steps : p.KW)) {         /* next group */                             \
             kw = 0;                                                                                        \
             const int tsw = acur; acur = anext; anext = tsw;                                               \
+            cur_tail = has_tail && ncb == ncblk;              /* the group just fetched becomes the current one */ \
             ++gnext;                                                                                       \
-            if (++ncb == ncblk) { ncb = 0; ++nkh; }                                                        \
+            if (++ncb == gpk) { ncb = 0; ++nkh; }                                                          \
         }                                                                                                  \
     }
 
@@ -637,7 +653,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
     for (int t = 0; t < NP; ++t) RW_A_PIECE(t, 0, 0, 0)
     RW_B_ISSUE(B0)
     int step = 0, kw = 0, acur = 0, anext = A_BYTES;
-    int gnext = 1, nkh = ncblk > 1 ? 0 : 1, ncb = ncblk > 1 ? 1 : 0;   // the group whose window is fetched during the current one
+    int cur_tail = 0;                                         // the first group of a kh is a full one (Cin >= 32)
+    int gnext = 1, nkh = gpk > 1 ? 0 : 1, ncb = gpk > 1 ? 1 : 0;       // the group whose window is fetched during the current one
     while (step < nsteps) {
         RW_STEP(B0, B0 + B_BYTES)
         if (step < nsteps) RW_STEP(B0 + B_BYTES, B0)
@@ -663,26 +680,28 @@ static int launch_rowwin(const ConvArgs* args, hipStream_t st) {
     const int bn = 32 * TN;
     const long long tiles = ((args->M + CS_BM - 1) / CS_BM) * ((args->Cout + bn - 1) / bn);
     if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
-    const unsigned wp = (unsigned)(args->W + args->KW - 1);
+    const unsigned wp = (unsigned)(args->OW + args->KW - 1);
     const unsigned inv_wp = 65536u / wp + 1u;
     hipLaunchKernelGGL((conv_split_rowwin_kernel<TN, NP>), dim3((unsigned)tiles), dim3(256), LDS, st, *args, inv_wp);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
 
-// window pieces per wave a layer needs: rows 128 + J (KW - 1) with J = (W + 126) / W + 1 image rows at most
+// window pieces per wave a layer needs: rows 128 + J (KW - 1) with J = (OW + 126) / OW + 1 image rows at most, + 1: the
+// second K-slice of a tail step reads one row beyond its tap (times zero weights when KW is odd: it must be DMA'd data)
 static int rowwin_np(const ConvArgs* a) {
-    const int J = (a->W + 126) / a->W + 1;
-    const int rows = 128 + J * (a->KW - 1);
+    const int J = (a->OW + 126) / a->OW + 1;
+    const int rows = 128 + J * (a->KW - 1) + 1;
     return (rows + 31) / 32;
 }
 
 static int launch_rowwin_any(const ConvArgs* a, int tn, hipStream_t st) {
-    if (a->SH != 1 || a->SW != 1 || a->KW < 2 || a->KW > 8 || 2 * a->PW != a->KW - 1 || a->OW != a->W || a->Cin % 32 != 0 ||
-        a->Kpad != a->KH * a->KW * a->Cin || a->M >= 0x7fffff00LL || a->H >= 0x3f00 || a->PH >= 0x100)
+    const int steps_per_kh = (a->Cin / 32) * a->KW + ((a->Cin & 16) ? (a->KW + 1) / 2 : 0);
+    if (a->SH != 1 || a->SW != 1 || a->KW < 2 || a->KW > 8 || a->OW != a->W + 2 * a->PW - a->KW + 1 || a->OW < 1 || a->Cin % 16 != 0 ||
+        a->Cin < 32 || a->Kpad != a->KH * steps_per_kh * 32 || a->M >= 0x7fffff00LL || a->H >= 0x3f00 || a->PH >= 0x100)
         return TISE_ERR_INVALID_ARG;
     {   // the multiply-shift divisions of the kernel must be exact over their ranges
-        const unsigned wp = (unsigned)(a->W + a->KW - 1), w = (unsigned)a->W;
+        const unsigned wp = (unsigned)(a->OW + a->KW - 1), w = (unsigned)a->OW;
         const unsigned iwp = 65536u / wp + 1u, iw = 65536u / w + 1u;
         for (unsigned u = 0; u < 512 + w; ++u)
             if (((u * iwp) >> 16) != u / wp || ((u * iw) >> 16) != u / w) return TISE_ERR_UNSUPPORTED;
