@@ -263,6 +263,10 @@ int tise_gather_rows_f16(const void* x_dev, const int64_t* index_dev, int64_t n,
  *   128  DMA with the address arithmetic hoisted out of the K loop (the default of the Python layer; M < 2^31,
  *        H, W < 16128); weights fp16 [Cout_pad][Kpad / 32][hi x32 | lo x32], K order (tap, 32-channel block) for
  *        all taps, then -- Cin % 32 == 16 -- the 16-channel tails two taps per 32-wide step.
+ *   64   row-window kernel for stride-1 layers with KW in 2..8 (the kw taps of a filter row share one fetch of the
+ *        pixel operand); tn in {2, 3, 4}; weights fp16 [Cout_pad][Kpad / 32][hi x32 | lo x32] in the K order
+ *        (kh, 32-channel block, kw), and per kh -- Cin % 32 == 16 -- the 16-channel tails two taps per 32-wide step
+ *        last.  Same accuracy as 16 / 128, not the same bits (fp32 summation order).
  *   512  conv_pipe.hip configuration 33: resident-weights sliding-window kernel for Cin = 32 3x3 stride 1;
  *        weights as for 16.
  *   (Round 1's variants 0 / 32 / 64 / 256 and the other pipe configurations tied with 128 and were removed.)
