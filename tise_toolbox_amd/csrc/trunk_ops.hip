@@ -159,7 +159,12 @@ __global__ __launch_bounds__(256) void avgpool3_bias_relu_split_kernel(const flo
 }
 
 // split tensor -> 3x3 / stride 2 max pool -> split tensor slice (8 channels = 2 x 16 B per thread).  The value
-// hi + lo*2^-11 is exact in fp32, so the maximum is taken on it and its (hi, lo) pair is passed through.
+// v = hi + lo * 2^-11 is exact in fp32 (two 11-bit mantissas), so the maximum is taken on it -- one mixed-precision FMA
+// and one v_max per tap and channel -- and split again at the end: fp16(v) gives hi back (v lies within half an ulp of
+// it; on an exact tie the neighbouring fp16 value with the complementary lo, the same v).  The first version carried the
+// winning (hi, lo) pair through the taps with compare + select chains: ~500 vector instructions per thread against
+// ~190 now: 5.0-5.3 instead of 4.7-4.9 TB/s launched back to back (tools/pool_probe.py); inside the trunk the launches
+// take the same time as before (2.9 ms per 1000 images for the four of them), i.e. the memory system sets it there.
 __global__ __launch_bounds__(256) void maxpool3s2_split_kernel(const _Float16* __restrict__ x, int x_C, int x_off,
                                                                int N, int H, int W, int C8,
                                                                _Float16* __restrict__ out, int out_C, int out_off) {
@@ -173,7 +178,6 @@ __global__ __launch_bounds__(256) void maxpool3s2_split_kernel(const _Float16* _
         const int64_t n = p / ((int64_t)OW * OH);
         const int64_t base = (n * H + 2 * oh) * W + 2 * ow;
         const int xo = tise_ilv_off(x_off + 8 * c8, x_C), xs = tise_ilv_second(x_off + 8 * c8, x_C);
-        half8v bh, bl;
         float bv[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) bv[i] = -INFINITY;
@@ -185,11 +189,14 @@ __global__ __launch_bounds__(256) void maxpool3s2_split_kernel(const _Float16* _
                 const half8v vh = *reinterpret_cast<const half8v*>(q);
                 const half8v vl = *reinterpret_cast<const half8v*>(q + xs);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float v = (float)vh[i] + (float)vl[i] * (1.f / 2048.f);
-                    if (v > bv[i]) { bv[i] = v; bh[i] = vh[i]; bl[i] = vl[i]; }
-                }
+                for (int i = 0; i < 8; ++i) bv[i] = fmaxf(bv[i], (float)vh[i] + (float)vl[i] * (1.f / 2048.f));
             }
+        half8v bh, bl;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            bh[i] = (_Float16)bv[i];
+            bl[i] = (_Float16)((bv[i] - (float)bh[i]) * 2048.f);
+        }
         const int ch = out_off + 8 * c8;
         _Float16* d = out + p * (2 * (int64_t)out_C) + tise_ilv_off(ch, out_C);
         *reinterpret_cast<half8v*>(d) = bh;
