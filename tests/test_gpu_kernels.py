@@ -510,6 +510,23 @@ def test_conv_rowwin_kernel_matches_fp64_conv(dev, case):
             assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
 
 
+def test_conv_default_variant_on_very_short_rows(dev):
+    """The default variant picks the row-window kernel for stride-1 layers with KW > 1; on rows so short that its window
+    would not fit (OW = 4 here) the layer falls back to the default kernel instead of failing."""
+    from tise_toolbox_amd.conv_split import SplitConv, merge, rowwin_fits, split
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x = (torch.rand((40, 4, 4, 64), generator=g) * 2.0).to(dev)
+    w = (torch.randn((96, 64, 3, 3), generator=g) * (2.0 / 576) ** 0.5).to(dev)
+    b = (torch.randn(96, generator=g) * 0.2).to(dev)
+    conv = SplitConv(w, b, (1, 1), (1, 1), dev)
+    assert conv.variant == "rowwin" and not rowwin_fits(4, 3) and rowwin_fits(35, 3) and rowwin_fits(8, 3)
+    out = torch.zeros((40, 4, 4, 2 * 96), dtype=torch.float16, device=dev)
+    conv(split(x), [(0, 96, out, 0, 0)])
+    ref = torch.relu(torch.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), 1, 1)).permute(0, 2, 3, 1)
+    assert (merge(out).double() - ref).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    assert conv._fallback is not None and conv._fallback.variant == "fast"
+
+
 def test_conv_split_tile_width_does_not_change_results(dev):
     """Every tile width (tn = 1..5) accumulates every output element over K in the same order with the same MFMA
     sequence: the outputs must be bit-identical -- the tile width is a pure performance choice (conv_split.pick_tn).

@@ -116,6 +116,13 @@ def rowwin_applies(cin, cout, kh, kw, stride, padding, tn):
     return tuple(stride) == (1, 1) and 2 <= kw <= 8 and cin % 16 == 0 and cin >= 32 and tn in (2, 3, 4)
 
 
+def rowwin_fits(ow, kw):
+    """The row-window kernel's window holds 5 or 6 pieces of 8 rows per wave (csrc/conv_split.hip, rowwin_np)."""
+    j = (ow + 126) // ow + 1
+    rows = 128 + j * (kw - 1) + 1
+    return -(-rows // 32) in (5, 6)
+
+
 # conv_pipe.hip: configuration 33 = resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1), 32 couts per launch
 PIPE_BN = {33: 32}
 
@@ -135,6 +142,7 @@ class SplitConv:
         self.padding = tuple(padding)
         self.tn = tn or pick_tn(cout)
         self.pipe_cfg = None
+        self._fallback, self._orig = None, None
         # kernel variant: "fast" = LDS-DMA staging with hoisted addressing (default); "glds" = its generic form
         # (addresses recomputed per K-step, natural K order, any M: the reference kernel of the tests);
         # "pipe" = conv_pipe.hip configuration 33 (Conv2d_2a)
@@ -173,6 +181,7 @@ class SplitConv:
         # (conv_split_fast_kernel: 128-byte LDS-DMA rows); the planar (2, Cout_pad, Kpad) form serves "glds" / "pipe"
         self.w_fast = None
         if self.variant == "rowwin":
+            self._orig = (weight.detach().float().cpu(), bias.detach().float().cpu())       # see __call__
             # row-window kernel: K order (kh, 32-channel block, kw) -- the kw taps of a (kh, block) group share one window;
             # Cin = 32 n + 16: each kh ends with the 16-channel tails, two taps per 32-wide step
             assert cin % 16 == 0 and self.tn in (2, 3, 4)
@@ -212,6 +221,12 @@ class SplitConv:
         assert x.dtype == torch.float16 and x.dim() == 4 and x.shape[3] == 2 * self.cin and x.is_contiguous()
         n, h, w, _ = x.shape
         oh, ow = self.out_hw(h, w)
+        if self.variant == "rowwin" and not rowwin_fits(ow, self.kw):
+            # rows so short that the window of a 128-pixel tile needs more than the kernel's six pieces per wave (OW < 7
+            # at KW = 3): the default kernel serves the layer from its own packing, built on first use
+            if self._fallback is None:
+                self._fallback = SplitConv(self._orig[0], self._orig[1], self.stride, self.padding, x.device, tn=self.tn, variant="fast")
+            return self._fallback(x, segs)
         a = ConvArgs()
         a.x = x.data_ptr()
         wt = self.w_fast if self.w_fast is not None else self.w
