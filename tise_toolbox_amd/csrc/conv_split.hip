@@ -17,9 +17,11 @@
 //
 // GEMM view: M = N*OH*OW output pixels, N = Cout, K = KH*KW*Cin.  Workgroup = 256 threads = 4 waves stacked along
 // M; tile = 128 pixels x (32*TN) couts x 32 k per step; each wave owns 32 x 32*TN: TN accumulator pairs (main,
-// corr) of v_mfma_f32_32x32x16_f16.  Two kernels: the generic one recomputes every source address per K-step (the
-// reference of the tests, any M); the default one hoists the addressing out of the K loop.  (Round 1's
-// register-staged kernel, 3-stage and window variants tied or lost and were removed; profiles/r01*.)
+// corr) of v_mfma_f32_32x32x16_f16.  Three kernels: the generic one recomputes every source address per K-step (the
+// reference of the tests, any M); the default one hoists the addressing out of the K loop; the row-window one
+// fetches the pixel operand once for all taps of a filter row (stride-1 layers with KW > 1).  conv_pipe.hip holds a
+// fourth for Conv2d_2a.  (Round 1's register-staged, 3-stage, window and wave-specialised variants and round 2's
+// big-tile / interleaved-issue experiments tied or lost and were removed; DESIGN.md section 4a, profiles/.)
 #include <hip/hip_fp16.h>
 #include "common.h"
 #include "conv_epilogue.h"
