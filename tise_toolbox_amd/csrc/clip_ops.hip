@@ -3,15 +3,17 @@
 // fp16 tensors, fp32 accumulation / statistics, as the fp16 model `clip.load` serves on a GPU computes.
 //
 //   gemm_f16_kernel      out = act(A W^T + bias) + residual      nn.Linear / the patch-embedding conv / the projections
-//                        128 x 128 x 64 tiles, 4 waves (2 x 2, 64 x 64 per wave), v_mfma_f32_32x32x16_f16, operands
-//                        global -> LDS by global_load_lds_dwordx4 in 128-BYTE rows (a K-step of 64 halves is one
-//                        line), two stages, two workgroups per CU, XOR-swizzled LDS rows (conflict-free
+//   gemm_f16_big_kernel  128 x 128 x 64 tiles, 4 waves (64 x 64 per wave), two workgroups per CU; for launches of many
+//                        tiles 256 x 256 x 64, 8 waves (128 x 64 per wave), one workgroup per CU.  Both:
+//                        v_mfma_f32_32x32x16_f16, operands global -> LDS by global_load_lds_dwordx4 in 128-BYTE rows
+//                        (a K-step of 64 halves is one line), two stages, XOR-swizzled LDS rows (conflict-free
 //                        ds_read_b128), epilogue staged per wave so that rows leave as full lines.
 //   layernorm_f16_kernel one wave per row, fp32 mean / variance (CLIP's LayerNorm computes in fp32), eps inside sqrt.
 //   attention_f16_kernel one WAVE per (sequence, head): S <= 96 tokens, head dim 64: K Q^T and V^T P^T on the matrix
 //                        cores with operands loaded straight into the MFMA layout, fp32 softmax in registers.
 //   vit_tokens_f16_kernel / text_tokens_f16_kernel / patchify_f16_kernel / gather_rows_f16_kernel: token assembly.
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -177,6 +179,150 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(const GemmArgs p) {
         for (int pass = 0; pass < 4; ++pass) {
             const int r = pass * 8 + (lane >> 3), ch = lane & 7;
             const int m = m0 + wm * 64 + i * 32 + r, n = ncol0 + ch * 8;
+            half8_t v = *reinterpret_cast<const half8_t*>(st + r * PITCH + ch * 16);
+            if (m < p.M && n < p.N) {
+                if (p.res) {
+                    const half8_t rr = *reinterpret_cast<const half8_t*>(p.res + (long long)m * p.ldr + n);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (_Float16)((float)v[k] + (float)rr[k]);
+                }
+                *reinterpret_cast<half8_t*>(p.out + (long long)m * p.ldo + n) = v;
+            }
+        }
+    }
+}
+
+// 256 x 256 x 64 tiles for the large GEMMs (at least four tiles per CU): eight waves (2 x 4, 128 x 64 per wave), two
+// stages of 64 KB, one workgroup per CU.  A CU moves 64 KB of operands per 256 MFMAs here -- 32 B/clk against the
+// 64 B/clk of the 128 x 128 kernel and the ~38 B/clk the LDS-DMA path delivers -- and a wave reads 6 fragments per 8
+// MFMAs instead of 4 per 4.  The price is one workgroup per CU: the DMA latency in front of a tile's first K-step and
+// its epilogue are exposed, so the launcher uses it only where a tile has enough K-steps and the launch enough tiles.
+__global__ __launch_bounds__(512, 1) void gemm_f16_big_kernel(const GemmArgs p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128;         // 64 KB
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                   // 2 x 4 waves of 128 x 64
+    const unsigned tiles_n = (unsigned)(p.N + BN - 1) / BN;
+    const unsigned nwg = gridDim.x;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (int)(bid / tiles_n) * BM;
+    const int n0 = (int)(bid % tiles_n) * BN;
+    const unsigned char* zp = g_clip_zero_page;
+    const unsigned char* pa[4];
+    const unsigned char* pw[4];
+    int ia[4], iw[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int r = (4 * wave + g) * 8 + (lane >> 3);        // 8 waves x 4 pieces x 8 rows = 256 rows of each operand
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const bool oka = m0 + r < p.M, okw = n0 + r < p.N;
+        pa[g] = oka ? reinterpret_cast<const unsigned char*>(p.a + (long long)(m0 + r) * p.lda + c * 8) : zp;
+        ia[g] = oka ? 128 : 0;
+        pw[g] = okw ? reinterpret_cast<const unsigned char*>(p.w + (long long)(n0 + r) * p.ldw + c * 8) : zp;
+        iw[g] = okw ? 128 : 0;
+    }
+#define GB_ISSUE(SOFF)                                                                                    \
+    {                                                                                                     \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
+            const unsigned char* s_ = pa[g];                                                               \
+            __builtin_amdgcn_global_load_lds(s_, (lds_ptr_t)(lds + (SOFF) + (4 * wave + g) * 1024), 16, 0, 0);            \
+            pa[g] = s_ + ia[g];                                                                            \
+        }                                                                                                  \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
+            const unsigned char* s_ = pw[g];                                                               \
+            __builtin_amdgcn_global_load_lds(s_, (lds_ptr_t)(lds + (SOFF) + A_BYTES + (4 * wave + g) * 1024), 16, 0, 0);  \
+            pw[g] = s_ + iw[g];                                                                            \
+        }                                                                                                  \
+    }
+    float16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int frow = lane & 31, fsw = (frow >> 1) & 7;
+    int fo[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fo[s] = frow * 128 + (((2 * s + (lane >> 5)) ^ fsw) * 16);
+    const unsigned char* fa = lds + (wm * 128) * 128;
+    const unsigned char* fb = lds + A_BYTES + (wn * 64) * 128;
+// reads of slice s+1 are written before the MFMAs of slice s (six reads per eight MFMAs)
+#define GB_READS(S, SOFF, BUF)                                                                            \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                      \
+            a_[BUF][i] = *reinterpret_cast<const half8_t*>(fa + (SOFF) + i * 32 * 128 + fo[S]);            \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+            b_[BUF][j] = *reinterpret_cast<const half8_t*>(fb + (SOFF) + j * 32 * 128 + fo[S]);            \
+    }
+#define GB_MFMAS(BUF)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_[BUF][j], a_[BUF][i], acc[i][j], 0, 0, 0);
+#define GB_COMPUTE(SOFF)                                                                                  \
+    {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        GB_READS(1, SOFF, 1) GB_MFMAS(0) __builtin_amdgcn_sched_barrier(0);                                \
+        GB_READS(2, SOFF, 0) GB_MFMAS(1) __builtin_amdgcn_sched_barrier(0);                                \
+        GB_READS(3, SOFF, 1) GB_MFMAS(0) __builtin_amdgcn_sched_barrier(0);                                \
+        GB_MFMAS(1) __builtin_amdgcn_sched_barrier(0);                                                     \
+    }
+    half8_t a_[2][4], b_[2][2];
+    const int nsteps = p.K / GM_BK;
+    GB_ISSUE(0)
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        GB_READS(0, 0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        GB_ISSUE(STAGE)
+        GB_COMPUTE(0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        GB_READS(0, STAGE, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (step + 2 < nsteps) GB_ISSUE(0)
+        GB_COMPUTE(STAGE)
+    }
+    if (step < nsteps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        GB_READS(0, 0, 0)
+        GB_COMPUTE(0)
+    }
+    __syncthreads();
+    constexpr int PITCH = 144;
+    unsigned char* st = lds + wave * (32 * PITCH);
+    const int ncol0 = n0 + wn * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = j * 32 + 8 * g + 4 * (lane >> 5);
+                const int n = ncol0 + cl;
+                half4_t h, bq = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                if (p.bias && n < p.N) bq = *reinterpret_cast<const half4_t*>(p.bias + n);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = acc[i][j][4 * g + k] + (float)bq[k];
+                    if (p.act == 1) v = v / (1.0f + __expf(-1.702f * v));
+                    h[k] = (_Float16)v;
+                }
+                *reinterpret_cast<half4_t*>(st + (lane & 31) * PITCH + cl * 2) = h;
+            }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + (lane >> 3), ch = lane & 7;
+            const int m = m0 + wm * 128 + i * 32 + r, n = ncol0 + ch * 8;
             half8_t v = *reinterpret_cast<const half8_t*>(st + r * PITCH + ch * 16);
             if (m < p.M && n < p.N) {
                 if (p.res) {
@@ -448,6 +594,19 @@ int tise_gemm_f16(const void* a_dev, int64_t lda, const void* w_dev, int64_t ldw
     p.M = m; p.N = n; p.K = k; p.act = act;
     const long long tiles = (long long)((m + 127) / 128) * ((n + 127) / 128);
     if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
+    // TISE_GEMM_BIG: 0 never, 1 (default) by the rule below, 2 always -- the A/B switch of tools/clip_gemm_probe.py
+    static const int big_mode = [] { const char* e = getenv("TISE_GEMM_BIG"); return e ? atoi(e) : 1; }();
+    const long long tiles_big = (long long)((m + 255) / 256) * ((n + 255) / 256);
+    if (big_mode == 2 || (big_mode == 1 && tiles_big >= 768)) {
+        constexpr int lds_big = 2 * (256 * 128 + 256 * 128);
+        static std::atomic<unsigned long long> attr_set{0};
+        if (tise_first_use_on_this_device(attr_set))
+            TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_big_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
+        hipLaunchKernelGGL(gemm_f16_big_kernel, dim3((unsigned)tiles_big), dim3(512), lds_big, (hipStream_t)stream, p);
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
     hipLaunchKernelGGL(gemm_f16_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, p);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
