@@ -510,6 +510,20 @@ def test_conv_rowwin_kernel_matches_fp64_conv(dev, case):
             assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
 
 
+@pytest.mark.parametrize("variant", ["rowwin", "fast", "glds"])
+def test_conv_kernels_random_shapes_vs_fp64(dev, variant):
+    """60 seeded random layer shapes per kernel (filters 1..7 x 1..8, asymmetric padding, strides, rows of 1..40 pixels,
+    Cin incl. the 16-channel tails, every tile width) against an fp64 convolution: the corner cases nobody thought of
+    (tools/conv_rowwin_fuzz.py runs more of them: 600 row-window configurations without a mismatch in round 2)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("conv_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                "tools", "conv_rowwin_fuzz.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    done, bad = fuzz.run(seed=11, count=60, variant=variant, dev=dev, verbose=False)
+    assert done == 60 and not bad, bad[:3]
+
+
 def test_conv_default_variant_on_very_short_rows(dev):
     """The default variant picks the row-window kernel for stride-1 layers with KW > 1; on rows so short that its window
     would not fit (OW = 4 here) the layer falls back to the default kernel instead of failing."""
