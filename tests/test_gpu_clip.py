@@ -11,7 +11,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("m,n,k,bias,res,act", [(12800, 768, 768, True, True, 0), (300, 2304, 768, True, False, 0),
                                                 (1000, 3072, 768, True, False, 1), (257, 512, 3072, False, False, 0),
                                                 (5, 64, 64, True, True, 1), (2560, 136, 128, True, True, 0),
-                                                (77 * 33, 2048, 512, True, False, 1)])
+                                                (77 * 33, 2048, 512, True, False, 1),
+                                                # >= 768 tiles of 256 x 256: the large-tile kernel, with M and N tails
+                                                (8192 - 37, 6144 - 8, 128, True, True, 1), (157696, 1536, 512, True, False, 0)])
 def test_gemm_f16_matches_fp32_matmul(cuda_device, m, n, k, bias, res, act):
     from tise_toolbox_amd import clip_hip
     g = torch.Generator(device="cpu").manual_seed(m + n + k)
