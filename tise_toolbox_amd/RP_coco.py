@@ -45,8 +45,8 @@ def parse_args(argv=None):
 
 def build_towers(weights_path, dev):
     """-> (towers, logit_scale).  ``towers.encode_image`` / ``.encode_text`` in fp16, as the model clip.load serves on a GPU.
-    Default: the hand-written kernels of csrc/clip_ops.hip (clip_hip.HipTowers: 1.15x / 1.8x the library-kernel module
-    on the image / text tower, profiles/r02r_clip_towers.txt); TISE_CLIP=torch runs the module itself on PyTorch-ROCm
+    Default: the hand-written kernels of csrc/clip_ops.hip (clip_hip.HipTowers: 1.4x / 2.4x the library-kernel module
+    on the image / text tower, profiles/r02x_clip_towers.txt); TISE_CLIP=torch runs the module itself on PyTorch-ROCm
     library kernels (what north_star prescribes for the forward passes; same parameters, same results to fp16 rounding)."""
     model = clip_model.build_clip(weights_path)
     scale = float(model.logit_scale.detach().exp())            # clip's convert_weights leaves logit_scale in fp32
@@ -124,6 +124,9 @@ def r_precision(img_emb, txt_emb, txt_index, perm, normalize=True, logit_scale=1
 
 @torch.no_grad()
 def embed_texts(model, tokenizer, captions, dev, batch):
+    """Normalised text embeddings, in order.  Tokenising (host, one core: ~60 k captions/s) and encoding (device: ~90 k/s,
+    asynchronous) overlap batch by batch; tokenising in DataLoader worker processes was tried and lost -- forking eight
+    workers from a process that holds a GPU context took 7 s for a 0.7 s job."""
     out = []
     for i in range(0, len(captions), batch):
         tok = tokenizer(captions[i:i + batch]).to(dev)
