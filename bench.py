@@ -291,11 +291,13 @@ def main():
     ev_tail = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     from tise_toolbox_amd.conv_split import SplitConv as _SC
     # HIP events around every convolution launch cost ~1.5 % of a step (130 extra records per 65 launches), so they
-    # bracket the conv launches of every 6th device batch only (all when there are < 12); the rocprofv3 summary of
-    # the same command is the cross-check.  TISE_BENCH_MODE=noevents switches them off.
+    # bracket the conv launches of at most three device batches -- first, middle, last: 195 launches, plenty for the
+    # average -- whatever the number of steps (measured: 0.8 % of the job with five of ten batches bracketed); the
+    # rocprofv3 summary of the same command is the cross-check.
+    # TISE_BENCH_MODE=noevents switches them off.
     mode = os.environ.get("TISE_BENCH_MODE", "events")
     conv_timer = [] if mode == "events" else None
-    every = 6 if nch >= 12 else 1
+    evented = {0, (nch - 1) // 2, nch - 1}
     _SC.timer = None
     u8_stem = getattr(eng, "_u8_stem", False)
     eng.begin(n_total=n_total, temperature=T_COCO, splits=10, rule="coco")
@@ -305,7 +307,7 @@ def main():
     t0 = time.perf_counter()
     for s, (a, b) in enumerate(chunks):
         batch = data[a:b]
-        _SC.timer = conv_timer if (conv_timer is not None and s % every == 0) else None
+        _SC.timer = conv_timer if (conv_timer is not None and s in evented) else None
         ev[s][0].record()
         if u8_stem:
             x = device.resize_u8_only(batch, (299, 299))       # uint8 out; the stem conv applies the input table
@@ -354,7 +356,7 @@ def main():
 
     from tise_toolbox_amd.trunk import SplitTrunk
     conv_events = conv_timer or []
-    timed_steps = len(range(0, nch, every)) if conv_timer is not None else 0
+    timed_steps = len(evented) if conv_timer is not None else 0
     if isinstance(eng.fused, SplitTrunk):
         # fp32-class arithmetic: every operand carried as two fp16 numbers (22 mantissa bits), three fp16 MFMAs
         # per product, fp32 accumulation; measured error vs an fp64 convolution is below MIOpen's fp32 kernels
