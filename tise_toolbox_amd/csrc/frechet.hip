@@ -333,6 +333,133 @@ __global__ __launch_bounds__(256) void pchol_trail_kernel(const double* __restri
     gemm_tile_store<2>(work, d, d, d, m0, n0, acc);
 }
 
+// ------------------------------------------------------------------ unpivoted blocked Cholesky (fast path, d <= 2048)
+// Pivoting is there to reveal the rank when N < d; a covariance of full numerical rank does not need it, and any
+// factor with L L^T = S gives the same eigenvalues of L^T S2 L.  So the factor is first attempted in natural order,
+// right-looking, 64 columns at a time -- one launch factors the diagonal block (every workgroup for itself, in
+// LDS) and solves its 64 rows of the panel against it, one launch applies the panel to the trailing lower triangle
+// on the fp64 MFMA tile: 2 x 32 launches at d = 2048 instead of 128 sixteen-pivot panels with a block-wide argmax
+// per pivot (12.6 ms).  A pivot that is not safely positive (<= 1e-12 of the largest diagonal entry, or non-finite)
+// raises st->nonpd and the caller starts over with the pivoted, rank-revealing factorisation.
+#define CHB 64
+
+__global__ __launch_bounds__(256) void chol_panel_kernel(const double* __restrict__ work, int d, int k0, double tol,
+                                                         double* __restrict__ LT, int* __restrict__ fail) {
+    __shared__ double D[CHB][CHB + 1];                            // the diagonal block, then its factor L11 (lower)
+    __shared__ double X[CHB][CHB + 1];                            // this workgroup's 64 rows of the panel
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    const int nb = min(CHB, d - k0);
+    if (tid == 0) s_bad = 0;
+    for (int e = tid; e < CHB * CHB; e += 256) {
+        const int r = e / CHB, c = e - r * CHB;
+        D[r][c] = (r < nb && c < nb && c <= r) ? work[(int64_t)(k0 + r) * d + (k0 + c)] : (r == c ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    // ---- potrf of the 64 x 64 block in LDS (right-looking; thread (r, q): row r = tid / 4, columns q, q+4, ...) ----
+    const int pr = tid >> 2, pq = tid & 3;
+    for (int j = 0; j < nb; ++j) {
+        const double piv = D[j][j];
+        if (!(piv > tol) || !isfinite(piv)) {                     // uniform: every thread reads the same value
+            if (tid == 0) s_bad = 1;
+            break;
+        }
+        const double inv = 1.0 / sqrt(piv);
+        __syncthreads();
+        if (tid < CHB && tid >= j && tid < nb) D[tid][j] = (tid == j) ? sqrt(piv) : D[tid][j] * inv;
+        __syncthreads();
+        if (pr > j && pr < nb) {
+            const double lrj = D[pr][j];
+            for (int c = j + 1 + pq; c <= pr; c += 4) D[pr][c] -= lrj * D[c][j];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) atomicOr(fail, 1);
+        return;
+    }
+    const int row0 = k0 + CHB * (int)blockIdx.x;                  // first matrix row of this workgroup
+    if (blockIdx.x == 0) {
+        // the diagonal block itself: LT[k0 + c][k0 + r] = L11[r][c] (zero above the diagonal)
+        for (int e = tid; e < CHB * CHB; e += 256) {
+            const int c = e / CHB, r = e - c * CHB;               // r fastest: contiguous in LT's row k0 + c
+            if (r < nb && c < nb) LT[(int64_t)(k0 + c) * d + (k0 + r)] = (c <= r) ? D[r][c] : 0.0;
+        }
+        return;
+    }
+    // ---- rows row0 .. row0+63 of the panel: X = work[rows][k0 .. k0+63], solve X L11^T = A21 row by row -------------
+    const int nrows = min(CHB, d - row0);
+    for (int e = tid; e < CHB * CHB; e += 256) {
+        const int r = e / CHB, c = e - r * CHB;
+        X[r][c] = (r < nrows && c < nb) ? work[(int64_t)(row0 + r) * d + (k0 + c)] : 0.0;
+    }
+    __syncthreads();
+    // thread (r, q): row r, partial dots over columns q, q+4, ... (the four lanes of a row are neighbours in a wave)
+    for (int j = 0; j < nb; ++j) {
+        double acc = 0.0;
+        for (int c = pq; c < j; c += 4) acc += X[pr][c] * D[j][c];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (pq == 0) X[pr][j] = (X[pr][j] - acc) / D[j][j];
+        __syncthreads();                                          // column j of every row is final before column j+1 reads it
+    }
+    for (int e = tid; e < CHB * CHB; e += 256) {
+        const int c = e / CHB, r = e - c * CHB;                   // r fastest: contiguous in LT's row k0 + c
+        if (r < nrows && c < nb) LT[(int64_t)(k0 + c) * d + (row0 + r)] = X[r][c];
+    }
+}
+
+// work -= L_panel L_panel^T on the trailing LOWER triangle (64 x 64 tiles with row tile >= column tile)
+__global__ __launch_bounds__(256) void chol_trail_kernel(const double* __restrict__ LT, int d, int k0, const int* __restrict__ fail,
+                                                         double* __restrict__ work) {
+    if (blockIdx.x > blockIdx.y || *fail) return;
+    __shared__ double lds[GT_LDS_DOUBLES];
+    const int nb = min(CHB, d - k0);
+    double4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const double* Lb = LT + (int64_t)k0 * d;
+    const int t0 = k0 + CHB;
+    const int m0 = t0 + blockIdx.y * GT_BM, n0 = t0 + blockIdx.x * GT_BN;
+    gemm_tile_64x64<double, double>(Lb, 1, d, Lb, d, 1, d, d, nb, m0, n0, acc, lds);
+    gemm_tile_store<2>(work, d, d, d, m0, n0, acc);
+}
+
+// rows of LT above the diagonal block of their panel are zero (L is lower triangular): LT[k][i] = 0 for i < 64 * (k / 64)
+__global__ void chol_zero_upper_kernel(double* __restrict__ LT, int d) {
+    const int64_t total = (int64_t)d * d;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(e / d), i = (int)(e - (int64_t)k * d);
+        if (i < (k / CHB) * CHB) LT[e] = 0.0;
+    }
+}
+
+__global__ void chol_finish_kernel(const int* __restrict__ fail, int d, FrState* __restrict__ st) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->done = 1; st->rank = *fail ? 0 : d; st->nonfinite = 0; }
+}
+
+__global__ __launch_bounds__(1024) void chol_maxdiag_kernel(const double* __restrict__ work, int d, double* __restrict__ out, int* __restrict__ fail) {
+    __shared__ double s_val[16];
+    double m = 0.0;
+    bool bad = false;
+    for (int i = threadIdx.x; i < d; i += blockDim.x) {
+        const double v = work[(int64_t)i * d + i];
+        if (!isfinite(v)) bad = true;
+        m = fmax(m, v);
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) s_val[threadIdx.x >> 6] = m;
+    const int anybad = __syncthreads_or(bad ? 1 : 0);
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < (int)(blockDim.x >> 6); ++i) m = fmax(m, s_val[i]);
+        out[0] = m;
+        *fail = anybad ? 1 : 0;
+    }
+}
+
 // zero rows [r, d) of LT so later consumers may ignore the rank
 __global__ void zero_rows_kernel(double* __restrict__ LT, int d, int r0) {
     const int64_t total = (int64_t)(d - r0) * d;
@@ -875,6 +1002,42 @@ __global__ __launch_bounds__(1024) void frechet_finish_kernel(const double* __re
 }
 
 // ------------------------------------------------------------------ host drivers
+int run_pchol(tise_frechet* h, const double* S, double off, int* rank_out, hipStream_t st);
+
+// factor of S (+ off I) into h->lt: the unpivoted fast path when it succeeds (full numerical rank), else the pivoted one
+int run_chol(tise_frechet* h, const double* S, double off, int* rank_out, hipStream_t st) {
+    const int d = h->d;
+    static const bool pivoted_only = getenv("TISE_CHOL_PIVOTED") != nullptr;      // A/B switch (tests, tools/frechet_probe.py)
+    if (d <= 2048 && d >= CHB && !pivoted_only) {
+        int* fail = h->chosen;                                     // one int of the pivoted path's scratch, rewritten by it anyway
+        double* maxdiag = h->diag;
+        hipLaunchKernelGGL(pchol_copy_kernel, dim3(2048), dim3(256), 0, st, S, d, off, h->t1);
+        hipLaunchKernelGGL(chol_maxdiag_kernel, dim3(1), dim3(1024), 0, st, h->t1, d, maxdiag, fail);
+        TISE_LAUNCH_CHECK();
+        double md = 0.0;
+        int f0 = 0;
+        TISE_HIP_CHECK(hipMemcpyAsync(&md, maxdiag, sizeof(double), hipMemcpyDeviceToHost, st));
+        TISE_HIP_CHECK(hipMemcpyAsync(&f0, fail, sizeof(int), hipMemcpyDeviceToHost, st));
+        TISE_HIP_CHECK(hipStreamSynchronize(st));
+        if (!f0 && md > 0.0) {
+            const double tol = 1e-12 * md;
+            hipLaunchKernelGGL(chol_zero_upper_kernel, dim3(2048), dim3(256), 0, st, h->lt, d);
+            for (int k0 = 0; k0 < d; k0 += CHB) {
+                const int npanel = ceil_div(d - k0, CHB);
+                hipLaunchKernelGGL(chol_panel_kernel, dim3(npanel), dim3(256), 0, st, h->t1, d, k0, tol, h->lt, fail);
+                if (npanel > 1)
+                    hipLaunchKernelGGL(chol_trail_kernel, dim3(npanel - 1, npanel - 1), dim3(256), 0, st, h->lt, d, k0, fail, h->t1);
+            }
+            hipLaunchKernelGGL(chol_finish_kernel, dim3(1), dim3(64), 0, st, fail, d, h->st);
+            TISE_LAUNCH_CHECK();
+            TISE_HIP_CHECK(hipMemcpyAsync(&f0, fail, sizeof(int), hipMemcpyDeviceToHost, st));
+            TISE_HIP_CHECK(hipStreamSynchronize(st));
+            if (!f0) { *rank_out = d; return TISE_OK; }
+        }
+    }
+    return run_pchol(h, S, off, rank_out, st);
+}
+
 int run_pchol(tise_frechet* h, const double* S, double off, int* rank_out, hipStream_t st) {
     const int d = h->d;
     if (d <= 2048) {                                   // blocked path: working copy lives in h->t1
@@ -1101,7 +1264,7 @@ static int frechet_core(tise_frechet_t* h, const double* mu1_dev, const double* 
     if (h->profiling) TISE_HIP_CHECK(hipEventRecord(h->ev[0], st));
     if (factor_here) {
         h->prefactored = 0;
-        int rc = run_pchol(h, sigma1_dev, diag_offset, &r, st);
+        int rc = run_chol(h, sigma1_dev, diag_offset, &r, st);
         if (rc != TISE_OK) return rc;
     } else {
         r = h->pf_rank;
@@ -1153,7 +1316,7 @@ int tise_frechet_prefactor(tise_frechet_t* h, const double* sigma_dev, void* str
     h->prefactored = 0;
     TISE_HIP_CHECK(hipEventRecord(h->evp[0], st));
     int r = 0;
-    int rc = run_pchol(h, sigma_dev, 0.0, &r, st);          // synchronises `st` (rank read-back), not the device
+    int rc = run_chol(h, sigma_dev, 0.0, &r, st);           // synchronises `st` (rank read-back), not the device
     if (rc != TISE_OK) return rc;
     TISE_HIP_CHECK(hipEventRecord(h->evp[1], st));
     h->pf_rank = r;
