@@ -85,9 +85,10 @@ int tise_stats_finalize(tise_stats_t* h, double* mu_dev, double* sigma_dev, void
  * (a6) Frechet distance.
  * Replaces calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps)
  *                                           image_realism/FID/fid_score.py:121-171
- * Tr sqrtm(S1 S2) is evaluated as sum_i sqrt(lambda_i(L^T S2 L)), S1 = L L^T a diagonally
- * pivoted Cholesky factor (rank-revealing, runs to the last positive pivot), L^T S2 L reduced
- * to tridiagonal form by Householder reflections, eigenvalues by Sturm bisection; all fp64.
+ * Tr sqrtm(S1 S2) is evaluated as sum_i sqrt(lambda_i(L^T S2 L)), S1 = L L^T: an unpivoted blocked
+ * Cholesky factor when every pivot is safely positive, otherwise the diagonally pivoted one
+ * (rank-revealing, runs to the last positive pivot); L^T S2 L reduced to tridiagonal form by
+ * Householder reflections, eigenvalues by Sturm bisection; all fp64.
  *
  *   out_dev[0] = fid            out_dev[1] = tr sqrt(S1 S2)     out_dev[2] = |mu1-mu2|^2
  *   out_dev[3] = tr S1          out_dev[4] = tr S2              out_dev[5] = rank(L) as double
@@ -119,7 +120,7 @@ int tise_frechet_distance_prefactored(tise_frechet_t* h, const double* mu_f_dev,
                                       const double* mu_o_dev, const double* sigma_o_dev, double* out_dev, void* stream);
 int tise_frechet_prefactor_ms(tise_frechet_t* h, double* ms_host);   /* HIP-event duration of the last prefactor */
 /* Optional phase timing of tise_frechet_distance with HIP events on the caller's stream.
- * ms_host[5] = pivoted Cholesky | GEMMs | tridiagonalisation | bisection | final reduction.
+ * ms_host[5] = Cholesky | GEMMs | tridiagonalisation | bisection | final reduction.
  * tise_frechet_phase_ms waits for the last recorded call to finish. */
 int tise_frechet_set_profiling(tise_frechet_t* h, int on);
 int tise_frechet_phase_ms(tise_frechet_t* h, double* ms_host, int* rank_host);
