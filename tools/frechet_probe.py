@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Phase times of the device Frechet distance at d = 2048 (HIP events inside the library), full-rank (N = 3000) and
-rank-deficient (N = 1000) inputs.  TISE_SYTRD_TWO_LAUNCH=1 selects round 1's two-launch-per-column tridiagonalisation."""
+rank-deficient (N = 1000) inputs.  TISE_SYTRD_TWO_LAUNCH=1 selects round 1's two-launch-per-column tridiagonalisation,
+TISE_CHOL_PIVOTED=1 the pivoted Cholesky without trying the unpivoted fast path first."""
 import os
 import sys
 import time
