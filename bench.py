@@ -2,22 +2,25 @@
 """Headline benchmark: images/sec through InceptionV3 + FID (+ IS*) on 30k 256x256 images, MI355X.
 
     python bench.py --gpus 1 --steps 60 --warmup 3
+    python bench.py --gpus 8                      (no torchrun environment: starts the 8 ranks itself, see _self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-The JOB is BASELINE.json's metric: IS* + FID of ONE set of K*500 synthetic uint8 256x256x3 images (30 000 at the
-default K = 60) that are already resident in HBM, against pre-computed reference statistics.  A STEP is 1/K of the
-job = the hot path over 500 images (the device runs them in batches of 1000, see DEVICE_BATCH):
+The JOB is BASELINE.json's metric and does not depend on the flags: IS* + FID of ONE set of 30 000 synthetic uint8
+256x256x3 images -- decoded pixels already resident in HBM (PNG decode and the host->device copy are NOT in the timed
+region; DESIGN.md section 6 gives the host-inclusive rates of the CLI) -- against pre-computed reference statistics.
+A STEP is 1/K of the job = the hot path over 30 000 / K images (500 at the default K = 60, 1 500 at --steps 20; the
+device runs them in batches of 1000, see DEVICE_BATCH; `--batch B` makes the job K*B images instead):
     resize 256->299 (PIL-exact, csrc/resize.hip) -> InceptionV3 trunk (hand-written split-fp16 MFMA convolutions,
     csrc/conv_split.hip / conv_pipe.hip / trunk_ops.hip) + fc -> fp64 covariance/mean accumulation (csrc/stats.hip)
     -> IS* split sums (csrc/is_score.hip).
 With N GPUs the SAME job is sharded (STRONG scaling, SURVEY.md section 8(d) "Config 3"): rank r takes the
-contiguous index range dist.shard_range(K*500, r, N) (3 750 images at N = 8) and runs it in device batches that
-divide its range (1000 / 1000 / 750 / 750 images at N = 1 / 2 / 4 / 8; a step stays 1/K of the job = 500 images).  After the loop the timed region contains, once: the
+contiguous index range dist.shard_range(30 000, r, N) (3 750 images at N = 8) and runs it in device batches that
+divide its range (1000 / 1000 / 750 / 750 images at N = 1 / 2 / 4 / 8; a step stays 1/K of the job).  After the loop the timed region contains, once: the
 all-reduce of the sufficient statistics over RCCL, the finalisation of (mu, sigma), the Frechet distance
-(csrc/frechet.hip, solved redundantly on every rank) and the IS* finalisation.  value = K*500 / max-over-ranks
+(csrc/frechet.hip, solved redundantly on every rank) and the IS* finalisation.  value = 30 000 / max-over-ranks
 seconds; `allreduce_ms` and `finalize_ms` are reported separately.  `--scaling weak` gives every rank its own
-K*500 images instead (round-1 behaviour).
+30 000 images instead.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline      the dominant hand-written kernel of the step loop, timed with HIP events inside the timed region,
@@ -51,7 +54,7 @@ if ROOT not in sys.path:
 PEAK_HBM_GBS = 8000.0
 PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: "Peak BF16/FP16 MFMA ~2.5 PF dense"
-GLOBAL_STEP_IMAGES = 500
+JOB_IMAGES = 30000         # BASELINE.json metric / configs[1]: 30k images (README.md:214-219 of the reference)
 DEVICE_BATCH = 1000        # images per device batch when it divides a rank's share (tools/batch_sweep.sh: 500 / 750 / 1000 / 1500
                            # -> 20.04 / 20.07 / 20.27 / 20.22 k images/s on one box: fewer launch gaps and tile tails per image)
 
@@ -225,7 +228,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=GLOBAL_STEP_IMAGES, help="images per step (job = steps x batch images)")
+    ap.add_argument("--images", type=int, default=JOB_IMAGES, help="images of the job (the metric's 30 000)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="explicit images per step: the job becomes steps x batch images (0: the job is --images, a step = images / steps)")
     ap.add_argument("--device-batch", type=int, default=0, help="images per device batch (0: chosen by rank_batch)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--ref-images", type=int, default=3000)
@@ -234,25 +239,30 @@ def main():
     ap.add_argument("--no-cross-check", action="store_true")
     ap.add_argument("--channels-last", type=int, default=-1)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus))                  # before anything touches the GPU in this process
 
     from tise_toolbox_amd import _lib, device, dist as tdist, fid_score
     from tise_toolbox_amd.engine import RealismEngine, T_COCO, frechet_solver
     rank, world, local_rank = tdist.init_from_env()
-    if world != args.gpus and rank == 0:
-        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    backend = torch.distributed.get_backend() if world > 1 else None
     if os.environ.get("TISE_FORCE_DEVICE0"):       # testing aid: several ranks on one GPU (gloo backend only)
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     cl = None if args.channels_last < 0 else bool(args.channels_last)
     eng = RealismEngine(dims=2048, device_index=local_rank, seed=0, with_logits=True, channels_last=cl)
-    B, K, W = args.batch, args.steps, args.warmup
+    K, W = args.steps, args.warmup
+    n_job = K * args.batch if args.batch > 0 else args.images
+    B = n_job / K                                             # images per step (a step = 1/K of the job)
     if args.scaling == "strong":
-        n_total = K * B
+        n_total = n_job
         lo, hi = tdist.shard_range(n_total, rank, world)
     else:
-        n_total = K * B * world
-        lo, hi = rank * K * B, (rank + 1) * K * B
+        n_total = n_job * world
+        lo, hi = rank * n_job, (rank + 1) * n_job
     n_rank = hi - lo
     rb = args.device_batch if args.device_batch > 0 else rank_batch(n_rank)
     chunks = [(a, min(a + rb, n_rank)) for a in range(0, n_rank, rb)]
@@ -264,8 +274,8 @@ def main():
         data[i:j] = synth_images_device(lo + i, lo + j, dev, seed=0)
     # reference statistics (the README recipe passes them as an .npz, fid_score.py:200-203): untimed
     eng.begin(n_total=args.ref_images)
-    for i in range(0, args.ref_images, B):
-        j = min(i + B, args.ref_images)
+    for i in range(0, args.ref_images, 500):
+        j = min(i + 500, args.ref_images)
         eng.step_u8(synth_images_device(i, j, dev, seed=1, shift=0.12), i)
     mu_ref, sigma_ref = eng.statistics()
     solver = frechet_solver(2048, dev)
@@ -424,10 +434,13 @@ def main():
             "dtype": conv_dtype, "data": "synthetic",
             "config": {"workload": f"IS*+FID of ONE set of {n_total} synthetic 256x256 images (BASELINE configs[1]/[2]: 30k "
                                    f"images, InceptionV3 pool3 2048-d) sharded over {world} GPU(s): {n_rank} images per GPU in "
-                                   f"device batches of {rb}; seeded stand-in InceptionV3 weights, reference stats from "
-                                   f"{args.ref_images} images",
+                                   f"device batches of {rb}; inputs are pre-decoded uint8 pixels resident in HBM (PNG decode and "
+                                   f"host->device copy excluded from the timed region); seeded stand-in InceptionV3 weights, "
+                                   f"reference stats from {args.ref_images} images",
                        "step_images": B, "images_per_gpu": n_rank, "images_total": n_total, "device_batch": rb,
-                       "device_batches_per_gpu": nch, "dims": 2048, "trunk": trunk_desc, "parallelism": f"dp{world}"},
+                       "device_batches_per_gpu": nch, "dims": 2048, "trunk": trunk_desc, "parallelism": f"dp{world}",
+                       "collective": {"world_size": world, "backend": backend,
+                                      "launcher": os.environ.get("TISE_BENCH_LAUNCHER", "external" if world > 1 else "none")}},
             "roofline": roofline,
             "stage_ms_per_device_batch": {"resize": resize_ms, "trunk": trunk_ms, "cov_syrk": syrk_ms},
             "allreduce_ms": allreduce_ms,
@@ -435,7 +448,7 @@ def main():
                             "host_wall_allreduce": (t_reduce_host - t_loop_host) * 1e3,
                             "stats_finalize": ev_tail[1].elapsed_time(ev_tail[2]),
                             "frechet_plus_is": ev_tail[2].elapsed_time(ev_tail[3]), **{k: v for k, v in phases.items()},
-                            "pchol_overlapped_on_side_stream": (solver.prefactor_ms() if prefactor_after >= 0 else None)},
+                            "pchol_side_stream_ms": (solver.prefactor_ms() if prefactor_after >= 0 else None)},
             "scores": {"fid": float(res["fid"]), "is_mean": is_mean, "is_std": is_std, "rank": res["rank"],
                        "flags": res["flags"]},
             "trunk_tflops": 11.42e9 * rb / (trunk_ms * 1e-3) / 1e12,
@@ -483,6 +496,25 @@ def main():
     tdist.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def _self_launch(n):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as FRESH child processes
+    (python -m torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1) and relay their output; rank 0's JSON
+    line goes to this process's stdout.  Called before this process has made any GPU call -- it never initialises HIP
+    and never replaces itself (no exec): it waits for the child and returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    env["TISE_BENCH_LAUNCHER"] = "self"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
 
 def fid_score_is(logits, dev):

@@ -1,6 +1,10 @@
 """CPU fp32 restatement of the reference's InceptionV3 forward (test infrastructure).
 
-PARITY UNPINNED.  The arithmetic behind ``image_realism/FID/inception.py:57``
+TOPOLOGY PINNED, WEIGHTS UNPINNED.  Round 3: the graph this module executes is compared node for node (94 convs:
+kernel / stride / padding / channels / sizes, BatchNorm eps, pools, concat order, 5 711 168 096 MAC) with the listing
+of the same network that the reference repository ships, executed by path under a stub tensorflow
+(``image_realism/IS/bird/inception/slim/inception_model.py:48-299`` -> ``tests/golden/inception_v3_topology.json``,
+``tests/test_topology.py``).  What stays unpinned is the NUMBERS of a pretrained forward: the arithmetic behind ``image_realism/FID/inception.py:57``
 (``torchvision.models.inception_v3(pretrained=True)``, torchvision==0.9.1 per
 ``requirements.txt:126``) is third-party and absent from /root/reference, and the
 build container has neither torchvision nor the pretrained file.  This module

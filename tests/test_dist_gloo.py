@@ -119,3 +119,33 @@ def test_bench_strong_scaling_shards_cover_the_job_once():
         assert covered[0][0] == 0 and covered[-1][1] == 30000
         assert all(x[1] == y[0] for x, y in zip(covered[:-1], covered[1:]))
     assert bench.rank_batch(1250) == 625 and bench.rank_batch(100) == 100 and bench.rank_batch(10000) == 1000
+
+
+def test_bench_self_launch_starts_fresh_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a torchrun environment starts N ranks itself: the parent
+    spawns `python -m torch.distributed.run --nproc-per-node N ... bench.py <same flags>` as a child process (no exec,
+    no GPU call in the parent), on 127.0.0.1 with a free port, and returns the child's exit code."""
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 7
+        return R()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert bench._self_launch(8) == 7
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["TISE_BENCH_LAUNCHER"] == "self"
+    # and main() takes that branch before importing anything that touches the GPU
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7

@@ -105,27 +105,27 @@ def test_resize_full_batch_bit_exact_and_batch_invariant(cuda_device):
 
 
 def test_bench_strong_scaling_two_ranks_on_one_gpu(cuda_device):
-    """bench.py --gpus 2 as two processes on THIS GPU (gloo rendezvous, TISE_DIST_BACKEND / TISE_FORCE_DEVICE0): the
-    strong-scaling job -- one image set sharded by global index, one all-reduce of the statistics, Frechet solved on
+    """`python bench.py --gpus 2` invoked DIRECTLY (no torchrun: bench.py starts its two ranks itself, both on THIS
+    GPU over a gloo rendezvous -- TISE_DIST_BACKEND / TISE_FORCE_DEVICE0): the strong-scaling job -- one image set sharded by global index, one all-reduce of the statistics, Frechet solved on
     both ranks -- must print the same scores as the one-process run of the same job, report the sharding it used and
     carry the roofline object.  (On a node the same code runs with backend nccl = RCCL.)"""
     import json
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    common = ["--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--no-cross-check", "--ref-images", "2200"]
+    common = ["--steps", "4", "--warmup", "1", "--images", "2000", "--no-cpu-baseline", "--no-cross-check", "--ref-images", "2200"]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, cwd=root, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads(one.stdout.strip().split("\n")[-1])
     env = dict(os.environ, TISE_DIST_BACKEND="gloo", TISE_FORCE_DEVICE0="1")
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2"] + common,
+    env.pop("WORLD_SIZE", None)
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"] + common,
                          cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     d2 = json.loads(two.stdout.strip().split("\n")[-1])
     assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["steps"] == 4
+    assert d2["config"]["collective"] == {"world_size": 2, "backend": "gloo", "launcher": "self"}
+    assert d1["config"]["step_images"] == 500 and "resident in HBM" in d1["config"]["workload"]
     assert d2["config"]["images_total"] == d1["config"]["images_total"] == 2000 and d2["config"]["images_per_gpu"] == 1000
     assert abs(d2["scores"]["fid"] - d1["scores"]["fid"]) <= 1e-7 and abs(d2["scores"]["is_mean"] - d1["scores"]["is_mean"]) <= 1e-9
     assert d2["roofline"]["frac"] > 0.05 and d2["allreduce_ms"] >= 0.0 and d2["cpu_baseline"] is None

@@ -249,3 +249,39 @@ def test_ranking_collect_refuses_synthetic_results(tmp_path):
     f.write_text("FID: 12.5" + weights.SYNTHETIC_TAG)
     with pytest.raises(ValueError, match="synthetic"):
         rs.parse_result_file("FID", str(f))
+
+
+def test_u8_cache_fingerprint_and_atomic_build(tmp_path):
+    """the decoded-pixel cache is valid only for the files it was built from -- images regenerated
+    under the same names and count (the evaluate-every-checkpoint workflow) invalidate it -- and a build that dies half
+    way leaves nothing that looks like a cache."""
+    from PIL import Image
+    from tise_toolbox_amd import img_data
+    d = tmp_path / "gen"
+    d.mkdir()
+    rng = np.random.default_rng(0)
+    for i in range(6):
+        Image.fromarray(rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)).save(d / f"{i}.png")
+    files = img_data.get_filenames(str(d))
+    cache = str(d / ".tise_u8_cache.npy")
+    assert not img_data.u8_cache_is_current(cache, files, str(d))
+    img_data.build_u8_cache(files, cache, num_workers=0, root=str(d))
+    assert img_data.u8_cache_is_current(cache, files, str(d)) and np.load(cache).shape == (6, 16, 16, 3)
+    assert sorted(os.listdir(d)) == sorted([".tise_u8_cache.npy", ".tise_u8_cache.npy.sha256"] + [f"{i}.png" for i in range(6)])
+    assert len(img_data.get_filenames(str(d))) == 6                     # neither cache file is walked as an image
+    # same names, same count, new pixels
+    st = os.stat(d / "3.png")
+    Image.fromarray(rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)).save(d / "3.png")
+    os.utime(d / "3.png", ns=(st.st_atime_ns, st.st_mtime_ns + 1_000_000))
+    assert not img_data.u8_cache_is_current(cache, files, str(d))
+    img_data.build_u8_cache(files, cache, num_workers=0, root=str(d))
+    assert np.array_equal(np.load(cache)[files.index(str(d / "3.png"))], np.asarray(Image.open(d / "3.png")))
+    # a build that fails half way (an image of another size) removes the temporary array AND the old fingerprint
+    Image.fromarray(rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)).save(d / "5.png")
+    with pytest.raises(ValueError):
+        img_data.build_u8_cache(files, cache, num_workers=0, batch_size=2, root=str(d))
+    assert not img_data.u8_cache_is_current(cache, files, str(d))
+    assert not [n for n in os.listdir(d) if ".tmp" in n] and not os.path.exists(cache + ".sha256")
+    # a truncated side file / missing array is "not current", never an exception
+    open(cache + ".sha256", "w").write("deadbeef")
+    assert not img_data.u8_cache_is_current(cache, files, str(d))

@@ -85,6 +85,16 @@ def world_size():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+def any_rank(flag):
+    """True on every rank when `flag` is true on at least one (also a synchronisation point); `flag` itself for one process."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return bool(flag)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return bool(t.item() > 0)
+
+
 def barrier():
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

@@ -226,9 +226,19 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
     rank, world, _ = tdist.env_world()
     if u8_cache:
         cache = os.path.join(path, U8_CACHE_NAME)          # the name holds neither "png" nor "jpg": never walked
-        if tdist.is_main() and not (os.path.exists(cache) and np.load(cache, mmap_mode="r").shape[0] == len(files)):
-            img_data.build_u8_cache(files, cache, num_workers)
-        tdist.barrier()
+        # valid only for exactly these files as they are on disk now (relative path, size, mtime_ns of every file in
+        # walk order, img_data.files_fingerprint): images regenerated under the same names rebuild it
+        err = None
+        if tdist.is_main() and not img_data.u8_cache_is_current(cache, files, path):
+            try:
+                img_data.build_u8_cache(files, cache, num_workers, root=path)
+            except Exception as e:                         # the other ranks must not wait in a barrier for a cache that never comes
+                err = e
+        failed = tdist.any_rank(err is not None)
+        if err is not None:
+            raise err
+        if failed:
+            raise RuntimeError(f"--u8-cache: rank 0 could not build {cache}")
         n_used = tdist.n_used_images(len(files), batch_size)
         lo, hi = tdist.shard_range(n_used // batch_size, rank, world)
         engine = _engine_for(model, dims)

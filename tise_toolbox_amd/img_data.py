@@ -49,26 +49,71 @@ class Dataset(data.Dataset):
         return get_filenames(data_path)
 
 
-def build_u8_cache(files, out_path, num_workers=8, batch_size=256):
+def files_fingerprint(files, root=None):
+    """sha256 over the walk-ordered list of (path relative to `root`, size, mtime_ns): what a decoded-pixel cache of
+    `files` is valid for.  Regenerating images into the same directory -- same names, same count, the
+    evaluate-every-checkpoint workflow -- changes mtime (and usually size), so the fingerprint changes."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        st = os.stat(f)
+        rel = os.path.relpath(f, root) if root else f
+        h.update(f"{rel}\0{st.st_size}\0{st.st_mtime_ns}\n".encode())
+    return h.hexdigest()
+
+
+def u8_cache_is_current(cache_path, files, root=None):
+    """True when `cache_path` and its fingerprint side file exist, the fingerprint matches `files` as they are on disk
+    now and the array has one row per file."""
+    side = cache_path + ".sha256"
+    if not (os.path.exists(cache_path) and os.path.exists(side)):
+        return False
+    try:
+        with open(side) as f:
+            want = f.read().strip()
+        return want == files_fingerprint(files, root) and np.load(cache_path, mmap_mode="r").shape[0] == len(files)
+    except (OSError, ValueError):
+        return False
+
+
+def build_u8_cache(files, out_path, num_workers=8, batch_size=256, root=None):
     """Decode `files` ONCE (walk order kept) into a memory-mappable ``.npy`` of shape (N, H, W, 3) uint8 -- SURVEY H2:
     50 k PNG/s of decode is 50-100 CPU cores, so repeated evaluations of the same image set (and multi-GPU runs) read
-    this cache instead: 5.9 GB for 30 k x 256 x 256.  All images must have the same size."""
+    this cache instead: 5.9 GB for 30 k x 256 x 256.  All images must have the same size.
+    The array is built in ``<out_path>.tmp.<pid>`` and renamed over `out_path` only after it is complete and flushed
+    (an interrupted build never leaves a cache that looks valid); ``<out_path>.sha256`` holds files_fingerprint() taken
+    BEFORE decoding, so files that change during the build invalidate the cache on the next run."""
     if not files:
         raise ValueError("no image files")
+    fingerprint = files_fingerprint(files, root)
     first = np.asarray(Image.open(files[0]).convert("RGB"))
     h, w, _ = first.shape
+    final_path, out_path = out_path, f"{out_path}.tmp.{os.getpid()}"
+    side = final_path + ".sha256"
+    if os.path.exists(side):
+        os.remove(side)                                   # the old fingerprint must not outlive the old array
     arr = np.lib.format.open_memmap(out_path, mode="w+", dtype=np.uint8, shape=(len(files), h, w, 3))
     loader = data.DataLoader(Dataset(None, file_names=files), batch_size=batch_size, shuffle=False, num_workers=num_workers,
                              collate_fn=collate_u8)
     i = 0
-    for batch in loader:
-        if isinstance(batch, (list, tuple)) or tuple(batch.shape[1:]) != (h, w, 3):
-            raise ValueError("--u8-cache needs images of one size; found a different size after " + files[i])
-        arr[i:i + batch.shape[0]] = batch.numpy()
-        i += batch.shape[0]
-    arr.flush()
-    del arr
-    return out_path
+    try:
+        for batch in loader:
+            if isinstance(batch, (list, tuple)) or tuple(batch.shape[1:]) != (h, w, 3):
+                raise ValueError("--u8-cache needs images of one size; found a different size after " + files[i])
+            arr[i:i + batch.shape[0]] = batch.numpy()
+            i += batch.shape[0]
+        if i != len(files):
+            raise RuntimeError(f"--u8-cache: decoded {i} of {len(files)} images")
+        arr.flush()
+        del arr
+        os.replace(out_path, final_path)
+        with open(side + ".tmp", "w") as f:
+            f.write(fingerprint + "\n")
+        os.replace(side + ".tmp", side)
+    finally:
+        if os.path.exists(out_path):
+            os.remove(out_path)
+    return final_path
 
 
 class U8CacheLoader:

@@ -194,6 +194,8 @@ def _trunk_forward(net, x):
 
 
 _SEEDED_CACHE = {}
+# white-noise fraction of each image of the BatchNorm calibration batch (seeded_init_)
+CALIBRATION_NOISE_FRACTIONS = (0.0, 0.0, 0.0, 0.03, 0.05, 0.05, 0.1, 0.2, 0.35, 0.5, 0.75, 1.0)
 
 
 @torch.no_grad()
@@ -232,10 +234,14 @@ def seeded_init_(net, seed=0, calibration="fid"):
             m.weight.copy_(torch.randn(m.weight.shape, generator=g) * 0.3)
             m.bias.zero_()
     # calibration batch: smooth random fields in [0,1], already through the inception.py:120-124 affine
-    n_cal = 8
+    # ... blended with white noise at fractions from 0 (smooth, photo-like) to 1 (i.i.d. uniform pixels, BASELINE
+    # configs[0]'s images): a stack calibrated on smooth fields alone amplifies white noise layer by layer (pool3 mean
+    # 51 instead of 0.25, FID ~1.3e3 for configs[0]: outside the published range the |dFID| <= 1e-3 budget is meant for)
+    alpha = torch.tensor(CALIBRATION_NOISE_FRACTIONS).view(-1, 1, 1, 1)
+    n_cal = alpha.shape[0]
     x = torch.rand((n_cal, 3, 10, 10), generator=g)
     x = F.interpolate(x, size=(299, 299), mode="bicubic", align_corners=False).clamp_(0.0, 1.0)
-    x = x + 0.05 * torch.rand((n_cal, 3, 299, 299), generator=g)
+    x = (1.0 - alpha) * x + alpha * torch.rand((n_cal, 3, 299, 299), generator=g)
     if calibration == "pm1":             # O-IS convention: Normalize((.5,.5,.5),(.5,.5,.5)) -> [-1, 1]
         x = (x - 0.5) / 0.5
     else:                                # FID wrapper convention: inception.py:120-124 on [0, 1] pixels
@@ -258,8 +264,8 @@ def seeded_init_(net, seed=0, calibration="fid"):
     # with them the absolute |dFID| <= 1e-3 budget -- sit in the range the reference publishes (2..200)
     for name in ("branch1x1", "branch3x3_2a", "branch3x3_2b", "branch3x3dbl_3a", "branch3x3dbl_3b", "branch_pool"):
         bn = getattr(net.Mixed_7c, name).bn
-        bn.weight.mul_(0.35)
-        bn.bias.mul_(0.35)
+        bn.weight.mul_(0.7)
+        bn.bias.mul_(0.7)
     net.eval()
     feats = _trunk_forward(net, x)
     for m, mom in zip(bns, old):
