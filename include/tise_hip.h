@@ -69,10 +69,12 @@ typedef struct tise_stats tise_stats_t;
 int tise_stats_create(int d, tise_stats_t** h);           /* allocates (d*d + d + 2) doubles, zeroed */
 int tise_stats_destroy(tise_stats_t* h);
 int tise_stats_reset(tise_stats_t* h, void* stream);
-/* accumulate `rows` feature rows: feats_dev[r*ld + c], c < d.  Callable once per batch. */
+/* accumulate `rows` feature rows: feats_dev[r*ld + c], c < d.  Callable once per batch.  ONE launch when d % 64 == 0
+ * and the rows are 16-byte aligned (the covariance kernel's diagonal-tile workgroups also fold the column sums and
+ * the row count); otherwise the two halves below, one after the other. */
 int tise_stats_update(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream);
-/* the two halves of tise_stats_update, separately launchable (bench.py times the MFMA half alone):
- * _cov: S += X^T X (fp64 MFMA)   _sum: s += column sums, n += rows                               */
+/* the two halves of tise_stats_update, separately launchable:
+ * _cov: S += X^T X (fp64 MFMA)   _sum: s += column sums, n += rows (column tiles x 8 row slices, fixed-order merge) */
 int tise_stats_update_cov(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream);
 int tise_stats_update_sum(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream);
 /* the contiguous fp64 buffer [S (d*d, upper triangle by 64x64 tile) | s (d) | n | pad] that a
@@ -270,7 +272,12 @@ int tise_gather_rows_f16(const void* x_dev, const int64_t* index_dev, int64_t n,
  *        last.  Same accuracy as 16 / 128, not the same bits (fp32 summation order).
  *   512  conv_pipe.hip configuration 33: resident-weights sliding-window kernel for Cin = 32 3x3 stride 1;
  *        weights as for 16.
- *   (Round 1's variants 0 / 32 / 64 / 256 and the other pipe configurations tied with 128 and were removed.)
+ *   256  (round 3) POOLED INPUT: the convolution (1x1, stride 1, no padding, Cin % 32 == 0, weights as for 128) reads
+ *        max_pool2d(x, 3, stride 2): args->H, W describe the UN-pooled tensor x, args->OH, OW the pooled grid
+ *        ((H - 3) / 2 + 1), which is also the output grid; M = N * OH * OW; tn in {2, 3, 4}.  The pool is taken while
+ *        the pixel operand is loaded (torchvision's MaxPool2d(3, 2) before Conv2d_3b_1x1 and before Mixed_5b,
+ *        image_realism/FID/inception.py:61-71); bit-identical to tise_maxpool3s2_split_nhwc followed by variant 128.
+ *   (Round 1's variants 0 / 32 and the other pipe configurations tied with 128 and were removed.)
  * Bits 8..11 of args->nseg are measurement switches (tools/conv_ablate.py, tools/conv_stamps.py) and must be
  * zero in product calls.
  * ------------------------------------------------------------------------------------------ */

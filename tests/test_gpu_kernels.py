@@ -239,6 +239,47 @@ def test_frechet_prefactored_equals_one_call_form(dev, kind):
         fresh.distance_prefactored(m1, m2, s2)                          # nothing factored yet
 
 
+@pytest.mark.parametrize("d", [100, 300, 1000])
+@pytest.mark.parametrize("pivoted", [False, True])
+def test_frechet_partial_last_panel_both_factorisations(dev, d, pivoted, monkeypatch):
+    """the unpivoted 64-column Cholesky with a PARTIAL last panel (d % 64 = 36, 44, 40) through
+    tise_frechet_distance, against the scipy-sqrtm oracle, and the same inputs through the pivoted factorisation (the
+    TISE_CHOL_PIVOTED switch is read per call): both within 1e-9 (full rank) and of each other."""
+    from tise_toolbox_amd import device
+    m1, s1, m2, s2 = _cases.frechet_case(d, "fullrank", seed=11)
+    want = fid_oracle.calculate_frechet_distance(m1, s1, m2, s2)
+    solver = device.FrechetSolver(d, dev)
+    if pivoted:
+        monkeypatch.setenv("TISE_CHOL_PIVOTED", "1")
+    got = solver.distance(m1, s1, m2, s2)
+    assert got["rank"] == d and abs(got["fid"] - want) <= 1e-9 * max(1.0, abs(want)), (got["fid"], want)
+    solver.set_profiling(True)
+    solver.distance(m1, s1, m2, s2)
+    ph = solver.phase_ms()
+    monkeypatch.delenv("TISE_CHOL_PIVOTED", raising=False)
+    solver.distance(m1, s1, m2, s2)
+    ph2 = solver.phase_ms()
+    if pivoted and d >= 300:
+        assert ph["pchol"] > ph2["pchol"]                         # the switch really selected the slower, pivoted kernels
+
+
+def test_frechet_lost_prefactor_is_detected(dev):
+    """tise_pivoted_cholesky overwrites the solver's factor buffer, so a factor left by prefactor() must be
+    invalidated (the prefactored distance then fails instead of silently using the wrong factor), and
+    fid_score.calculate_fid_given_paths's fall-back path -- the one-call form -- gives the right answer."""
+    from tise_toolbox_amd import _lib, device
+    d = 192
+    m1, s1, m2, s2 = _cases.frechet_case(d, "fullrank", seed=5)
+    other = _cases.frechet_case(d, "fullrank", seed=6)[1]
+    solver = device.FrechetSolver(d, dev)
+    solver.prefactor(torch.as_tensor(s1, device=dev))
+    solver.pivoted_cholesky(torch.as_tensor(other, device=dev))            # overwrites h->lt
+    with pytest.raises(_lib.TiseStatusError):
+        solver.distance_prefactored(m1, m2, s2)
+    want = fid_oracle.calculate_frechet_distance(m1, s1, m2, s2)
+    assert abs(solver.distance(m1, s1, m2, s2)["fid"] - want) <= 1e-9
+
+
 def test_frechet_properties(dev):
     from tise_toolbox_amd import fid_score
     d = 128
@@ -566,6 +607,72 @@ def test_conv_split_tile_width_does_not_change_results(dev):
                     ref = out
                 else:
                     assert torch.equal(out, ref), (variant, tn, Cin, Cout)
+
+
+def test_conv_pooled_input_is_bit_identical_to_pool_then_conv(dev):
+    """conv_poolin_kernel (max_pool2d(3, 2) taken inside the operand load of a 1x1 convolution; the trunk's two stem
+    pools, inception.py:61-71) against the two-kernel path it replaces -- tise_maxpool3s2_split_nhwc, then the default
+    kernel: same re-split pooled values, same K order and MFMA sequence => every output bit equal; and against an
+    fp64 max-pool + convolution.  Shapes: the trunk's two (147^2 x 64 -> 80; 71^2 x 192 -> 208 into four segments
+    incl. the raw fp32 pool-branch slice), odd sizes, an M tail, one image, exact-tie windows (constant regions)."""
+    import torch.nn.functional as F
+    from tise_toolbox_amd.conv_split import SplitConv, merge, split
+    from tise_toolbox_amd.trunk import SplitTrunk
+    g = torch.Generator(device="cpu").manual_seed(33)
+    for (n, H, W, Cin, Cout, segs_spec) in [(3, 147, 147, 64, 80, None), (2, 71, 71, 192, 208, (64, 112, 176, 208)),
+                                            (5, 9, 12, 32, 40, None), (1, 3, 3, 96, 256, None), (7, 20, 7, 64, 136, (8, 136))]:
+        x = (torch.rand((n, H, W, Cin), generator=g) * 3.0)
+        x[:, : H // 2, : W // 2, : Cin // 2] = 1.25                  # constant windows: ties between taps
+        x = x.to(dev)
+        w = (torch.randn((Cout, Cin, 1, 1), generator=g) * (2.0 / Cin) ** 0.5).to(dev)
+        b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+        xs = split(x)
+        conv = SplitConv(w, b, (1, 1), (0, 0), dev, variant="fast")
+        oh, ow = conv.pooled_out_hw(H, W)
+
+        def run(pooled):
+            outs, segs = [], []
+            bounds = [0] + list(segs_spec or (Cout,))
+            for i, (c0, c1) in enumerate(zip(bounds[:-1], bounds[1:])):
+                raw = segs_spec is not None and i == len(bounds) - 2            # last segment raw fp32 (pool branch)
+                t = (torch.full((n, oh, ow, c1 - c0), 7.0, dtype=torch.float32, device=dev) if raw else
+                     torch.full((n, oh, ow, 2 * (c1 - c0)), 7.0, dtype=torch.float16, device=dev))
+                outs.append(t)
+                segs.append((c0, c1, t, 0, 1 if raw else 0))
+            if pooled:
+                conv(xs, segs, pooled_input=True)
+            else:
+                conv(SplitTrunk._maxpool_split(xs), segs)
+            return outs
+        fused, two = run(True), run(False)
+        for a, c in zip(fused, two):
+            assert torch.equal(a, c), (H, W, Cin, Cout)
+        # fp64 reference on the values the split tensor really holds
+        xm = merge(xs).double().permute(0, 3, 1, 2)
+        ref = F.conv2d(F.max_pool2d(xm, 3, 2), w.double(), None).permute(0, 2, 3, 1)
+        bounds = [0] + list(segs_spec or (Cout,))
+        got, want = [], []
+        for o, c0, c1 in zip(fused, bounds[:-1], bounds[1:]):
+            if o.dtype == torch.float32:                                  # raw segment: conv only (bias + ReLU follow the avg-pool)
+                got.append(o.double()); want.append(ref[..., c0:c1])
+            else:
+                got.append(merge(o).double()); want.append(torch.relu(ref[..., c0:c1] + b.double()[c0:c1]))
+        got, want = torch.cat(got, -1), torch.cat(want, -1)
+        assert (got - want).abs().max().item() <= 4e-6 * max(1.0, want.abs().max().item()), (H, W, Cin, Cout)
+
+
+def test_split_trunk_fused_pools_do_not_change_a_bit(dev, monkeypatch):
+    """The whole trunk with the stem max-pools fused into their consumers == the trunk with separate pool kernels."""
+    from tise_toolbox_amd.inception import InceptionV3
+    from tise_toolbox_amd.trunk import SplitTrunk
+    m = InceptionV3([3], seed=0).to(dev).eval()
+    x = torch.rand((5, 3, 299, 299), device=dev).contiguous(memory_format=torch.channels_last)
+    fused = SplitTrunk(m, dev)
+    assert fused.fuse_pool
+    monkeypatch.setenv("TISE_POOL_FUSE", "0")
+    plain = SplitTrunk(m, dev)
+    assert not plain.fuse_pool
+    assert torch.equal(fused(x), plain(x))
 
 
 def test_split_trunk_batch_sizes_and_determinism(dev):

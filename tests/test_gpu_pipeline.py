@@ -372,6 +372,23 @@ def test_ragged_crops_one_trunk_pass_and_per_class_fid(setup, tmp_path):
         m2, s2 = fid_score._compute_statistics_of_path(str(tmp_path / f"gen_{c}"), model, n2, 2048, True, 0)
         want = fid_score.calculate_frechet_distance(m1, s1, m2, s2)
         assert abs(per[c] - want) <= 1e-6 * max(1.0, abs(want)), (c, per[c], want)
+    # ... and the CPU ORACLE on the same crops (object_fidelity/O-FID/fid_score.py:188-205 applied to
+    # one class's files): PIL-exact resize of every crop, CPU fp32 InceptionV3 with the same 80-class stand-in
+    # weights, np.cov, scipy sqrtm.  |dFID| <= 1e-3.
+    from tise_toolbox_amd import img_data
+    from tise_toolbox_amd.inception import build_inception3
+    sd80 = {k: v.float() for k, v in build_inception3(num_classes=80, seed=0).state_dict().items()}
+
+    def oracle_stats(root):
+        files = img_data.get_filenames(str(root))
+        x = np.stack([resize_oracle.to_tensor(resize_oracle.resize_bilinear_u8(np.asarray(Image.open(f).convert("RGB")), 299, 299))
+                      for f in files])
+        act = inception_oracle.inception_forward(sd80, torch.from_numpy(x))[3].flatten(1).numpy().astype(np.float64)
+        return fid_oracle.calculate_activation_statistics(act)
+    for c in per:
+        want = fid_oracle.calculate_frechet_distance(*oracle_stats(tmp_path / f"ref_{c}"), *oracle_stats(tmp_path / f"gen_{c}"))
+        print("per-class O-FID", c, "device", per[c], "oracle", want)
+        assert abs(per[c] - want) <= 1e-3, (c, per[c], want)
 
 
 def test_baseline_config0_1k_vs_1k_random_pngs(cuda_device, tmp_path, monkeypatch):

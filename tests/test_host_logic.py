@@ -231,11 +231,17 @@ def test_weights_resolution_never_silently_synthetic(tmp_path, monkeypatch, caps
     with pytest.raises(RuntimeError, match="Invalid path"):
         weights.resolve(str(tmp_path / "nope.pth"), False, "inception")
     f = tmp_path / "w.pth"; f.write_bytes(b"x")
-    assert weights.resolve(str(f), True, "inception") == (str(f), "")
-    # the files the reference itself would read are found without a flag
+    assert weights.resolve(str(f), False, "inception") == (str(f), "")
+    with pytest.raises(RuntimeError, match="mutually exclusive"):         # an explicit stand-in request is never overridden
+        weights.resolve(str(f), True, "inception")
+    # the files the reference itself would read are found without a flag (and named on stderr)
     hub = tmp_path / "torch_home" / "hub" / "checkpoints"; hub.mkdir(parents=True)
     (hub / "inception_v3_google-1a9a5a14.pth").write_bytes(b"x")
+    capsys.readouterr()
     assert weights.resolve(None, False, "inception") == (str(hub / "inception_v3_google-1a9a5a14.pth"), "")
+    assert "inception_v3_google-1a9a5a14.pth" in capsys.readouterr().err
+    # ... but --synthetic-weights means the stand-ins on every machine, whatever ~/.cache holds
+    assert weights.resolve(None, True, "inception") == (None, weights.SYNTHETIC_TAG)
     (tmp_path / "weights").mkdir()
     (tmp_path / "weights" / "inceptionv3_fine_to_with_80_coco_classes.pth").write_bytes(b"x")
     assert weights.resolve(None, False, "inception80")[0] == os.path.join("weights", "inceptionv3_fine_to_with_80_coco_classes.pth")

@@ -98,7 +98,9 @@ def main(argv=None):
         sums[pi, 1] = float(len(mine))
     tdist.all_reduce_sum_(sums)
     s = sums.cpu().numpy()
-    phrase_res = {p: {"success": float(s[i, 0]), "total": float(s[i, 1]), "score": float(s[i, 0]) / float(s[i, 1])}
+    # a phrase without items keeps the score 0.0 it was initialised with and still enters the mean (PA.py:52-67)
+    phrase_res = {p: {"success": float(s[i, 0]), "total": float(s[i, 1]),
+                      "score": float(s[i, 0]) / float(s[i, 1]) if s[i, 1] else 0.0}
                   for i, p in enumerate(phrases)}
     PA = np.mean([phrase_res[p]["score"] for p in phrase_res])                # :67
     if tdist.is_main():

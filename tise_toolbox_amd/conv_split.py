@@ -215,12 +215,22 @@ class SplitConv:
         ow = (w + 2 * self.padding[1] - self.kw) // self.stride[1] + 1
         return oh, ow
 
-    def __call__(self, x, segs):
+    def pooled_out_hw(self, h, w):
+        """Output grid of ``__call__(..., pooled_input=True)``: max_pool2d(3, stride 2) of the input, then this 1x1 conv."""
+        return (h - 3) // 2 + 1, (w - 3) // 2 + 1
+
+    def __call__(self, x, segs, pooled_input=False):
         """x: split tensor (N, H, W, 2*Cin) fp16.  segs: list of (c0, c1, dst_tensor, dst_off, mode):
-        mode 0 -> dst is a split tensor (N, OH, OW, 2*C), mode 1 -> dst is a (N, OH, OW, C) fp32 tensor."""
+        mode 0 -> dst is a split tensor (N, OH, OW, 2*C), mode 1 -> dst is a (N, OH, OW, C) fp32 tensor.
+        ``pooled_input``: the convolution (1x1, Cin % 32 == 0, default packing) reads max_pool2d(x, 3, stride 2) -- the
+        pool is taken while loading the operand (conv_poolin_kernel), bit-identical to pooling first."""
         assert x.dtype == torch.float16 and x.dim() == 4 and x.shape[3] == 2 * self.cin and x.is_contiguous()
         n, h, w, _ = x.shape
         oh, ow = self.out_hw(h, w)
+        if pooled_input:
+            assert (self.kh, self.kw, self.stride, self.padding) == (1, 1, (1, 1), (0, 0)) and self.cin % 32 == 0
+            assert self.variant == "fast" and self.w_fast is not None and h >= 3 and w >= 3
+            oh, ow = self.pooled_out_hw(h, w)
         if self.variant == "rowwin" and not rowwin_fits(ow, self.kw):
             # rows so short that the window of a 128-pixel tile needs more than the kernel's six pieces per wave (OW < 7
             # at KW = 3): the default kernel serves the layer from its own packing, built on first use
@@ -256,7 +266,9 @@ class SplitConv:
         if timer is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.pipe_cfg is not None:
+        if pooled_input:
+            code = min(max(tn, 2), 4) | 256
+        elif self.pipe_cfg is not None:
             code = 512 | self.pipe_cfg
         else:
             code = tn | {"glds": 16, "fast": 128, "rowwin": 64}[self.variant]

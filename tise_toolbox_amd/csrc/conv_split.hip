@@ -728,6 +728,186 @@ static int launch_rowwin_any(const ConvArgs* a, int tn, hipStream_t st) {
     return TISE_ERR_UNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pooled-input 1x1 convolution ("poolin"): max_pool2d(3, stride 2) FUSED INTO THE OPERAND LOAD of the 1x1 convolution
+// that consumes it -- the two stem pools of the trunk (inception.py:61-66: MaxPool -> Conv2d_3b_1x1; :69-71: MaxPool
+// -> Mixed_5b, whose four 1x1 convolutions run as one).  As separate kernels the pool wrote its result (1.4 + 0.9 GB per
+// 1000 images), the convolution read it back, and both launches were bound by that traffic (profiles/r02z: max-pools
+// 2.8 ms, Conv2d_3b 0.68 ms, Mixed_5b's 1x1 0.6 ms per 1000 images).  Here the pixel operand of a K-step is not DMA'd:
+// every thread loads the nine taps of two (pooled pixel, 8-channel) pairs -- 64 contiguous bytes per pixel line and
+// four lanes -- takes the maximum of the MERGED values v = hi + lo * 2^-11 (exact in fp32), re-splits it and writes the
+// (hi, lo) chunks into the LDS rows the MFMA fragments are read from (the default kernel's 128-byte rows and swizzle).
+// The arithmetic is that of maxpool3s2_split_kernel followed by conv_split_fast_kernel -- the same re-split values, the
+// same K order and MFMA sequence -- so the result is BIT-IDENTICAL to the two-kernel path (tests).  Weights stream by
+// LDS-DMA as in the default kernel (two stages); one pixel-operand buffer (the kernel is bound by the pool's input
+// read, and two to three workgroups per CU overlap one another's load and MFMA phases).
+// Geometry in the argument struct: H, W = the UN-pooled input, OH, OW = the pooled grid = the convolution's output
+// grid, KH = KW = 1, M = N * OH * OW.
+template <int TN>
+__global__ __launch_bounds__(256, 2) void conv_poolin_kernel(const ConvArgs p) {
+    constexpr int BN = 32 * TN;
+    constexpr int A_BYTES = CS_BM * 128, B_BYTES = BN * 128;
+    constexpr int OPER = A_BYTES + 2 * B_BYTES;
+    constexpr int ETW = TN > 1 ? 2 : 1;
+    constexpr int EPI0 = 4 * conv_epi::Staging<ETW>::BYTES;
+    constexpr int EPI_BYTES = EPI0 + conv_epi::EpiArea<BN>::BYTES;
+    constexpr int LDS_BYTES = OPER > EPI_BYTES ? OPER : EPI_BYTES;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned tiles_n = (unsigned)(p.Cout + BN - 1) / BN;
+    const unsigned nwg = gridDim.x;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const unsigned tile_m = bid / tiles_n;
+    const int tile_n = (int)(bid - tile_m * tiles_n);
+    const long long m0 = (long long)tile_m * CS_BM;
+    const int n0 = tile_n * BN;
+    const int pix_bytes = p.Cin * 4;
+
+    // producer role: items (row, 8-channel pair c): row = (tid >> 2) + 64 * it, c = tid & 3 -- the four lanes of a row
+    // read 64 contiguous bytes of the hi half and 64 of the lo half of a pixel's 128-byte block line
+    const int pc = tid & 3;
+    const unsigned char* src0[2];                             // top-left tap of the item's pooled pixel, channel pair c, block 0
+    int arow_off[2];                                          // byte offset of the item's hi chunk inside the A buffer
+    {
+        const unsigned ohw = (unsigned)(p.OH * p.OW), M32 = (unsigned)p.M;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = (tid >> 2) + 64 * it;
+            const unsigned pix = tile_m * CS_BM + row;
+            const unsigned pp = pix < M32 ? pix : 0u;         // rows beyond M compute pixel 0 and are dropped by the epilogue
+            const unsigned n = pp / ohw;
+            const unsigned rem = pp - n * ohw;
+            const unsigned oh = rem / (unsigned)p.OW, ow = rem - oh * (unsigned)p.OW;
+            src0[it] = reinterpret_cast<const unsigned char*>(p.x) +
+                       (((long long)n * p.H + 2 * oh) * p.W + 2 * ow) * pix_bytes + pc * 16;
+            arow_off[it] = row * 128 + ((pc ^ ((row >> 1) & 7)) * 16);
+        }
+    }
+    // weights: as in the default kernel
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (long long)n0 * p.Kpad * 4;
+    unsigned pb[TN];
+    int pb_off[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int q = wave * TN + i;
+        const int r = q * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        pb[i] = (unsigned)r * (unsigned)p.Kpad * 4u + c * 16;
+        pb_off[i] = A_BYTES + q * 1024;
+    }
+    float16_t acc_main[1][TN], acc_corr[1][TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc_main[0][t][j] = 0.f; acc_corr[0][t][j] = 0.f; }
+    conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
+    if (tid < BN / 4) {
+        sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + n0 + 4 * tid);
+        bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + n0 + 4 * tid);
+    }
+    const int bswz = ((lane & 31) >> 1) & 7;
+    const int fb0 = (lane & 31) * 128 + (((lane >> 5)) ^ bswz) * 16;
+    const int fb1 = (lane & 31) * 128 + ((2 + (lane >> 5)) ^ bswz) * 16;
+    const unsigned char* fa = lds + wave * 32 * 128;
+    const int row_bytes = p.W * pix_bytes;
+    const int nsteps = p.Cin / CS_BK;
+
+#define PI_B_ISSUE(BOFF)                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                       \
+        const unsigned char* sw_ = wbase + pb[i];                                                          \
+        __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)(lds + (BOFF) + pb_off[i]), 16, 0, 0);            \
+        pb[i] += 128;                                                                                      \
+    }
+    PI_B_ISSUE(0)
+    for (int step = 0; step < nsteps; ++step) {
+        const int bcur = (step & 1) * B_BYTES;
+        // ---- pooled pixel operand of this K-step: 2 items x 9 taps x (hi, lo) 16-byte loads ------------------
+        half8_t ph[2], pl[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const unsigned char* s0 = src0[it] + step * 128;
+            half8_t vh[9], vl[9];
+#pragma unroll
+            for (int dh = 0; dh < 3; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 3; ++dw) {
+                    const unsigned char* q = s0 + dh * row_bytes + dw * pix_bytes;
+                    vh[dh * 3 + dw] = *reinterpret_cast<const half8_t*>(q);
+                    vl[dh * 3 + dw] = *reinterpret_cast<const half8_t*>(q + 64);
+                }
+            float bv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bv[i] = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bv[i] = fmaxf(bv[i], (float)vh[t][i] + (float)vl[t][i] * (1.f / 2048.f));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                ph[it][i] = (_Float16)bv[i];
+                pl[it][i] = (_Float16)((bv[i] - (float)ph[it][i]) * 2048.f);
+            }
+        }
+        __syncthreads();                                      // the previous step's fragment reads of the A buffer are done
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            *reinterpret_cast<half8_t*>(lds + arow_off[it]) = ph[it];
+            *reinterpret_cast<half8_t*>(lds + (arow_off[it] ^ 64)) = pl[it];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this step's weights have landed (issued one step ago)
+        __syncthreads();
+        // next step's weights into the other stage (last read by the MFMAs of step - 1, which ended before the first
+        // barrier above); issued AFTER the barrier, whose fence would otherwise wait for them
+        if (step + 1 < nsteps) PI_B_ISSUE(((step + 1) & 1) * B_BYTES)
+        // ---- MFMAs: the default kernel's order (bit-identical accumulation) ---------------------------------
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int fbo = s ? fb1 : fb0;
+            const half8_t a_hi = *reinterpret_cast<const half8_t*>(fa + fbo);
+            const half8_t a_lo = *reinterpret_cast<const half8_t*>(fa + (fbo ^ 64));
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const unsigned char* bb = lds + A_BYTES + bcur + t * 32 * 128;
+                const half8_t b_hi = *reinterpret_cast<const half8_t*>(bb + fbo);
+                const half8_t b_lo = *reinterpret_cast<const half8_t*>(bb + (fbo ^ 64));
+                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo, a_hi, acc_corr[0][t], 0, 0, 0);
+                acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_hi, acc_main[0][t], 0, 0, 0);
+                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_lo, acc_corr[0][t], 0, 0, 0);
+            }
+        }
+    }
+#undef PI_B_ISSUE
+    __syncthreads();
+    conv_epi::prepare<BN>(p, lds + EPI0, n0, sc_pre, bs_pre);
+    __syncthreads();
+    conv_epi::store_tiles_desc<TN, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, lds + EPI0, m0 + wave * 32);
+}
+
+static int launch_poolin(const ConvArgs* a, int tn, hipStream_t st) {
+    if (a->KH != 1 || a->KW != 1 || a->PH != 0 || a->PW != 0 || a->Cin % 32 != 0 || a->Kpad != a->Cin || a->H < 3 || a->W < 3 ||
+        a->OH != (a->H - 3) / 2 + 1 || a->OW != (a->W - 3) / 2 + 1 || a->M != (long long)a->N * a->OH * a->OW || a->M >= 0x7fffff00LL ||
+        (long long)a->W * a->Cin * 4 * 3 >= 0x7fffffffLL)
+        return TISE_ERR_INVALID_ARG;
+    const int bn = 32 * tn;
+    const long long tiles = ((a->M + CS_BM - 1) / CS_BM) * ((a->Cout + bn - 1) / bn);
+    if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)tiles), block(256);
+    switch (tn) {
+        case 2: hipLaunchKernelGGL(conv_poolin_kernel<2>, grid, block, 0, st, *a); break;
+        case 3: hipLaunchKernelGGL(conv_poolin_kernel<3>, grid, block, 0, st, *a); break;
+        case 4: hipLaunchKernelGGL(conv_poolin_kernel<4>, grid, block, 0, st, *a); break;
+        default: return TISE_ERR_INVALID_ARG;
+    }
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
 int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream);   // conv_pipe.hip
 
 extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
@@ -746,6 +926,7 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     }
     if (args->seg[0].c0 != 0) return TISE_ERR_INVALID_ARG;
     if (tn & 512) return tise_conv_pipe_launch(args, tn & 255, stream);   // resident-weights sliding-window kernel
+    if (tn & 256) return launch_poolin(args, tn & 15, (hipStream_t)stream);       // max-pool fused into a 1x1 convolution's operand load
     if (tn & 64) return launch_rowwin_any(args, tn & 15, (hipStream_t)stream);   // row-window kernel, K order (kh, block, kw)
     const bool glds = (tn & 16) != 0;
     // fast path: K order (tap, full 32-channel block) then paired 16-channel tails (see the kernel); Kpad says which

@@ -1007,7 +1007,7 @@ int run_pchol(tise_frechet* h, const double* S, double off, int* rank_out, hipSt
 // factor of S (+ off I) into h->lt: the unpivoted fast path when it succeeds (full numerical rank), else the pivoted one
 int run_chol(tise_frechet* h, const double* S, double off, int* rank_out, hipStream_t st) {
     const int d = h->d;
-    static const bool pivoted_only = getenv("TISE_CHOL_PIVOTED") != nullptr;      // A/B switch (tests, tools/frechet_probe.py)
+    const bool pivoted_only = getenv("TISE_CHOL_PIVOTED") != nullptr;             // A/B switch, read per call (tests, tools/frechet_probe.py)
     if (d <= 2048 && d >= CHB && !pivoted_only) {
         int* fail = h->chosen;                                     // one int of the pivoted path's scratch, rewritten by it anyway
         double* maxdiag = h->diag;
@@ -1235,6 +1235,7 @@ int tise_pivoted_cholesky(tise_frechet_t* h, const double* sigma_dev, double* lt
     hipStream_t st = (hipStream_t)stream;
     const int d = h->d;
     int r = 0;
+    h->prefactored = 0;                                        // h->lt is overwritten: a factor left by tise_frechet_prefactor is gone
     int rc = run_pchol(h, sigma_dev, 0.0, &r, st);
     if (rc != TISE_OK) return rc;
     if (r < d) {

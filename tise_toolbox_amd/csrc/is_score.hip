@@ -13,7 +13,7 @@
 //
 // Kernels (all HBM-bound: logits are read twice, 2 * 4 * C bytes per row)
 //   is_row_kernel   one wave per row: row max, log-sum-exp, a_i = sum_c p z - lse   (wave shuffles)
-//   is_col_kernel   one thread per class column, fixed row order: B_kc += exp(z_ic - lse_i); one extra
+//   is_col_kernel   32 columns x 32 row phases per workgroup, fixed row order: B_kc += exp(z_ic - lse_i); one extra
 //                   block folds a_i into A_k.  Fixed order => bitwise reproducible, no atomics.
 //   is_finalize_kernel  scores, mean, std (ddof 0).
 #include "common.h"
@@ -69,16 +69,19 @@ __global__ __launch_bounds__(256) void is_row_kernel(const float* __restrict__ l
     }
 }
 
-// blocks [0, nblk_c): 256 threads = 64 columns x 4 row phases, rows in fixed order.
+// blocks [0, nblk_c): 1024 threads = 32 columns x 32 row phases, rows in fixed order (the first version ran 64 columns
+// x 4 phases in 16 workgroups: every thread walked 250 rows of fp64 exp by itself, 83-97 us per 1000 x 1000 batch).
 // block nblk_c: folds a_i into A_k.
-__global__ __launch_bounds__(256) void is_col_kernel(const float* __restrict__ logits, int64_t rows, int64_t ld, int C,
+#define ISC_COLS 32
+#define ISC_PH 32
+__global__ __launch_bounds__(1024) void is_col_kernel(const float* __restrict__ logits, int64_t rows, int64_t ld, int C,
                                                      int c0, double inv_t, const double* __restrict__ lse,
                                                      const double* __restrict__ a, int64_t idx_base, int64_t n_total,
                                                      int splits, int rule, int nblk_c, double* __restrict__ acc) {
-    __shared__ double part[4][64];
+    __shared__ double part[ISC_PH][ISC_COLS + 1];
     double* A = acc;
     double* B = acc + splits;
-    const int ph = threadIdx.x >> 6, lc = threadIdx.x & 63;
+    const int ph = threadIdx.x / ISC_COLS, lc = threadIdx.x % ISC_COLS;
     if ((int)blockIdx.x == nblk_c) {
         // A_k += sum of a_i over the rows of split k present in this call (fixed order)
         for (int k = 0; k < splits; ++k) {
@@ -86,26 +89,35 @@ __global__ __launch_bounds__(256) void is_col_kernel(const float* __restrict__ l
             split_range(k, idx_base, rows, n_total, splits, rule, &r0, &r1);
             if (r1 <= r0) continue;                      // uniform across the block
             double v = 0.0;
-            for (int64_t r = r0 + threadIdx.x; r < r1; r += 256) v += a[r];
+            for (int64_t r = r0 + threadIdx.x; r < r1; r += 1024) v += a[r];
             v = wave_sum(v);
-            if (lc == 0) part[ph][0] = v;
+            if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][0] = v;
             __syncthreads();
-            if (threadIdx.x == 0) A[k] += ((part[0][0] + part[1][0]) + part[2][0]) + part[3][0];
+            if (threadIdx.x == 0) {
+                double t = 0.0;
+                for (int w = 0; w < 16; ++w) t += part[w][0];
+                A[k] += t;
+            }
             __syncthreads();
         }
         return;
     }
-    const int c = blockIdx.x * 64 + lc;
+    const int c = blockIdx.x * ISC_COLS + lc;
     for (int k = 0; k < splits; ++k) {
         int64_t r0, r1;
         split_range(k, idx_base, rows, n_total, splits, rule, &r0, &r1);
         if (r1 <= r0) continue;                          // uniform across the block
         double sum = 0.0;
         if (c < C)
-            for (int64_t r = r0 + ph; r < r1; r += 4) sum += exp((double)logits[r * ld + c0 + c] * inv_t - lse[r]);
+            for (int64_t r = r0 + ph; r < r1; r += ISC_PH) sum += exp((double)logits[r * ld + c0 + c] * inv_t - lse[r]);
         part[ph][lc] = sum;
         __syncthreads();
-        if (ph == 0 && c < C) B[(int64_t)k * C + c] += ((part[0][lc] + part[1][lc]) + part[2][lc]) + part[3][lc];
+        if (ph == 0 && c < C) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < ISC_PH; ++q) t += part[q][lc];
+            B[(int64_t)k * C + c] += t;
+        }
         __syncthreads();
     }
 }
@@ -166,8 +178,8 @@ int tise_is_update(const float* logits_dev, int64_t rows, int64_t ld, int C, dou
     hipLaunchKernelGGL(is_row_kernel, dim3((unsigned)ceil_div64(rows, 4)), dim3(256), 0, st, logits_dev, rows, ld, Ce, c0,
                        inv_t, lse, a);
     TISE_LAUNCH_CHECK();
-    const int nblk_c = ceil_div(Ce, 64);
-    hipLaunchKernelGGL(is_col_kernel, dim3(nblk_c + 1), dim3(256), 0, st, logits_dev, rows, ld, Ce, c0, inv_t, lse, a,
+    const int nblk_c = ceil_div(Ce, ISC_COLS);
+    hipLaunchKernelGGL(is_col_kernel, dim3(nblk_c + 1), dim3(1024), 0, st, logits_dev, rows, ld, Ce, c0, inv_t, lse, a,
                        idx_base, n_total, splits, split_rule, nblk_c, acc_dev);
     TISE_LAUNCH_CHECK();
     return TISE_OK;

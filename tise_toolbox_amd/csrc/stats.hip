@@ -24,6 +24,7 @@ struct tise_stats {
     int tiles;        // ceil(d / 64)
     double* buf;      // device: S | s | n | pad
     size_t n_doubles;
+    double* scratch;  // device: COLSUM_SLICES x tiles x 64 partial column sums | tiles ticket counters (unsigned)
 };
 
 // XCD-aware, bijective remap of a linear block id: blocks that share id % 8 share an XCD (and
@@ -60,9 +61,15 @@ __global__ __launch_bounds__(256) void syrk_f32_upper_kernel(const float* __rest
 // (float4 loads, 8 per thread) under 64 MFMAs per wave (4096 cycles) of work on the previous slab; the
 // slab stays fp32 in LDS (pitch 80 floats: the two k-rows a 32-lane half reads land on disjoint banks)
 // and is widened to fp64 (exact) in registers.
+// COLSUM: the workgroups of the DIAGONAL tiles (tm == tn) also fold the column sums s += sum_rows X of their 64
+// columns -- the slab is in LDS anyway -- and tile (0, 0) adds the row count: np.mean's sufficient statistic without a
+// second pass over X and without a second launch (the stand-alone colsum kernel was 32 workgroups on 256 CUs, 65-77 us
+// per 1000 x 2048 batch = 0.11 TB/s).  Fixed order: thread (column c, phase p) adds rows p, p+4, ... of every slab.
 #define SYF_P 80
+template <bool COLSUM>
 __global__ __launch_bounds__(256, 2) void syrk_f32_upper_bk64_kernel(const float* __restrict__ X, int64_t ld, int rows,
-                                                                     int d, int tiles, double* __restrict__ S) {
+                                                                     int d, int tiles, double* __restrict__ S,
+                                                                     double* __restrict__ s, double* __restrict__ n) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 64 * SYF_P];
     float* As = lds;
     float* Bs = lds + 64 * SYF_P;
@@ -97,6 +104,8 @@ __global__ __launch_bounds__(256, 2) void syrk_f32_upper_bk64_kernel(const float
         for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
     SYF_FETCH(0)
     const float* Bp = Bs;
+    const bool diag = COLSUM && tm == tn;                     // workgroup-uniform
+    double csum = 0.0;
     for (int k0 = 0; k0 < rows; k0 += 64) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -105,6 +114,10 @@ __global__ __launch_bounds__(256, 2) void syrk_f32_upper_bk64_kernel(const float
         }
         __syncthreads();
         if (k0 + 64 < rows) { SYF_FETCH(k0 + 64) }
+        if (diag) {                                           // rows past the end were zeroed by value
+#pragma unroll
+            for (int kk = 0; kk < 64; kk += 4) csum += (double)As[(kk + wave) * SYF_P + lane];
+        }
 #pragma unroll
         for (int kk = 0; kk < 64; kk += 4) {
             const double a0 = (double)As[(kk + fk) * SYF_P + wr * 32 + fi];
@@ -119,6 +132,50 @@ __global__ __launch_bounds__(256, 2) void syrk_f32_upper_bk64_kernel(const float
         __syncthreads();
     }
     gemm_tile_store<1>(S, d, d, d, tm * 64, tn * 64, acc);
+    if (diag) {
+        double* part = reinterpret_cast<double*>(lds);        // [4][64]; every wave is past the loop's last barrier
+        part[wave * 64 + lane] = csum;
+        __syncthreads();
+        if (wave == 0) s[tm * 64 + lane] += ((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
+        if (tm == 0 && tid == 0) *n += (double)rows;
+    }
+}
+
+// Stand-alone column sums (shapes the fused kernel does not serve, and tise_stats_update_sum).  Grid = column tiles x
+// row slices, so d = 2048 launches 32 x 8 = 256 workgroups; a slice's partial sums go to scratch and the LAST
+// workgroup of a column tile to arrive (ticket counter) adds the slices in slice order: fixed order => reproducible.
+#define COLSUM_SLICES 8
+__global__ __launch_bounds__(256) void colsum_f32_sliced_kernel(const float* __restrict__ X, int64_t ld, int rows, int d,
+                                                                double* __restrict__ s, double* __restrict__ n,
+                                                                double* __restrict__ scratch, unsigned* __restrict__ tickets) {
+    __shared__ double part[4][64];
+    __shared__ unsigned s_last;
+    const int lc = threadIdx.x & 63, ph = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lc;
+    const int per = (rows + COLSUM_SLICES - 1) / COLSUM_SLICES;
+    const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+    double acc = 0.0;
+    if (c < d)
+        for (int r = r0 + ph; r < r1; r += 4) acc += (double)X[(int64_t)r * ld + c];
+    part[ph][lc] = acc;
+    __syncthreads();
+    if (ph == 0) scratch[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + lc] = ((part[0][lc] + part[1][lc]) + part[2][lc]) + part[3][lc];
+    __threadfence();                                          // the slice's partials are visible device-wide before the ticket
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&tickets[blockIdx.x], 1u);
+    __syncthreads();
+    if (s_last != COLSUM_SLICES - 1) return;
+    __threadfence();
+    if (ph == 0 && c < d) {
+        double t = 0.0;
+        for (int y = 0; y < COLSUM_SLICES; ++y)
+            t += scratch[((int64_t)y * gridDim.x + blockIdx.x) * 64 + lc];
+        s[c] += t;
+    }
+    if (threadIdx.x == 0) {
+        tickets[blockIdx.x] = 0;                              // ready for the next launch (stream order)
+        if (blockIdx.x == 0) *n += (double)rows;
+    }
 }
 
 // 256 threads = 64 columns x 4 row phases; fixed summation order => bitwise reproducible.
@@ -165,6 +222,11 @@ int tise_stats_create(int d, tise_stats_t** out) {
     if (e != hipSuccess) { tise_set_last_hip_error((int)e); delete h; return TISE_ERR_HIP; }
     e = hipMemset(h->buf, 0, h->n_doubles * sizeof(double));
     if (e != hipSuccess) { tise_set_last_hip_error((int)e); hipFree(h->buf); delete h; return TISE_ERR_HIP; }
+    const size_t scratch_bytes = ((size_t)8 * h->tiles * 64) * sizeof(double) + (size_t)h->tiles * sizeof(unsigned) + 64;
+    h->scratch = nullptr;
+    e = hipMalloc((void**)&h->scratch, scratch_bytes);
+    if (e == hipSuccess) e = hipMemset(h->scratch, 0, scratch_bytes);
+    if (e != hipSuccess) { tise_set_last_hip_error((int)e); hipFree(h->buf); if (h->scratch) hipFree(h->scratch); delete h; return TISE_ERR_HIP; }
     *out = h;
     return TISE_OK;
 }
@@ -172,6 +234,7 @@ int tise_stats_create(int d, tise_stats_t** out) {
 int tise_stats_destroy(tise_stats_t* h) {
     if (!h) return TISE_OK;
     hipFree(h->buf);
+    hipFree(h->scratch);
     delete h;
     return TISE_OK;
 }
@@ -193,8 +256,8 @@ int tise_stats_update_cov(tise_stats_t* h, const float* feats_dev, int64_t rows,
     const int nwg = h->tiles * (h->tiles + 1) / 2;
     const bool fast = (h->d % 64 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(feats_dev) & 15) == 0);
     if (fast)
-        hipLaunchKernelGGL(syrk_f32_upper_bk64_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, feats_dev, ld,
-                           (int)rows, h->d, h->tiles, h->buf);
+        hipLaunchKernelGGL(syrk_f32_upper_bk64_kernel<false>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, feats_dev, ld,
+                           (int)rows, h->d, h->tiles, h->buf, (double*)nullptr, (double*)nullptr);
     else
         hipLaunchKernelGGL(syrk_f32_upper_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, feats_dev, ld, (int)rows,
                            h->d, h->tiles, h->buf);
@@ -206,14 +269,31 @@ int tise_stats_update_sum(tise_stats_t* h, const float* feats_dev, int64_t rows,
     int rc = stats_check(h, feats_dev, rows, ld);
     if (rc != TISE_OK || rows == 0) return rc;
     double* s = h->buf + (size_t)h->d * h->d;
-    hipLaunchKernelGGL(colsum_f32_kernel, dim3(h->tiles), dim3(256), 0, (hipStream_t)stream, feats_dev, ld, (int)rows,
-                       h->d, s, s + h->d);
+    if (rows >= 64 * COLSUM_SLICES) {
+        unsigned* tickets = reinterpret_cast<unsigned*>(h->scratch + (size_t)COLSUM_SLICES * h->tiles * 64);
+        hipLaunchKernelGGL(colsum_f32_sliced_kernel, dim3(h->tiles, COLSUM_SLICES), dim3(256), 0, (hipStream_t)stream,
+                           feats_dev, ld, (int)rows, h->d, s, s + h->d, h->scratch, tickets);
+    } else {
+        hipLaunchKernelGGL(colsum_f32_kernel, dim3(h->tiles), dim3(256), 0, (hipStream_t)stream, feats_dev, ld, (int)rows,
+                           h->d, s, s + h->d);
+    }
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
 
 int tise_stats_update(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream) {
-    int rc = tise_stats_update_cov(h, feats_dev, rows, ld, stream);
+    int rc = stats_check(h, feats_dev, rows, ld);
+    if (rc != TISE_OK || rows == 0) return rc;
+    const bool fast = (h->d % 64 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(feats_dev) & 15) == 0);
+    if (fast) {                                               // ONE launch: covariance tiles + column sums + row count
+        const int nwg = h->tiles * (h->tiles + 1) / 2;
+        double* s = h->buf + (size_t)h->d * h->d;
+        hipLaunchKernelGGL(syrk_f32_upper_bk64_kernel<true>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, feats_dev, ld,
+                           (int)rows, h->d, h->tiles, h->buf, s, s + h->d);
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
+    rc = tise_stats_update_cov(h, feats_dev, rows, ld, stream);
     if (rc != TISE_OK) return rc;
     return tise_stats_update_sum(h, feats_dev, rows, ld, stream);
 }

@@ -289,7 +289,12 @@ def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_c
         np.savez(save_stats, mu=np.asarray(m2), sigma=np.asarray(s2))
     if not use_pf or np.shape(m1) != np.shape(m2) or np.shape(s1) != np.shape(s2):
         return calculate_frechet_distance(m1, s1, m2, s2)     # generic path (shape asserts :149-150 included)
-    res = solver.distance_prefactored(np.atleast_1d(m1), np.atleast_1d(m2), np.atleast_2d(s2))
+    try:
+        res = solver.distance_prefactored(np.atleast_1d(m1), np.atleast_1d(m2), np.atleast_2d(s2))
+    except _lib.TiseStatusError:
+        # the factor is gone: the process-wide solver of this (dims, device) served another distance / factorisation
+        # between prefactor() and here (a model's forward hook, a second thread).  The one-call form needs nothing kept.
+        return calculate_frechet_distance(m1, s1, m2, s2)
     if res["flags"] & _lib.TISE_FLAG_NONFINITE:          # :156-160 (eps retry) lives in calculate_frechet_distance
         return calculate_frechet_distance(m1, s1, m2, s2)
     calculate_frechet_distance.last_result = res
@@ -343,6 +348,7 @@ def _class_statistics(path, model, batch_size, dims, num_workers):
             idx = torch.tensor([i for i, x in enumerate(cls) if x == c], device=feats.device)
             accs[c].update(feats.index_select(0, idx))
         base += feats.shape[0]
+    engine.check_numerics()                                # split-fp16 range guard, agreed on by all ranks before the all-reduces
     for c in names:                                        # same class list on every rank (same walk)
         tdist.all_reduce_sum_(accs[c].buffer())
     return accs

@@ -265,6 +265,9 @@ class SplitTrunk(FusedTrunk):
         self.stem_w = self.c1a.w.permute(2, 3, 1, 0).contiguous().float()
         assert tuple(self.stem_w.shape) == (3, 3, 3, 32) and self.c1a.stride == (2, 2) and self.c1a.padding == (0, 0)
         self.sblocks = [(kind, {k: sc(v) for k, v in P.items()}) for kind, P in self.blocks]
+        # the two stem max-pools are taken inside the operand load of the 1x1 convolutions that consume them
+        # (Conv2d_3b; Mixed_5b's fused 1x1): conv_poolin_kernel, bit-identical to pooling first.  TISE_POOL_FUSE=0: separate kernels
+        self.fuse_pool = os.environ.get("TISE_POOL_FUSE", "1") != "0"
 
     # ---- helpers on split tensors (N, H, W, 2C) fp16 --------------------------------------------------
     @staticmethod
@@ -298,15 +301,17 @@ class SplitTrunk(FusedTrunk):
         _lib.call("tise_avgpool3_bias_relu_split_nhwc", _p(raw), c, 0, n, h, w, c, _p(bias), _p(out), out.shape[3] // 2,
                   out_off, _stream())
 
-    def _sblock_a(self, x, P):
+    def _sblock_a(self, x, P, pooled_input=False):
         n, h, w, _ = x.shape
         f = P["f"]
+        if pooled_input:                                                # x is the UN-pooled tensor (stem max-pool 2 fused)
+            h, w = f.pooled_out_hw(h, w)
         pf = f.cout - 176
         dev = x.device
         out = self._new(n, h, w, 224 + pf, dev)
         t5, t3 = self._new(n, h, w, 48, dev), self._new(n, h, w, 64, dev)
         raw = torch.empty((n, h, w, pf), dtype=torch.float32, device=dev)
-        f(x, [(0, 64, out, 0, 0), (64, 112, t5, 0, 0), (112, 176, t3, 0, 0), (176, 176 + pf, raw, 0, 1)])
+        f(x, [(0, 64, out, 0, 0), (64, 112, t5, 0, 0), (112, 176, t3, 0, 0), (176, 176 + pf, raw, 0, 1)], pooled_input=pooled_input)
         self._avgpool_split(raw, f.bias[176:176 + pf], out, 224)
         P["c5"](t5, [(0, 64, out, 64, 0)])
         t3 = self._sconv(P["d2"], t3)
@@ -399,11 +404,21 @@ class SplitTrunk(FusedTrunk):
 
     def _after_stem(self, a):
         a = self._sconv(self.s2a, a)
-        a = self._maxpool_split(self._sconv(self.s2b, a))
-        a = self._sconv(self.s3b, a)
-        a = self._maxpool_split(self._sconv(self.s4a, a))
+        a = self._sconv(self.s2b, a)
         fn = {"A": self._sblock_a, "B": self._sblock_b, "C": self._sblock_c, "D": self._sblock_d, "E": self._sblock_e}
-        for kind, P in self.sblocks:
+        if self.fuse_pool:
+            n, h, w, _ = a.shape
+            oh, ow = self.s3b.pooled_out_hw(h, w)
+            t = self._new(n, oh, ow, self.s3b.cout, a.device)
+            self.s3b(a, [(0, self.s3b.cout, t, 0, 0)], pooled_input=True)          # max-pool 1 + Conv2d_3b_1x1
+            a = self._sconv(self.s4a, t)
+            a = self._sblock_a(a, self.sblocks[0][1], pooled_input=True)           # max-pool 2 + Mixed_5b
+            rest = self.sblocks[1:]
+        else:
+            a = self._sconv(self.s3b, self._maxpool_split(a))
+            a = self._maxpool_split(self._sconv(self.s4a, a))
+            rest = self.sblocks
+        for kind, P in rest:
             a = fn[kind](a, P)
         n, h, w, c2 = a.shape                                           # merge + global average, one pass
         c = c2 // 2

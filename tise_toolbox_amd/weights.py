@@ -40,16 +40,21 @@ def warn_synthetic(what):
 def resolve(weights, synthetic, kind):
     """-> (path or None, tag).  ``None`` means seeded stand-in parameters (only with ``synthetic``)."""
     what, defaults = _KINDS[kind]
+    if synthetic:
+        # an explicit request always wins: a seeded plumbing / throughput run must not pick up a file that happens to
+        # sit in ~/.cache or the working directory on one machine and not on another
+        if weights:
+            raise RuntimeError("--synthetic-weights and --weights are mutually exclusive")
+        warn_synthetic(what)
+        return None, SYNTHETIC_TAG
     if weights:
         if not os.path.exists(weights):
             raise RuntimeError("Invalid path: %s" % weights)
         return weights, ""
     for p in defaults():
         if os.path.exists(p):
+            print(f"[tise] {what}: parameters from {p}", file=sys.stderr, flush=True)
             return p, ""
-    if synthetic:
-        warn_synthetic(what)
-        return None, SYNTHETIC_TAG
     raise RuntimeError(
         f"no parameters for {what}: the reference downloads them, this machine cannot.  Pass --weights PATH, put the "
         f"file at {defaults()[0]!r}, or pass --synthetic-weights for a plumbing/throughput run with seeded stand-ins")

@@ -24,7 +24,7 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
     pass_id = os.path.dirname(f)
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if "conv_split" not in name and "conv_win32" not in name and "conv_spec" not in name:
+        if "conv_split" not in name and "conv_win32" not in name and "conv_poolin" not in name and "conv_colwin" not in name:
             continue
         key = (pass_id, int(r["Dispatch_Id"]))
         rows[key]["name"] = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
@@ -79,7 +79,8 @@ if "FETCH_SIZE" in per_counter and "WRITE_SIZE" in per_counter:
     json.dump(pj, open(pj_path, "w"), indent=1)
 # ---- issue counters -------------------------------------------------------------------------------------------
 want = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES",
-        "GRBM_GUI_ACTIVE", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY"]
+        "GRBM_GUI_ACTIVE", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
+        "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_ADDR_CONFLICT", "SQ_ACTIVE_INST_LDS"]
 have = [c for c in want if c in per_counter]
 if have:
     agg = collections.OrderedDict()
@@ -105,12 +106,15 @@ if have:
           "* `vs clock-free peak`: the same figure is fp16-MFMA rate / (1024 SIMDs x 1024 flop/clk x the clock the chip actually ran)",
           "* `VALU:MFMA` = SQ_INSTS_VALU / SQ_INSTS_MFMA (SQ_INSTS_VALU counts the MFMAs as well)",
           "* `issue-stall` = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, `parked` = SQ_WAIT_ANY / SQ_WAVE_CYCLES", "",
-          "| kernel | launches | MFMA util | VALU:MFMA | issue-stall | parked | SQ_INSTS_MFMA |",
-          "|---|---:|---:|---:|---:|---:|---:|"]
+          "* `LDS conflict` = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (cycles the LDS spent replaying bank conflicts / cycles it was",
+          "  busy with indexed operations: ds_read / ds_write, not the LDS-DMA fills), `LDS:MFMA` = SQ_INSTS_LDS / SQ_INSTS_MFMA", "",
+          "| kernel | launches | MFMA util | VALU:MFMA | issue-stall | parked | LDS conflict | LDS:MFMA | SQ_INSTS_MFMA |",
+          "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
     for name, a in agg.items():
         md.append(f"| `{name}` | {int(a['launches'])} | {ratio(a, 'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 8.0 / 1024.0)} | "
                   f"{ratio(a, 'SQ_INSTS_VALU', 'SQ_INSTS_MFMA')} | {ratio(a, 'SQ_WAIT_INST_ANY', 'SQ_WAVE_CYCLES')} | "
-                  f"{ratio(a, 'SQ_WAIT_ANY', 'SQ_WAVE_CYCLES')} | {a.get('SQ_INSTS_MFMA', 0):.3e} |")
+                  f"{ratio(a, 'SQ_WAIT_ANY', 'SQ_WAVE_CYCLES')} | {ratio(a, 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE')} | "
+                  f"{ratio(a, 'SQ_INSTS_LDS', 'SQ_INSTS_MFMA')} | {a.get('SQ_INSTS_MFMA', 0):.3e} |")
     md += ["", "raw sums: " + ", ".join(f"{c} {tot[c]:.4e}" for c in have)]
     open(os.path.join(out_dir, f"{tag}_conv_mfma_util.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md))

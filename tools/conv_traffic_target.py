@@ -23,13 +23,13 @@ alg = []
 detail = []
 
 
-def wrapped(self, xs, segs):
-    r = orig(self, xs, segs)
+def wrapped(self, xs, segs, pooled_input=False):
+    r = orig(self, xs, segs, pooled_input=pooled_input)
     n, h, w, _ = xs.shape
     oh, ow = r
     wn = (self.w_fast if self.w_fast is not None else self.w).numel()
     alg.append(n * h * w * self.cin * 4 + n * oh * ow * self.cout * 4 + wn * 2)
-    detail.append((f"{h}x{w}x{self.cin}->{self.cout} k{self.kh}x{self.kw} s{self.stride[0]} tn{self.tn}", n * h * w * self.cin * 4,
+    detail.append((f"{h}x{w}x{self.cin}->{self.cout} k{self.kh}x{self.kw} s{self.stride[0]} tn{self.tn}" + (" maxpool-in" if pooled_input else ""), n * h * w * self.cin * 4,
                    n * oh * ow * self.cout * 4, wn * 2))
     return r
 
