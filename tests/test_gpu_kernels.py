@@ -467,12 +467,17 @@ def test_split_pool_ops(dev):
     got = SplitTrunk._maxpool_split(xs)
     want = F.max_pool2d(merge(xs).permute(0, 3, 1, 2), 3, 2).permute(0, 2, 3, 1)
     assert torch.equal(merge(got), want.contiguous())
-    raw = torch.randn((2, 9, 11, 32), generator=g).to(dev)
-    bias = torch.randn(32, generator=g).to(dev)
-    out = torch.zeros((2, 9, 11, 2 * 64), dtype=torch.float16, device=dev)
-    SplitTrunk._avgpool_split(raw, bias, out, 16)
-    want = torch.relu(F.avg_pool2d(raw.permute(0, 3, 1, 2), 3, 1, 1) + bias.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
-    assert (merge(out)[..., 16:48] - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+    # average-pool tail (column-walking kernel): the trunk's shapes, one-pixel-wide / one-row images, a slice in the middle
+    for (n, h, w, c, co, off) in [(2, 9, 11, 32, 64, 16), (3, 8, 8, 192, 2048, 1856), (2, 35, 35, 64, 288, 224), (5, 17, 17, 192, 768, 576),
+                                  (2, 1, 6, 16, 48, 32), (2, 7, 1, 8, 16, 8)]:
+        raw = torch.randn((n, h, w, c), generator=g).to(dev)
+        bias = torch.randn(c, generator=g).to(dev)
+        out = torch.zeros((n, h, w, 2 * co), dtype=torch.float16, device=dev)
+        SplitTrunk._avgpool_split(raw, bias, out, off)
+        want = torch.relu(F.avg_pool2d(raw.permute(0, 3, 1, 2), 3, 1, 1) + bias.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+        got = merge(out)
+        assert (got[..., off:off + c] - want).abs().max().item() <= 2e-6 * want.abs().max().item(), (n, h, w, c)
+        assert not torch.cat([got[..., :off], got[..., off + c:]], -1).any()
 
 
 def test_split_trunk_matches_module_graph(dev):
@@ -547,6 +552,9 @@ def test_conv_rowwin_kernel_matches_fp64_conv(dev, case):
         assert got[..., :16].abs().max().item() == 0 and got[..., 32:64].abs().max().item() == 0
         if first is None:
             first = (out.clone(), raw.clone())
+            out_g, raw_g = torch.zeros_like(out), torch.zeros_like(raw)
+            generic(xs, [(a, c, out_g if m == 0 else raw_g, off, m) for (a, c, _, off, m) in segs])
+            assert torch.equal(out, out_g) and torch.equal(raw, raw_g)
         else:
             assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
 
@@ -620,7 +628,7 @@ def test_conv_pooled_input_is_bit_identical_to_pool_then_conv(dev):
     from tise_toolbox_amd.trunk import SplitTrunk
     g = torch.Generator(device="cpu").manual_seed(33)
     for (n, H, W, Cin, Cout, segs_spec) in [(3, 147, 147, 64, 80, None), (2, 71, 71, 192, 208, (64, 112, 176, 208)),
-                                            (5, 9, 12, 32, 40, None), (1, 3, 3, 96, 256, None), (7, 20, 7, 64, 136, (8, 136))]:
+                                            (5, 9, 12, 32, 48, None), (1, 3, 3, 96, 256, None), (7, 20, 7, 64, 144, (16, 144))]:
         x = (torch.rand((n, H, W, Cin), generator=g) * 3.0)
         x[:, : H // 2, : W // 2, : Cin // 2] = 1.25                  # constant windows: ties between taps
         x = x.to(dev)
@@ -710,18 +718,22 @@ def test_conv_split_rejects_misaligned_segments(dev):
 
 @pytest.mark.parametrize("case", [(149, 149, 32, (0, 0), 3), (35, 35, 32, (1, 1), 5), (23, 23, 32, (0, 0), 3), (9, 11, 64, (1, 1), 2),
                                   (149, 149, 32, (0, 0), 40), (147, 147, 64, (1, 1), 9)])
-def test_conv_win32_sliding_window_kernel(dev, case):
-    """conv_pipe.hip, configuration 33: resident weights + sliding ring window + compute / service wave split, for the
-    32-channel 3x3 stride-1 layers.  Against fp64 (valid and padded borders, image boundaries inside tiles, one tile
-    per workgroup up to 27, tails of the grid, 64 couts = two launches, three destination segments) and bit-identical
-    over repeated runs (the hand-off between the wave groups is the new synchronisation here)."""
+@pytest.mark.parametrize("cfg", [34, 33])
+def test_conv_win32_sliding_window_kernel(dev, case, cfg):
+    """conv_pipe.hip: configuration 33 (LDS-resident weights + sliding ring window + compute / service wave split) and
+    configuration 34 (round 3: REGISTER-resident weights, all eight waves compute and finish their own tiles, 32 or 64
+    couts in one launch) for the 32-channel 3x3 stride-1 layers.  Against fp64 (valid and padded borders, image
+    boundaries inside tiles, one tile per workgroup up to 27, tails of the grid, odd tile counts, 64 couts, three
+    destination segments), bit-identical over repeated runs (ring reuse / barriers) and bit-identical to the generic
+    kernel (same K order and MFMA sequence)."""
     from tise_toolbox_amd.conv_split import SplitConv, merge, split
     H, W, Cout, pad, n = case
     g = torch.Generator(device="cpu").manual_seed(H + Cout + n)
     x = (torch.rand((n, H, W, 32), generator=g) * 3.0).to(dev)
     w = (torch.randn((Cout, 32, 3, 3), generator=g) * (2.0 / 288) ** 0.5).to(dev)
     b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
-    conv = SplitConv(w, b, (1, 1), pad, dev, variant="pipe", pipe_cfg=33)
+    conv = SplitConv(w, b, (1, 1), pad, dev, variant="pipe", pipe_cfg=cfg)
+    generic = SplitConv(w, b, (1, 1), pad, dev, variant="glds")
     oh, ow = conv.out_hw(H, W)
     ref_lin = torch.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), None, 1, pad).permute(0, 2, 3, 1)
     ref = torch.relu(ref_lin + b.double())

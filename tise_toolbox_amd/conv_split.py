@@ -124,7 +124,7 @@ def rowwin_fits(ow, kw):
 
 
 # conv_pipe.hip: configuration 33 = resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1), 32 couts per launch
-PIPE_BN = {33: 32}
+PIPE_BN = {33: 32, 34: 64}
 
 
 class SplitConv:

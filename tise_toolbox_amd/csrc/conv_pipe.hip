@@ -27,6 +27,9 @@ __device__ __attribute__((aligned(64))) unsigned char g_pipe_zero_page[64];
 
 #define CP_BK 32
 
+// a tile index beyond the grid (odd tile count, two tiles per iteration): nothing to compute or store (wave-uniform)
+__device__ __forceinline__ bool wrap_guard(long long tile, long long ntiles) { return tile < ntiles; }
+
 // ------------------------------------------------------------------------------------------------
 // Resident-weights sliding-window kernel for the two 32-channel 3x3 layers of the stem (Conv2d_2a 149^2 x 32 -> 32
 // valid, Conv2d_2b 147^2 x 32 -> 64 padded, as two 32-cout launches; 3.0 of the trunk's 21.5 conv ms).  With
@@ -231,6 +234,204 @@ __global__ __launch_bounds__(512, 1) void conv_win32_kernel(const ConvArgs p, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-resident-weights sliding-window kernel (configuration 34, round 3) for the same two layers: Conv2d_2a
+// (149^2 x 32 -> 32) and Conv2d_2b (147^2 x 32 -> 64, padded).  With Cin = 32 the whole filter of 32 couts is
+// 9 taps x 2 K-slices x (hi, lo) = 36 MFMA B-fragments = 144 VGPRs: every wave keeps the weights of ITS 32 couts in
+// registers for its whole life, so the only operand that moves is the input, once: the ring of conv_win32_kernel
+// (a tile adds the 128 grid pixels behind the previous window: 16 KB of LDS-DMA per 128-pixel tile, against 51 KB of
+// window + 72 KB of weights per tile for the row-window kernel that served Conv2d_2b, where the weight stream alone
+// kept the DMA path as busy as the matrix cores).  No weight tile in LDS also means no hand-off buffer is needed:
+// all eight waves compute AND run their own epilogue, two per SIMD, so one wave's epilogue runs under the other's MFMAs.
+//   wave w: pixel slice (w & 3) of a 128-pixel tile;  COUT = 64: group (w >> 2) owns couts 32*(w >> 2) .. +31 of the
+//   SAME tile (both groups read the same A fragments);  COUT = 32: group (w >> 2) owns tile 2*it + (w >> 2).
+// Per iteration (one barrier): DMA of the new rows two iterations ahead (2 or 4 pieces per wave), 9 taps x 6 MFMAs with
+// the next tap's A fragments requested first, `s_waitcnt vmcnt` for the rows of the next iteration, epilogue.
+// Same K order and MFMA sequence as the generic kernel => bit-identical results.  Grid-pixel tiling, border handling
+// and ring arithmetic as conv_win32_kernel above.
+template <int COUT>
+__global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, const int R16, const long long ntiles) {
+    constexpr int KHC = 3, KWC = 3, ntaps = 9;
+    constexpr int TPI = 64 / COUT;                        // tiles per iteration
+    constexpr int PF = COUT == 64 ? 2 : 1;                // the ring holds the new rows of PF iterations ahead (LDS: 160 KB)
+    constexpr int NPW = 2 * TPI;                          // 8-row DMA pieces per wave per iteration
+    constexpr int STG = conv_epi::Staging<1>::BYTES;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ms = wave & 3, grp = wave >> 2;
+    const int ring = R16 + 128 * TPI * PF;                // rows (a multiple of 16)
+    unsigned char* wbuf = lds;
+    unsigned char* epi_area = wbuf + ring * 128;
+    unsigned char* stage = epi_area + 2048 + wave * STG;
+
+    const long long G = (long long)gridDim.x;
+    const long long mgrid = (long long)p.N * p.H * p.W;
+    const int minoff = -p.PH * p.W - p.PW;
+    const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x);
+    const unsigned char* zp = g_pipe_zero_page;
+    // a workgroup walks a contiguous run of iterations (TPI tiles each)
+    const long long niter_all = (ntiles + TPI - 1) / TPI;
+    const long long per = (niter_all + G - 1) / G;
+    const long long i_begin = (long long)blockIdx.x * per, i_end = (i_begin + per < niter_all) ? i_begin + per : niter_all;
+    if (i_begin >= niter_all) return;
+    const long long t_begin = i_begin * TPI;
+    const long long g_base = t_begin * 128 + minoff;      // grid pixel of relative row 0
+    const long long nit = i_end - i_begin;
+
+    // ---- this wave's weights -> registers -------------------------------------------------------------------
+    half8_t bw[ntaps][2][2];                              // [tap][K-slice][hi / lo]
+    {
+        const _Float16* wgt = reinterpret_cast<const _Float16*>(p.w);
+        const int cout = (COUT == 64 ? grp * 32 : 0) + (lane & 31);
+        const _Float16* wrow = wgt + (long long)cout * p.Kpad + (lane >> 5) * 8;
+#pragma unroll
+        for (int t = 0; t < ntaps; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bw[t][s2][0] = *reinterpret_cast<const half8_t*>(wrow + t * CP_BK + s2 * 16);
+                bw[t][s2][1] = *reinterpret_cast<const half8_t*>(wrow + p.w_plane + t * CP_BK + s2 * 16);
+            }
+    }
+#define RW32_ROWS(REL0, NPIECES, Q0, QS)                                                                  \
+    {                                                                                                     \
+        for (int q = (Q0); q < (NPIECES); q += (QS)) {                                                     \
+            const long long rel = (REL0) + q * 8;                                                          \
+            const long long g = g_base + rel + (lane >> 3);                                                \
+            const bool ok = g >= 0 && g < mgrid;                                                           \
+            const int prow = (int)(rel % ring);                                                            \
+            const int c = (lane & 7) ^ ((((prow >> 3) & 1) << 2) | (lane >> 4));                           \
+            const unsigned char* src = xg + g * 128 + c * 16;                                              \
+            src = ok ? src : zp;                                                                           \
+            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(wbuf + prow * 128), 16, 0, 0);               \
+        }                                                                                                  \
+    }
+    // window of the first iteration and the new rows of the next PF - 1, by all eight waves
+    RW32_ROWS(0, (R16 >> 3) + 16 * TPI * (PF - 1), wave, 8)
+    {
+        conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
+        if (tid < COUT / 4) {
+            sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + 4 * tid);
+            bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + 4 * tid);
+        }
+        static_assert(conv_epi::EpiArea<COUT>::BYTES <= 2048, "epilogue area");
+        conv_epi::prepare<COUT>(p, epi_area, 0, sc_pre, bs_pre);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int lrow0 = (TPI == 2 ? grp * 128 : 0) + ms * 32 + (lane & 31) - minoff;   // window row of this lane's tile row at offset 0
+    const unsigned hw = (unsigned)(p.H * p.W);
+    for (long long it = 0; it < nit; ++it) {
+        // the new rows of iteration it + PF replace the oldest 128 TPI rows (last read before the previous barrier)
+        const bool ahead = it + PF < nit;
+        if (ahead) { RW32_ROWS((long long)R16 + (it + PF - 1) * 128 * TPI, 16 * TPI, wave, 8) }
+        const long long tile = t_begin + it * TPI + (TPI == 2 ? grp : 0);
+        unsigned tapmask = 0xffffffffu;                    // per-lane tap validity (padded convolutions)
+        if (p.PH | p.PW) {
+            const unsigned g = (unsigned)(tile * 128) + ms * 32 + (lane & 31);        // grid pixels < 2^31 (launcher)
+            const unsigned rem = g % hw;
+            const int y = (int)(rem / (unsigned)p.W), x = (int)rem - y * p.W;
+            tapmask = 0u;
+#pragma unroll
+            for (int t = 0; t < ntaps; ++t) {
+                const int yy = y + t / KWC - p.PH, xx = x + t % KWC - p.PW;
+                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) tapmask |= 1u << t;
+            }
+        }
+        float16_t acc_main[1][1], acc_corr[1][1];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc_main[0][0][j] = 0.f; acc_corr[0][0][j] = 0.f; }
+        const int wstart = (int)((it * 128 * TPI) % ring);     // physical row of this iteration's window row 0
+        half8_t fa_[2][2][2];
+#define RW32_READS(TAP, BUF)                                                                              \
+        {                                                                                                  \
+            const int kh_ = (TAP) / KWC, kw_ = (TAP) % KWC;                                                \
+            int wrow = wstart + lrow0 + (kh_ - p.PH) * p.W + (kw_ - p.PW);                                 \
+            wrow = wrow >= ring ? wrow - ring : wrow;                                                      \
+            const int aswz = (wrow >> 1) & 7;                                                              \
+            const unsigned char* ap = wbuf + wrow * 128;                                                   \
+            const unsigned am = (tapmask >> (TAP)) & 1u ? 0xffffffffu : 0u;                                \
+            _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                             \
+                const int ao = ((2 * s2 + (lane >> 5)) ^ aswz) * 16;                                       \
+                u32x4_t ah = *reinterpret_cast<const u32x4_t*>(ap + ao);                                   \
+                u32x4_t al = *reinterpret_cast<const u32x4_t*>(ap + (ao ^ 64));                            \
+                ah &= am; al &= am;                                                                        \
+                fa_[BUF][s2][0] = __builtin_bit_cast(half8_t, ah);                                         \
+                fa_[BUF][s2][1] = __builtin_bit_cast(half8_t, al);                                         \
+            }                                                                                              \
+        }
+#define RW32_MFMAS(TAP, BUF)                                                                              \
+        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                 \
+            acc_corr[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[TAP][s2][1], fa_[BUF][s2][0], acc_corr[0][0], 0, 0, 0); \
+            acc_main[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[TAP][s2][0], fa_[BUF][s2][0], acc_main[0][0], 0, 0, 0); \
+            acc_corr[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[TAP][s2][0], fa_[BUF][s2][1], acc_corr[0][0], 0, 0, 0); \
+        }
+        if (wrap_guard(tile, ntiles)) {
+            RW32_READS(0, 0)
+#pragma unroll
+            for (int tap = 0; tap < ntaps; ++tap) {
+                if (tap + 1 < ntaps) {
+                    if ((tap + 1) & 1) { RW32_READS(tap + 1, 1) } else { RW32_READS(tap + 1, 0) }
+                }
+                if (tap & 1) { RW32_MFMAS(tap, 1) } else { RW32_MFMAS(tap, 0) }
+            }
+        }
+        // the rows of the next iteration have landed.  PF = 2: they were issued one iteration ago and only this
+        // iteration's DMA is younger;  PF = 1: they are this iteration's DMA (issued before the taps above)
+        if (PF == 2 && ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wrap_guard(tile, ntiles))
+            conv_epi::store_tiles_desc<1, 1, true, COUT>(p, acc_main, acc_corr, stage, epi_area, tile * 128 + ms * 32,
+                                                         COUT == 64 ? grp * 4 : 0);
+        __syncthreads();
+    }
+#undef RW32_ROWS
+#undef RW32_READS
+#undef RW32_MFMAS
+}
+
+int launch_regw32(const ConvArgs* a, hipStream_t st) {
+    if (a->Cin != 32 || a->SH != 1 || a->SW != 1 || a->KH != 3 || a->KW != 3 || a->Kpad != 9 * 32 || a->W < 8 ||
+        (a->Cout != 32 && a->Cout != 64) || (long long)a->N * a->H * a->W >= 0x7fffff00LL)
+        return TISE_ERR_INVALID_ARG;
+    const int tpi = 64 / a->Cout;
+    const int R = 128 * tpi + 2 * a->W + 2;
+    const int R16 = (R + 15) & ~15;
+    const int pf = a->Cout == 64 ? 2 : 1;
+    const size_t lds = (size_t)(R16 + 128 * tpi * pf) * 128 + 2048 + 8 * (size_t)conv_epi::Staging<1>::BYTES;
+    if (lds > 160 * 1024) return TISE_ERR_UNSUPPORTED;
+    static std::atomic<unsigned long long> attr_set32{0}, attr_set64{0};
+    if (a->Cout == 32) {
+        if (tise_first_use_on_this_device(attr_set32))
+            TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_regw32_kernel<32>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    } else {
+        if (tise_first_use_on_this_device(attr_set64))
+            TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_regw32_kernel<64>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    }
+    const long long mg = (long long)a->N * a->H * a->W;
+    const long long ntiles = (mg + 127) / 128;
+    int dev = 0, ncu = 256;
+    hipDeviceProp_t prop;
+    TISE_HIP_CHECK(hipGetDevice(&dev));
+    static int ncu_cached = 0;
+    if (ncu_cached == 0) {
+        TISE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        ncu_cached = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    ncu = ncu_cached;
+    const long long niter = (ntiles + tpi - 1) / tpi;
+    const long long grid = niter < ncu ? niter : ncu;
+    if (a->Cout == 32)
+        hipLaunchKernelGGL((conv_regw32_kernel<32>), dim3((unsigned)grid), dim3(512), lds, st, *a, R16, ntiles);
+    else
+        hipLaunchKernelGGL((conv_regw32_kernel<64>), dim3((unsigned)grid), dim3(512), lds, st, *a, R16, ntiles);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
 int launch_win32(const ConvArgs* a, hipStream_t st) {
     if (a->Cin != 32 || a->SH != 1 || a->SW != 1 || a->KH != 3 || a->KW != 3 || a->Kpad != 9 * 32 || a->W < 8 ||
         (long long)a->N * a->H * a->W >= 0x7fffff00LL)
@@ -266,8 +467,10 @@ int launch_win32(const ConvArgs* a, hipStream_t st) {
 
 }  // namespace
 
-// cfg 33: resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; 32 couts per launch).
+// cfg 33: LDS-resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; 32 couts per launch).
+// cfg 34: register-resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; Cout = 32 or 64, one launch).
 int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream) {
+    if (cfg == 34) return launch_regw32(a, (hipStream_t)stream);
     if (cfg != 33) return TISE_ERR_INVALID_ARG;
     return launch_win32(a, (hipStream_t)stream);
 }

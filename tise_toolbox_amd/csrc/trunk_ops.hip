@@ -20,6 +20,7 @@
 // All are float4-vectorised along the channel dimension (every channel count / offset in the
 // network is a multiple of 16).  Algorithmic bytes: one read + one write of the tensor (+8 neighbour
 // reads served by L2 for the pools).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -157,6 +158,69 @@ __global__ __launch_bounds__(256) void avgpool3_bias_relu_split_kernel(const flo
         *reinterpret_cast<half8v*>(d) = hi;
         *reinterpret_cast<half8v*>(d + tise_ilv_second(ch, out_C)) = lo;
     }
+}
+
+// Column-walking form of the kernel above (round 3; the default): thread = (image, column x, 8 channels) walks DOWN the
+// H rows keeping the horizontal 3-tap sums of the last three rows in registers, so an output costs 3 new taps (6 x 16-byte
+// loads) instead of 9 (18 loads), and the index arithmetic is 32-bit and done once per thread, not per output
+// (the per-output form reached 2.6-3.3 TB/s of algorithmic bytes: bound by its 18 loads and 64-bit divisions, not by
+// HBM).  Summation order per channel: ((left + centre) + right) per row, then (above + this) + below.
+__global__ __launch_bounds__(256) void avgpool3_bias_relu_split_colwalk_kernel(const float* __restrict__ x, int x_ld, int x_off,
+                                                                               int N, int H, int W, int C8,
+                                                                               const float* __restrict__ bias,
+                                                                               _Float16* __restrict__ out, int out_C, int out_off) {
+    const unsigned total = (unsigned)N * (unsigned)W * (unsigned)C8;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= total) return;
+    const unsigned c8 = e % (unsigned)C8;
+    const unsigned col = e / (unsigned)C8;
+    const unsigned w = col % (unsigned)W, n = col / (unsigned)W;
+    const bool hasl = w > 0, hasr = w + 1 < (unsigned)W;
+    const float* base = x + ((size_t)n * H * W + w) * (size_t)x_ld + x_off + 8 * c8;
+    const size_t rstride = (size_t)W * x_ld;
+    const float4 b0 = *reinterpret_cast<const float4*>(bias + 8 * c8), b1 = *reinterpret_cast<const float4*>(bias + 8 * c8 + 4);
+    const int ch = out_off + 8 * (int)c8;
+    _Float16* obase = out + ((size_t)n * H * W + w) * (size_t)(2 * out_C) + tise_ilv_off(ch, out_C);
+    const int osecond = tise_ilv_second(ch, out_C);
+    const size_t ostride = (size_t)W * 2 * out_C;
+    float hs[3][8];                                           // horizontal sums of rows y - 1, y, y + 1 (rotating)
+#define AP_HSUM(DST, ROW)                                                                                  \
+    {                                                                                                      \
+        const float4* q = reinterpret_cast<const float4*>(base + (size_t)(ROW) * rstride);                  \
+        const float4 c0 = q[0], c1 = q[1];                                                                  \
+        float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0, r0 = l0, r1 = l0;                             \
+        if (hasl) { const float4* ql = reinterpret_cast<const float4*>(base + (size_t)(ROW) * rstride - x_ld); l0 = ql[0]; l1 = ql[1]; } \
+        if (hasr) { const float4* qr = reinterpret_cast<const float4*>(base + (size_t)(ROW) * rstride + x_ld); r0 = qr[0]; r1 = qr[1]; } \
+        DST[0] = (l0.x + c0.x) + r0.x; DST[1] = (l0.y + c0.y) + r0.y; DST[2] = (l0.z + c0.z) + r0.z; DST[3] = (l0.w + c0.w) + r0.w; \
+        DST[4] = (l1.x + c1.x) + r1.x; DST[5] = (l1.y + c1.y) + r1.y; DST[6] = (l1.z + c1.z) + r1.z; DST[7] = (l1.w + c1.w) + r1.w; \
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hs[0][i] = 0.f;               // the row above the image
+    AP_HSUM(hs[1], 0)
+    float vmax = 0.f;
+    for (int y = 0; y < H; ++y) {
+        if (y + 1 < H) { AP_HSUM(hs[2], y + 1) }
+        else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) hs[2][i] = 0.f;
+        }
+        const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        half8v hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float v = fmaxf(((hs[0][i] + hs[1][i]) + hs[2][i]) / 9.f + bs[i], 0.f);      // count_include_pad=True: always / 9
+            vmax = fmaxf(vmax, v);
+            hi[i] = (_Float16)v;
+            lo[i] = (_Float16)((v - (float)hi[i]) * 2048.f);
+        }
+        _Float16* d = obase + (size_t)y * ostride;
+        *reinterpret_cast<half8v*>(d) = hi;
+        *reinterpret_cast<half8v*>(d + osecond) = lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { hs[0][i] = hs[1][i]; hs[1][i] = hs[2][i]; }
+    }
+#undef AP_HSUM
+    tise_flag_split_overflow(vmax);
 }
 
 // split tensor -> 3x3 / stride 2 max pool -> split tensor slice (8 channels = 2 x 16 B per thread).  The value
@@ -435,9 +499,16 @@ int tise_avgpool3_bias_relu_split_nhwc(const float* x_dev, int64_t x_ld, int x_o
         (reinterpret_cast<uintptr_t>(bias_dev) & 15) != 0)
         return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
-    hipLaunchKernelGGL(avgpool3_bias_relu_split_kernel, dim3(grid_for((int64_t)n * h * w * (C / 8))), dim3(256), 0,
-                       (hipStream_t)stream, x_dev, x_ld, x_off, n, h, w, C / 8, bias_dev,
-                       reinterpret_cast<_Float16*>(out_dev), (int)out_ld, out_off);
+    const int64_t cols = (int64_t)n * w * (C / 8);
+    static const bool per_output = getenv("TISE_AVGPOOL_PER_OUTPUT") != nullptr;      // A/B switch: round 2's kernel
+    if (!per_output && cols < 0x7fffff00LL && x_ld < 0x7fffffffLL && (reinterpret_cast<uintptr_t>(x_dev) & 15) == 0)
+        hipLaunchKernelGGL(avgpool3_bias_relu_split_colwalk_kernel, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0,
+                           (hipStream_t)stream, x_dev, (int)x_ld, x_off, n, h, w, C / 8, bias_dev,
+                           reinterpret_cast<_Float16*>(out_dev), (int)out_ld, out_off);
+    else
+        hipLaunchKernelGGL(avgpool3_bias_relu_split_kernel, dim3(grid_for((int64_t)n * h * w * (C / 8))), dim3(256), 0,
+                           (hipStream_t)stream, x_dev, x_ld, x_off, n, h, w, C / 8, bias_dev,
+                           reinterpret_cast<_Float16*>(out_dev), (int)out_ld, out_off);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }

@@ -257,10 +257,15 @@ class SplitTrunk(FusedTrunk):
             return SplitConv(c.w, c.b, c.stride, c.padding, self.device)
 
         self.s2a, self.s2b, self.s3b, self.s4a = sc(self.c2a), sc(self.c2b), sc(self.c3b), sc(self.c4a)
-        # Conv2d_2a (149^2 x 32 -> 32, 3x3): resident-weights sliding-window kernel (conv_pipe.hip configuration 33),
-        # 1.05 vs 1.34 ms at batch 500; for the 64-cout Conv2d_2b it needs two launches and only ties (1.96 vs 1.90)
+        # Conv2d_2a (149^2 x 32 -> 32) and Conv2d_2b (147^2 x 32 -> 64, padded): Cin = 32 means a wave can hold the whole
+        # filter of 32 couts in registers (conv_pipe.hip configuration 34): the input streams through a sliding LDS ring
+        # once, nothing else moves.  TISE_CONV_REGW=0: round 2's kernels (configuration 33 for 2a, row window for 2b)
         if os.environ.get("TISE_CONV_VARIANT", "auto") in ("auto", "fast") and os.environ.get("TISE_CONV_WIN32", "1") != "0":
-            self.s2a = SplitConv(self.c2a.w, self.c2a.b, self.c2a.stride, self.c2a.padding, self.device, variant="pipe", pipe_cfg=33)
+            regw = os.environ.get("TISE_CONV_REGW", "1") != "0"
+            self.s2a = SplitConv(self.c2a.w, self.c2a.b, self.c2a.stride, self.c2a.padding, self.device, variant="pipe",
+                                 pipe_cfg=34 if regw else 33)
+            if regw:
+                self.s2b = SplitConv(self.c2b.w, self.c2b.b, self.c2b.stride, self.c2b.padding, self.device, variant="pipe", pipe_cfg=34)
         # stem weights for the direct kernel: [kh][kw][cin][cout] fp32
         self.stem_w = self.c1a.w.permute(2, 3, 1, 0).contiguous().float()
         assert tuple(self.stem_w.shape) == (3, 3, 3, 32) and self.c1a.stride == (2, 2) and self.c1a.padding == (0, 0)

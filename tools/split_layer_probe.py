@@ -22,14 +22,15 @@ orig = SplitConv.__call__
 recs = []
 
 
-def wrapped(self, xs, segs):
+def wrapped(self, xs, segs, pooled_input=False):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    r = orig(self, xs, segs)
+    r = orig(self, xs, segs, pooled_input=pooled_input)
     e1.record()
     n, h, w, _ = xs.shape
     oh, ow = r
-    recs.append((e0, e1, f"{h}x{w}x{self.cin}->{self.cout} k{self.kh}x{self.kw} s{self.stride[0]} tn{self.tn}",
+    kind = "maxpool-in" if pooled_input else (f"pipe{self.pipe_cfg}" if self.pipe_cfg is not None else self.variant)
+    recs.append((e0, e1, f"{h}x{w}x{self.cin}->{self.cout} k{self.kh}x{self.kw} s{self.stride[0]} tn{self.tn} {kind}",
                  2.0 * n * oh * ow * self.cout * self.k))
     return r
 
@@ -45,4 +46,4 @@ for ms, name, fl in rows:
     a = agg.setdefault(name, [0.0, 0, 0.0])
     a[0] += ms; a[1] += 1; a[2] += fl
 for name, (ms, cnt, fl) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
-    print(f"{name:36s} x{cnt}  {ms:7.3f} ms ({100*ms/tot:4.1f}%)  {3*fl/ms/1e9:5.0f} TF16")
+    print(f"{name:48s} x{cnt}  {ms:7.3f} ms ({100*ms/tot:4.1f}%)  {3*fl/ms/1e9:5.0f} TF16")

@@ -23,7 +23,7 @@ def short(name):
 
 MINE = ("syrk_f32", "colsum", "stats_finalize", "resize_bilinear", "is_row", "is_col", "is_final", "pchol", "sytrd",
         "bisect", "gershgorin", "gemm_f64", "symmetrize", "frechet_finish", "axpy", "zero_rows", "bias_relu",
-        "avgpool", "maxpool", "tise_", "conv_split", "conv_pipe", "stem_conv", "split_mean")
+        "avgpool", "maxpool", "tise_", "conv_split", "conv_pipe", "conv_win32", "conv_regw32", "conv_poolin", "stem_conv", "split_mean")
 
 
 def main():
