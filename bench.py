@@ -237,6 +237,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline AND parity (both need the CPU oracle)")
     ap.add_argument("--cpu-sample", type=int, default=250, help="images of the timed set the CPU oracle processes")
     ap.add_argument("--no-cross-check", action="store_true")
+    ap.add_argument("--no-kernel-probe", action="store_true", help="skip the stand-alone timing of the HBM-bound kernels after the timed region")
     ap.add_argument("--channels-last", type=int, default=-1)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -409,7 +410,8 @@ def main():
                 "launches_per_batch": n_launch / timed_steps, "algorithmic_flop_per_batch": conv_flop / timed_steps,
                 "batches_with_events": timed_steps,
                 "mfma_tflops_f16": 3.0 * conv_flop / (conv_ms * 1e-3) / 1e12, "mfma_peak_f16": PEAK_F16_MFMA_TFLOPS}
-        kern.update(hbm_kernel_probe(eng, data[chunks[0][0]:chunks[0][1]], dev))
+        if not args.no_kernel_probe:
+            kern.update(hbm_kernel_probe(eng, data[chunks[0][0]:chunks[0][1]], dev))
         for k in kern.values():
             k["frac"] = k["achieved"] / k["peak"]
         traffic, traffic_src = None, None

@@ -757,6 +757,72 @@ def test_conv_win32_sliding_window_kernel(dev, case, cfg):
             assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
 
 
+def test_conv_sliding_window_writes_into_a_zero_bordered_buffer(dev):
+    """args->out_hp (round 3): Conv2d_2a writes its result into the interior of a zero-bordered buffer and the padded
+    Conv2d_2b runs as a VALID convolution over it (no tap masks).  (i) the interior equals the plain output bit for
+    bit and the border is untouched; (ii) valid conv over the bordered buffer == padded conv over the plain tensor,
+    bit for bit (the masked taps contributed exact zeros); (iii) the trunk with and without the buffer agrees bit for
+    bit; (iv) kernels without a grid epilogue refuse the offset form."""
+    from tise_toolbox_amd import _lib
+    from tise_toolbox_amd.conv_split import SplitConv, split
+    from tise_toolbox_amd.inception import InceptionV3
+    from tise_toolbox_amd.trunk import SplitTrunk
+    g = torch.Generator(device="cpu").manual_seed(77)
+    for (n, H, W) in [(3, 29, 31), (2, 149, 149)]:
+        x = (torch.rand((n, H, W, 32), generator=g) * 3.0).to(dev)
+        w1 = (torch.randn((32, 32, 3, 3), generator=g) * (2.0 / 288) ** 0.5).to(dev)
+        w2 = (torch.randn((64, 32, 3, 3), generator=g) * (2.0 / 288) ** 0.5).to(dev)
+        b1, b2 = (torch.randn(32, generator=g) * 0.2).to(dev), (torch.randn(64, generator=g) * 0.2).to(dev)
+        xs = split(x)
+        c1 = SplitConv(w1, b1, (1, 1), (0, 0), dev, variant="pipe", pipe_cfg=34)
+        oh, ow = c1.out_hw(H, W)
+        plain = torch.empty((n, oh, ow, 64), dtype=torch.float16, device=dev)
+        c1(xs, [(0, 32, plain, 0, 0)])
+        buf = torch.full((n, oh + 2, ow + 2, 64), 9.0, dtype=torch.float16, device=dev)
+        c1(xs, [(0, 32, buf, 0, 0)], out_pad=(oh + 2, ow + 2, 1, 1))
+        assert torch.equal(buf[:, 1:-1, 1:-1], plain)
+        border = buf.clone(); border[:, 1:-1, 1:-1] = 9.0
+        assert (border == 9.0).all()
+        buf[:, 0] = 0; buf[:, -1] = 0; buf[:, :, 0] = 0; buf[:, :, -1] = 0
+        padded = SplitConv(w2, b2, (1, 1), (1, 1), dev, variant="pipe", pipe_cfg=34)
+        valid = SplitConv(w2, b2, (1, 1), (0, 0), dev, variant="pipe", pipe_cfg=34)
+        o1 = torch.empty((n, oh, ow, 128), dtype=torch.float16, device=dev)
+        o2 = torch.empty_like(o1)
+        padded(plain, [(0, 64, o1, 0, 0)])
+        valid(buf, [(0, 64, o2, 0, 0)])
+        assert torch.equal(o1, o2)
+        fast = SplitConv(w1, b1, (1, 1), (0, 0), dev, variant="fast")
+        with pytest.raises(_lib.TiseStatusError):
+            _raw_out_pad_call(fast, xs, buf, oh, ow)
+    m = InceptionV3([3], seed=0).to(dev).eval()
+    x = torch.rand((3, 3, 299, 299), device=dev).contiguous(memory_format=torch.channels_last)
+    with_buf = SplitTrunk(m, dev)
+    assert with_buf.pad2b
+    os.environ["TISE_CONV_PADBUF"] = "0"
+    try:
+        without = SplitTrunk(m, dev)
+    finally:
+        del os.environ["TISE_CONV_PADBUF"]
+    assert not without.pad2b
+    a, b = with_buf(x).clone(), without(x).clone()
+    assert torch.equal(a, b) and torch.equal(with_buf(x), a)            # second call reuses the persistent buffer
+
+
+def _raw_out_pad_call(conv, xs, buf, oh, ow):
+    """SplitConv refuses out_pad for non-sliding-window variants in Python; go through the C-ABI to see the library refuse it."""
+    import ctypes
+    from tise_toolbox_amd import _lib
+    from tise_toolbox_amd.conv_split import ConvArgs
+    n, h, w, _ = xs.shape
+    a = ConvArgs()
+    a.x = xs.data_ptr(); a.w = conv.w_fast.data_ptr(); a.scale = conv.scale.data_ptr(); a.bias = conv.bias.data_ptr()
+    a.N, a.H, a.W, a.Cin, a.KH, a.KW, a.SH, a.SW, a.PH, a.PW, a.OH, a.OW = n, h, w, 32, 3, 3, 1, 1, 0, 0, oh, ow
+    a.Cout, a.K, a.Kpad, a.M, a.nseg = conv.cout, conv.k, conv.kpad, n * oh * ow, 1
+    a.seg[0].c0, a.seg[0].c1, a.seg[0].dst, a.seg[0].ld, a.seg[0].off, a.seg[0].mode = 0, conv.cout, buf.data_ptr(), 32, 0, 0
+    a.out_hp, a.out_wp, a.out_y0, a.out_x0 = oh + 2, ow + 2, 1, 1
+    _lib.call("tise_conv_split_f16", ctypes.byref(a), conv.tn | 128, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
 # ------------------------------------------------------------------------------------------- split format: range
 @pytest.mark.parametrize("case", [(17, 17, 192, 224, 1, 7, (0, 3)), (35, 35, 64, 96, 3, 3, (1, 1)), (8, 8, 448, 384, 3, 3, (1, 1)),
                                   (73, 73, 80, 192, 3, 3, (0, 0)), (17, 17, 768, 704, 1, 1, (0, 0))])

@@ -30,7 +30,8 @@ class ConvArgs(ctypes.Structure):
                 ("KH", ctypes.c_int), ("KW", ctypes.c_int), ("SH", ctypes.c_int), ("SW", ctypes.c_int),
                 ("PH", ctypes.c_int), ("PW", ctypes.c_int), ("OH", ctypes.c_int), ("OW", ctypes.c_int),
                 ("Cout", ctypes.c_int), ("K", ctypes.c_int), ("Kpad", ctypes.c_int), ("M", ctypes.c_longlong),
-                ("nseg", ctypes.c_int), ("seg", ConvSeg * 4)]
+                ("nseg", ctypes.c_int), ("seg", ConvSeg * 4),
+                ("out_hp", ctypes.c_int), ("out_wp", ctypes.c_int), ("out_y0", ctypes.c_int), ("out_x0", ctypes.c_int)]
 
 
 def split_planes(x):
@@ -219,11 +220,13 @@ class SplitConv:
         """Output grid of ``__call__(..., pooled_input=True)``: max_pool2d(3, stride 2) of the input, then this 1x1 conv."""
         return (h - 3) // 2 + 1, (w - 3) // 2 + 1
 
-    def __call__(self, x, segs, pooled_input=False):
+    def __call__(self, x, segs, pooled_input=False, out_pad=None):
         """x: split tensor (N, H, W, 2*Cin) fp16.  segs: list of (c0, c1, dst_tensor, dst_off, mode):
         mode 0 -> dst is a split tensor (N, OH, OW, 2*C), mode 1 -> dst is a (N, OH, OW, C) fp32 tensor.
         ``pooled_input``: the convolution (1x1, Cin % 32 == 0, default packing) reads max_pool2d(x, 3, stride 2) -- the
-        pool is taken while loading the operand (conv_poolin_kernel), bit-identical to pooling first."""
+        pool is taken while loading the operand (conv_poolin_kernel), bit-identical to pooling first.
+        ``out_pad`` = (hp, wp, y0, x0) (sliding-window kernels only): the destination tensors are (N, hp, wp, ...) images
+        and the (OH, OW) result is written at offset (y0, x0) inside them (the rest is left untouched)."""
         assert x.dtype == torch.float16 and x.dim() == 4 and x.shape[3] == 2 * self.cin and x.is_contiguous()
         n, h, w, _ = x.shape
         oh, ow = self.out_hw(h, w)
@@ -248,15 +251,21 @@ class SplitConv:
         a.Cout, a.K, a.Kpad = self.cout, self.k, self.kpad
         a.M = n * oh * ow
         a.nseg = len(segs) | getattr(self, "debug_flags", 0)
+        dshape = (n, oh, ow)
+        if out_pad is not None:
+            hp, wp, y0, x0 = out_pad
+            assert self.pipe_cfg is not None and not pooled_input and y0 + oh <= hp and x0 + ow <= wp and min(y0, x0) >= 0
+            a.out_hp, a.out_wp, a.out_y0, a.out_x0 = hp, wp, y0, x0
+            dshape = (n, hp, wp)
         for i, (c0, c1, dst, off, mode) in enumerate(segs):
             s = a.seg[i]
             s.c0, s.c1, s.off, s.mode = c0, c1, off, mode
             s.dst = dst.data_ptr()
             if mode == 0:
-                assert dst.dtype == torch.float16 and dst.shape[:3] == (n, oh, ow) and dst.is_contiguous()
+                assert dst.dtype == torch.float16 and dst.shape[:3] == dshape and dst.is_contiguous()
                 s.ld = dst.shape[3] // 2
             else:
-                assert dst.dtype == torch.float32 and dst.shape[:3] == (n, oh, ow) and dst.is_contiguous()
+                assert dst.dtype == torch.float32 and dst.shape[:3] == dshape and dst.is_contiguous()
                 s.ld = dst.shape[3]
         if getattr(self, "debug_ptr", None):                    # tools/conv_stamps.py
             a.seg[3].dst = self.debug_ptr

@@ -95,6 +95,7 @@ __device__ __forceinline__ void prepare(const tise_conv_args& p, unsigned char* 
         ChunkDesc d;
         d.base = (long long)reinterpret_cast<unsigned char*>(sd_) + (smode == 0 ? tise_ilv_off(ch, (int)sl_) * 2 : ch * 4);
         d.row_stride = sl_ * 4;                                // split pixel = 4*C bytes, the same as fp32
+        if (p.out_hp) d.base += ((long long)p.out_y0 * p.out_wp + p.out_x0) * d.row_stride;      // result at an offset inside a larger image (GRID kernels)
         d.second = smode == 0 ? tise_ilv_second(ch, (int)sl_) * 2 : 16;
         d.mode = smode;
         d.valid = col < p.Cout ? 1 : 0;
@@ -107,10 +108,12 @@ __device__ __forceinline__ void prepare(const tise_conv_args& p, unsigned char* 
 // from two 32-bit divisions and is stepped forward per pass (grid pixel counts < 2^31: launcher).
 // BN_AREA: tile width the descriptor area was prepared for (default: this wave's TNW tiles are the whole tile);
 // chunk0: first 8-cout chunk of this wave inside the tile (wave layouts with more than one wave along the couts).
+// nyx (GRID only): {n, y, x} of grid pixel m0w + (lane / lanes-per-row), when the caller tracks it incrementally.
 template <int TNW, int TW, bool GRID = false, int BN_AREA = 32 * TNW>
 __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float16_t (&acc_main)[1][TNW],
                                                  float16_t (&acc_corr)[1][TNW], unsigned char* tw,
-                                                 const unsigned char* area, long long m0w, int chunk0 = 0) {
+                                                 const unsigned char* area, long long m0w, int chunk0 = 0,
+                                                 const unsigned* nyx = nullptr) {
     constexpr int BN = BN_AREA;
     constexpr int PITCH = Staging<TW>::PITCH;
     const int lane = threadIdx.x & 63;
@@ -169,19 +172,25 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float1
                 d += step;
             }
         } else {
-            const unsigned g0 = (unsigned)(m0w + row0);
-            const unsigned hw = (unsigned)(p.H * p.W);
-            unsigned n = g0 / hw;
-            const unsigned rem = g0 - n * hw;
-            unsigned y = rem / (unsigned)p.W, x = rem - y * (unsigned)p.W;
+            // (n, y, x) of grid pixel m0w + row0: two 32-bit divisions, or handed in by a kernel that tracks them
+            unsigned n, y, x;
+            if (nyx) { n = nyx[0]; y = nyx[1]; x = nyx[2]; }
+            else {
+                const unsigned g0 = (unsigned)(m0w + row0);
+                const unsigned hw = (unsigned)(p.H * p.W);
+                n = g0 / hw;
+                const unsigned rem = g0 - n * hw;
+                y = rem / (unsigned)p.W; x = rem - y * (unsigned)p.W;
+            }
             const long long half_off = (q & 1) ? cd.second : 0;
+            const int ohp = p.out_hp ? p.out_hp : p.OH, owp = p.out_hp ? p.out_wp : p.OW;      // destination image pitch
 #pragma unroll
             for (int r4 = 0; r4 < 32 * TW / 8; ++r4) {
                 if (r4 * rows_per_pass >= 32) continue;
                 const u32x4_t val = *reinterpret_cast<const u32x4_t*>(src + r4 * rows_per_pass * PITCH);
                 const bool ok = cd.valid && row0 + r4 * rows_per_pass < rows_ok && y < (unsigned)p.OH && x < (unsigned)p.OW;
                 if (ok) {
-                    const long long pp = ((long long)n * p.OH + y) * p.OW + x;
+                    const long long pp = ((long long)n * ohp + y) * owp + x;
                     *reinterpret_cast<u32x4_t*>(cd.base + pp * cd.row_stride + half_off) = val;
                 }
                 x += rows_per_pass;                               // next pass: rows_per_pass grid pixels further (W >= 8)

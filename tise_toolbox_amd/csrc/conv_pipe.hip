@@ -249,18 +249,23 @@ __global__ __launch_bounds__(512, 1) void conv_win32_kernel(const ConvArgs p, co
 // the next tap's A fragments requested first, `s_waitcnt vmcnt` for the rows of the next iteration, epilogue.
 // Same K order and MFMA sequence as the generic kernel => bit-identical results.  Grid-pixel tiling, border handling
 // and ring arithmetic as conv_win32_kernel above.
-template <int COUT>
+// Instruction diet (profiles/r03d_conv_mfma_util.md: the first version ran at VALU:MFMA 13, MFMA util 0.33 -- bound by
+// vector issue, not by the matrix cores or the DMA): tap masks only in the PADDED instance (Conv2d_2b runs UNPADDED on a
+// zero-bordered copy of its input, which Conv2d_2a writes directly: args->out_hp), ring positions and the (n, y, x) of a
+// lane's pixels advanced incrementally (no division in the loop), four fragment addresses per tap from one.
+template <int COUT, bool PADDED>
 __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, const int R16, const long long ntiles) {
     constexpr int KHC = 3, KWC = 3, ntaps = 9;
     constexpr int TPI = 64 / COUT;                        // tiles per iteration
     constexpr int PF = COUT == 64 ? 2 : 1;                // the ring holds the new rows of PF iterations ahead (LDS: 160 KB)
     constexpr int NPW = 2 * TPI;                          // 8-row DMA pieces per wave per iteration
+    constexpr int STEP = 128 * TPI;                       // grid pixels per iteration
     constexpr int STG = conv_epi::Staging<1>::BYTES;
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ms = wave & 3, grp = wave >> 2;
-    const int ring = R16 + 128 * TPI * PF;                // rows (a multiple of 16)
+    const int ring = R16 + STEP * PF;                     // rows (a multiple of 16)
     unsigned char* wbuf = lds;
     unsigned char* epi_area = wbuf + ring * 128;
     unsigned char* stage = epi_area + 2048 + wave * STG;
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
     if (i_begin >= niter_all) return;
     const long long t_begin = i_begin * TPI;
     const long long g_base = t_begin * 128 + minoff;      // grid pixel of relative row 0
-    const long long nit = i_end - i_begin;
+    const int nit = (int)(i_end - i_begin);
 
     // ---- this wave's weights -> registers -------------------------------------------------------------------
     half8_t bw[ntaps][2][2];                              // [tap][K-slice][hi / lo]
@@ -293,13 +298,15 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
                 bw[t][s2][1] = *reinterpret_cast<const half8_t*>(wrow + p.w_plane + t * CP_BK + s2 * 16);
             }
     }
-#define RW32_ROWS(REL0, NPIECES, Q0, QS)                                                                  \
+// DMA of the 8-row pieces Q0, Q0 + QS, ... < NPIECES of the rows that start at relative row REL0 (a long long), whose
+// physical ring row is PROW0 (< ring; REL0 mod ring, kept incrementally by the caller)
+#define RW32_ROWS(REL0, PROW0, NPIECES, Q0, QS)                                                           \
     {                                                                                                     \
         for (int q = (Q0); q < (NPIECES); q += (QS)) {                                                     \
-            const long long rel = (REL0) + q * 8;                                                          \
-            const long long g = g_base + rel + (lane >> 3);                                                \
+            const long long g = g_base + (REL0) + q * 8 + (lane >> 3);                                     \
             const bool ok = g >= 0 && g < mgrid;                                                           \
-            const int prow = (int)(rel % ring);                                                            \
+            int prow = (PROW0) + q * 8;                                                                    \
+            while (prow >= ring) prow -= ring;                /* scalar; at most twice */                  \
             const int c = (lane & 7) ^ ((((prow >> 3) & 1) << 2) | (lane >> 4));                           \
             const unsigned char* src = xg + g * 128 + c * 16;                                              \
             src = ok ? src : zp;                                                                           \
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
         }                                                                                                  \
     }
     // window of the first iteration and the new rows of the next PF - 1, by all eight waves
-    RW32_ROWS(0, (R16 >> 3) + 16 * TPI * (PF - 1), wave, 8)
+    RW32_ROWS(0LL, 0, (R16 >> 3) + 16 * TPI * (PF - 1), wave, 8)
     {
         conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
         if (tid < COUT / 4) {
@@ -317,49 +324,75 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
         static_assert(conv_epi::EpiArea<COUT>::BYTES <= 2048, "epilogue area");
         conv_epi::prepare<COUT>(p, epi_area, 0, sc_pre, bs_pre);
     }
+    // per-iteration advance of a grid position by STEP pixels: (sn, sy, sx) = STEP in (image, row, column) digits
+    const unsigned W_ = (unsigned)p.W, H_ = (unsigned)p.H;
+    const unsigned sx = (unsigned)STEP % W_, syf = (unsigned)STEP / W_;
+    const unsigned sy = syf % H_, sn = syf / H_;
+    // (n, y, x) of the first grid pixel this lane STORES in an iteration (row (lane >> 3) of its 32-pixel slice) and
+    // (y, x) of the pixel it COMPUTES (row (lane & 31); PADDED only: tap validity)
+    unsigned en, ey, ex, cy = 0, cx = 0;
+    {
+        const unsigned hw = H_ * W_;
+        const unsigned g0 = (unsigned)(t_begin * 128) + (TPI == 2 ? grp * 128 : 0) + ms * 32;     // grid pixels < 2^31 (launcher)
+        const unsigned ge = g0 + (lane >> 3);
+        en = ge / hw;
+        const unsigned rem = ge - en * hw;
+        ey = rem / W_; ex = rem - ey * W_;
+        if (PADDED) {
+            const unsigned gc = g0 + (lane & 31);
+            const unsigned remc = gc % hw;
+            cy = remc / W_; cx = remc - cy * W_;
+        }
+    }
+    // tap offsets in ring rows (scalars) and this lane's window row at ring position 0
+    int toff[ntaps];
+#pragma unroll
+    for (int t = 0; t < ntaps; ++t) toff[t] = (t / KWC - p.PH) * p.W + (t % KWC - p.PW);
+    const int lrow0 = (TPI == 2 ? grp * 128 : 0) + ms * 32 + (lane & 31) - minoff;   // window row of this lane's tile row at offset 0
+    const int l5 = lane >> 5;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int lrow0 = (TPI == 2 ? grp * 128 : 0) + ms * 32 + (lane & 31) - minoff;   // window row of this lane's tile row at offset 0
-    const unsigned hw = (unsigned)(p.H * p.W);
-    for (long long it = 0; it < nit; ++it) {
-        // the new rows of iteration it + PF replace the oldest 128 TPI rows (last read before the previous barrier)
+    int wstart = 0;                                        // physical row of this iteration's window row 0: (it * STEP) mod ring
+    int pnew = (R16 + (PF - 1) * STEP) % ring;             // physical row of the rows DMA'd in this iteration
+    long long relnew = (long long)R16 + (PF - 1) * STEP;
+    for (int it = 0; it < nit; ++it) {
+        // the new rows of iteration it + PF replace the oldest STEP rows (last read before the previous barrier)
         const bool ahead = it + PF < nit;
-        if (ahead) { RW32_ROWS((long long)R16 + (it + PF - 1) * 128 * TPI, 16 * TPI, wave, 8) }
-        const long long tile = t_begin + it * TPI + (TPI == 2 ? grp : 0);
-        unsigned tapmask = 0xffffffffu;                    // per-lane tap validity (padded convolutions)
-        if (p.PH | p.PW) {
-            const unsigned g = (unsigned)(tile * 128) + ms * 32 + (lane & 31);        // grid pixels < 2^31 (launcher)
-            const unsigned rem = g % hw;
-            const int y = (int)(rem / (unsigned)p.W), x = (int)rem - y * p.W;
+        if (ahead) { RW32_ROWS(relnew, pnew, 16 * TPI, wave, 8) }
+        const long long tile = t_begin + (long long)it * TPI + (TPI == 2 ? grp : 0);
+        unsigned tapmask = 0x1ffu;                         // per-lane tap validity (PADDED)
+        if (PADDED) {
             tapmask = 0u;
 #pragma unroll
             for (int t = 0; t < ntaps; ++t) {
-                const int yy = y + t / KWC - p.PH, xx = x + t % KWC - p.PW;
+                const int yy = (int)cy + t / KWC - p.PH, xx = (int)cx + t % KWC - p.PW;
                 if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) tapmask |= 1u << t;
             }
         }
         float16_t acc_main[1][1], acc_corr[1][1];
 #pragma unroll
         for (int j = 0; j < 16; ++j) { acc_main[0][0][j] = 0.f; acc_corr[0][0][j] = 0.f; }
-        const int wstart = (int)((it * 128 * TPI) % ring);     // physical row of this iteration's window row 0
+        int wbase = wstart + lrow0;                        // < 2 * ring
         half8_t fa_[2][2][2];
+// the four fragments of a tap: K-slice 0 hi at the swizzled chunk (lane >> 5), K-slice 1 = chunk ^ 2, lo = chunk ^ 4
 #define RW32_READS(TAP, BUF)                                                                              \
         {                                                                                                  \
-            const int kh_ = (TAP) / KWC, kw_ = (TAP) % KWC;                                                \
-            int wrow = wstart + lrow0 + (kh_ - p.PH) * p.W + (kw_ - p.PW);                                 \
-            wrow = wrow >= ring ? wrow - ring : wrow;                                                      \
-            const int aswz = (wrow >> 1) & 7;                                                              \
-            const unsigned char* ap = wbuf + wrow * 128;                                                   \
-            const unsigned am = (tapmask >> (TAP)) & 1u ? 0xffffffffu : 0u;                                \
-            _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                             \
-                const int ao = ((2 * s2 + (lane >> 5)) ^ aswz) * 16;                                       \
-                u32x4_t ah = *reinterpret_cast<const u32x4_t*>(ap + ao);                                   \
-                u32x4_t al = *reinterpret_cast<const u32x4_t*>(ap + (ao ^ 64));                            \
-                ah &= am; al &= am;                                                                        \
-                fa_[BUF][s2][0] = __builtin_bit_cast(half8_t, ah);                                         \
-                fa_[BUF][s2][1] = __builtin_bit_cast(half8_t, al);                                         \
+            int wrow = wbase + toff[TAP];                                                                  \
+            wrow = wrow >= ring ? wrow - ring : wrow;         /* wbase + toff < 2 * ring */                   \
+            const int a0 = wrow * 128 + ((l5 ^ ((wrow >> 1) & 7)) << 4);                                   \
+            u32x4_t ah0 = *reinterpret_cast<const u32x4_t*>(wbuf + a0);                                    \
+            u32x4_t al0 = *reinterpret_cast<const u32x4_t*>(wbuf + (a0 ^ 64));                             \
+            u32x4_t ah1 = *reinterpret_cast<const u32x4_t*>(wbuf + (a0 ^ 32));                             \
+            u32x4_t al1 = *reinterpret_cast<const u32x4_t*>(wbuf + (a0 ^ 96));                             \
+            if (PADDED) {                                                                                  \
+                const unsigned am = (tapmask >> (TAP)) & 1u ? 0xffffffffu : 0u;                            \
+                ah0 &= am; al0 &= am; ah1 &= am; al1 &= am;                                                \
             }                                                                                              \
+            fa_[BUF][0][0] = __builtin_bit_cast(half8_t, ah0);                                             \
+            fa_[BUF][0][1] = __builtin_bit_cast(half8_t, al0);                                             \
+            fa_[BUF][1][0] = __builtin_bit_cast(half8_t, ah1);                                             \
+            fa_[BUF][1][1] = __builtin_bit_cast(half8_t, al1);                                             \
         }
 #define RW32_MFMAS(TAP, BUF)                                                                              \
         _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                 \
@@ -367,7 +400,8 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
             acc_main[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[TAP][s2][0], fa_[BUF][s2][0], acc_main[0][0], 0, 0, 0); \
             acc_corr[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[TAP][s2][0], fa_[BUF][s2][1], acc_corr[0][0], 0, 0, 0); \
         }
-        if (wrap_guard(tile, ntiles)) {
+        const bool live = wrap_guard(tile, ntiles);
+        if (live) {
             RW32_READS(0, 0)
 #pragma unroll
             for (int tap = 0; tap < ntaps; ++tap) {
@@ -381,14 +415,39 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
         // iteration's DMA is younger;  PF = 1: they are this iteration's DMA (issued before the taps above)
         if (PF == 2 && ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (wrap_guard(tile, ntiles))
+        if (live) {
+            const unsigned nyx[3] = {en, ey, ex};
             conv_epi::store_tiles_desc<1, 1, true, COUT>(p, acc_main, acc_corr, stage, epi_area, tile * 128 + ms * 32,
-                                                         COUT == 64 ? grp * 4 : 0);
+                                                         COUT == 64 ? grp * 4 : 0, nyx);
+        }
+        // next iteration: ring positions and grid coordinates STEP pixels further
+        wstart += STEP; wstart = wstart >= ring ? wstart - ring : wstart;
+        pnew += STEP; pnew = pnew >= ring ? pnew - ring : pnew;
+        relnew += STEP;
+        ex += sx; ey += sy; en += sn;
+        if (ex >= W_) { ex -= W_; ++ey; }
+        if (ey >= H_) { ey -= H_; ++en; }
+        if (PADDED) {
+            cx += sx; cy += sy;
+            if (cx >= W_) { cx -= W_; ++cy; }
+            if (cy >= H_) cy -= H_;
+        }
         __syncthreads();
     }
 #undef RW32_ROWS
 #undef RW32_READS
 #undef RW32_MFMAS
+}
+
+template <int COUT, bool PADDED>
+static int launch_regw32_inst(const ConvArgs* a, int R16, long long ntiles, long long grid, size_t lds, hipStream_t st) {
+    static std::atomic<unsigned long long> attr_set{0};
+    if (tise_first_use_on_this_device(attr_set))
+        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_regw32_kernel<COUT, PADDED>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((conv_regw32_kernel<COUT, PADDED>), dim3((unsigned)grid), dim3(512), lds, st, *a, R16, ntiles);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
 }
 
 int launch_regw32(const ConvArgs* a, hipStream_t st) {
@@ -401,35 +460,22 @@ int launch_regw32(const ConvArgs* a, hipStream_t st) {
     const int pf = a->Cout == 64 ? 2 : 1;
     const size_t lds = (size_t)(R16 + 128 * tpi * pf) * 128 + 2048 + 8 * (size_t)conv_epi::Staging<1>::BYTES;
     if (lds > 160 * 1024) return TISE_ERR_UNSUPPORTED;
-    static std::atomic<unsigned long long> attr_set32{0}, attr_set64{0};
-    if (a->Cout == 32) {
-        if (tise_first_use_on_this_device(attr_set32))
-            TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_regw32_kernel<32>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    } else {
-        if (tise_first_use_on_this_device(attr_set64))
-            TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_regw32_kernel<64>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
     const long long mg = (long long)a->N * a->H * a->W;
     const long long ntiles = (mg + 127) / 128;
-    int dev = 0, ncu = 256;
-    hipDeviceProp_t prop;
-    TISE_HIP_CHECK(hipGetDevice(&dev));
     static int ncu_cached = 0;
     if (ncu_cached == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        TISE_HIP_CHECK(hipGetDevice(&dev));
         TISE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         ncu_cached = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    ncu = ncu_cached;
     const long long niter = (ntiles + tpi - 1) / tpi;
-    const long long grid = niter < ncu ? niter : ncu;
+    const long long grid = niter < ncu_cached ? niter : ncu_cached;
+    const bool padded = (a->PH | a->PW) != 0;
     if (a->Cout == 32)
-        hipLaunchKernelGGL((conv_regw32_kernel<32>), dim3((unsigned)grid), dim3(512), lds, st, *a, R16, ntiles);
-    else
-        hipLaunchKernelGGL((conv_regw32_kernel<64>), dim3((unsigned)grid), dim3(512), lds, st, *a, R16, ntiles);
-    TISE_LAUNCH_CHECK();
-    return TISE_OK;
+        return padded ? launch_regw32_inst<32, true>(a, R16, ntiles, grid, lds, st) : launch_regw32_inst<32, false>(a, R16, ntiles, grid, lds, st);
+    return padded ? launch_regw32_inst<64, true>(a, R16, ntiles, grid, lds, st) : launch_regw32_inst<64, false>(a, R16, ntiles, grid, lds, st);
 }
 
 int launch_win32(const ConvArgs* a, hipStream_t st) {
@@ -470,6 +516,8 @@ int launch_win32(const ConvArgs* a, hipStream_t st) {
 // cfg 33: LDS-resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; 32 couts per launch).
 // cfg 34: register-resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; Cout = 32 or 64, one launch).
 int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream) {
+    if (a->out_hp && (a->out_y0 < 0 || a->out_x0 < 0 || a->out_y0 + a->OH > a->out_hp || a->out_x0 + a->OW > a->out_wp))
+        return TISE_ERR_INVALID_ARG;
     if (cfg == 34) return launch_regw32(a, (hipStream_t)stream);
     if (cfg != 33) return TISE_ERR_INVALID_ARG;
     return launch_win32(a, (hipStream_t)stream);

@@ -257,6 +257,8 @@ class SplitTrunk(FusedTrunk):
             return SplitConv(c.w, c.b, c.stride, c.padding, self.device)
 
         self.s2a, self.s2b, self.s3b, self.s4a = sc(self.c2a), sc(self.c2b), sc(self.c3b), sc(self.c4a)
+        self.pad2b = False
+        self._padbufs = {}
         # Conv2d_2a (149^2 x 32 -> 32) and Conv2d_2b (147^2 x 32 -> 64, padded): Cin = 32 means a wave can hold the whole
         # filter of 32 couts in registers (conv_pipe.hip configuration 34): the input streams through a sliding LDS ring
         # once, nothing else moves.  TISE_CONV_REGW=0: round 2's kernels (configuration 33 for 2a, row window for 2b)
@@ -264,8 +266,13 @@ class SplitTrunk(FusedTrunk):
             regw = os.environ.get("TISE_CONV_REGW", "1") != "0"
             self.s2a = SplitConv(self.c2a.w, self.c2a.b, self.c2a.stride, self.c2a.padding, self.device, variant="pipe",
                                  pipe_cfg=34 if regw else 33)
+            # Conv2d_2b's zero padding made physical: Conv2d_2a writes into the interior of a zero-bordered buffer (out_pad)
+            # and Conv2d_2b runs as a VALID convolution over it -- no per-lane tap masks in the kernel (bit-identical:
+            # the masked taps contributed zeros).  TISE_CONV_PADBUF=0: the padded kernel instance on the plain tensor
+            self.pad2b = regw and os.environ.get("TISE_CONV_PADBUF", "1") != "0" and tuple(self.c2b.padding) == (1, 1)
             if regw:
-                self.s2b = SplitConv(self.c2b.w, self.c2b.b, self.c2b.stride, self.c2b.padding, self.device, variant="pipe", pipe_cfg=34)
+                self.s2b = SplitConv(self.c2b.w, self.c2b.b, self.c2b.stride, (0, 0) if self.pad2b else self.c2b.padding,
+                                     self.device, variant="pipe", pipe_cfg=34)
         # stem weights for the direct kernel: [kh][kw][cin][cout] fp32
         self.stem_w = self.c1a.w.permute(2, 3, 1, 0).contiguous().float()
         assert tuple(self.stem_w.shape) == (3, 3, 3, 32) and self.c1a.stride == (2, 2) and self.c1a.padding == (0, 0)
@@ -407,9 +414,27 @@ class SplitTrunk(FusedTrunk):
                   _stream())
         return self._after_stem(a)
 
+    def _zero_bordered(self, n, hp, wp, c, dev):
+        """Persistent split tensor (n, hp, wp, 2c) whose border stays zero: allocated and zeroed once per shape (the two
+        most recent shapes are kept), only its interior is ever written."""
+        key = (n, hp, wp, c, str(dev))
+        buf = self._padbufs.pop(key, None)
+        if buf is None:
+            buf = torch.zeros((n, hp, wp, 2 * c), dtype=torch.float16, device=dev)
+            while len(self._padbufs) >= 2:
+                self._padbufs.pop(next(iter(self._padbufs)))
+        self._padbufs[key] = buf                                        # most recently used last
+        return buf
+
     def _after_stem(self, a):
-        a = self._sconv(self.s2a, a)
-        a = self._sconv(self.s2b, a)
+        if self.pad2b:
+            n, h, w, _ = a.shape
+            oh, ow = self.s2a.out_hw(h, w)
+            buf = self._zero_bordered(n, oh + 2, ow + 2, self.s2a.cout, a.device)
+            self.s2a(a, [(0, self.s2a.cout, buf, 0, 0)], out_pad=(oh + 2, ow + 2, 1, 1))
+            a = self._sconv(self.s2b, buf)
+        else:
+            a = self._sconv(self.s2b, self._sconv(self.s2a, a))
         fn = {"A": self._sblock_a, "B": self._sblock_b, "C": self._sblock_c, "D": self._sblock_d, "E": self._sblock_e}
         if self.fuse_pool:
             n, h, w, _ = a.shape

@@ -24,7 +24,7 @@ for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=T
     pass_id = os.path.dirname(f)
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if "conv_split" not in name and "conv_win32" not in name and "conv_poolin" not in name and "conv_colwin" not in name:
+        if "conv_split" not in name and "conv_win32" not in name and "conv_poolin" not in name and "conv_regw32" not in name:
             continue
         key = (pass_id, int(r["Dispatch_Id"]))
         rows[key]["name"] = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")

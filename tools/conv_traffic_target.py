@@ -23,8 +23,8 @@ alg = []
 detail = []
 
 
-def wrapped(self, xs, segs, pooled_input=False):
-    r = orig(self, xs, segs, pooled_input=pooled_input)
+def wrapped(self, xs, segs, pooled_input=False, **kw):
+    r = orig(self, xs, segs, pooled_input=pooled_input, **kw)
     n, h, w, _ = xs.shape
     oh, ow = r
     wn = (self.w_fast if self.w_fast is not None else self.w).numel()

@@ -22,10 +22,10 @@ orig = SplitConv.__call__
 recs = []
 
 
-def wrapped(self, xs, segs, pooled_input=False):
+def wrapped(self, xs, segs, pooled_input=False, **kw):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    r = orig(self, xs, segs, pooled_input=pooled_input)
+    r = orig(self, xs, segs, pooled_input=pooled_input, **kw)
     e1.record()
     n, h, w, _ = xs.shape
     oh, ow = r
