@@ -9,6 +9,7 @@
 // window-resident form (7, 11-15) and wave-specialised 128- / 256-pixel configurations (40-47).  All of them measured
 // within +-3 % of the default `fast` kernel in the bench (profiles/r01g_conv_pipe_probe.txt, r01i_conv_spec_probe.txt)
 // and were removed in round 2 together with their tests; the measurements stay in profiles/ and DESIGN.md.
+#include <stdlib.h>
 #include <hip/hip_fp16.h>
 #include "common.h"
 #include "conv_epilogue.h"
@@ -253,7 +254,9 @@ __global__ __launch_bounds__(512, 1) void conv_win32_kernel(const ConvArgs p, co
 // vector issue, not by the matrix cores or the DMA): tap masks only in the PADDED instance (Conv2d_2b runs UNPADDED on a
 // zero-bordered copy of its input, which Conv2d_2a writes directly: args->out_hp), ring positions and the (n, y, x) of a
 // lane's pixels advanced incrementally (no division in the loop), four fragment addresses per tap from one.
-template <int COUT, bool PADDED>
+// DBG instance only (tools/conv_ablate.py; never launched by the product path): bits 8..10 of args->nseg switch the DMA,
+// the taps and the epilogue off.
+template <int COUT, bool PADDED, bool DBG = false>
 __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, const int R16, const long long ntiles) {
     constexpr int KHC = 3, KWC = 3, ntaps = 9;
     constexpr int TPI = 64 / COUT;                        // tiles per iteration
@@ -296,6 +299,17 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
             for (int s2 = 0; s2 < 2; ++s2) {
                 bw[t][s2][0] = *reinterpret_cast<const half8_t*>(wrow + t * CP_BK + s2 * 16);
                 bw[t][s2][1] = *reinterpret_cast<const half8_t*>(wrow + p.w_plane + t * CP_BK + s2 * 16);
+            }
+        // the loads above must be COMPLETE, and known to the compiler to be complete, before the loop: an empty asm that
+        // reads and rewrites every fragment makes it wait here.  (Otherwise the wait for these loads is sunk to their
+        // first use inside the loop as `s_waitcnt vmcnt(0)`, which every iteration then also spends waiting for the
+        // ring rows it has just requested: measured as 0.28 of 1.70 ms with the DMA switched off.)
+#pragma unroll
+        for (int t = 0; t < ntaps; ++t)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                asm volatile("" : "+v"(bw[t][s2][0]));
+                asm volatile("" : "+v"(bw[t][s2][1]));
             }
     }
 // DMA of the 8-row pieces Q0, Q0 + QS, ... < NPIECES of the rows that start at relative row REL0 (a long long), whose
@@ -353,13 +367,14 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    float16_t acc_main[1][1], acc_corr[1][1];
     int wstart = 0;                                        // physical row of this iteration's window row 0: (it * STEP) mod ring
     int pnew = (R16 + (PF - 1) * STEP) % ring;             // physical row of the rows DMA'd in this iteration
     long long relnew = (long long)R16 + (PF - 1) * STEP;
     for (int it = 0; it < nit; ++it) {
         // the new rows of iteration it + PF replace the oldest STEP rows (last read before the previous barrier)
         const bool ahead = it + PF < nit;
-        if (ahead) { RW32_ROWS(relnew, pnew, 16 * TPI, wave, 8) }
+        if (ahead && !(DBG && (p.nseg & 0x100))) { RW32_ROWS(relnew, pnew, 16 * TPI, wave, 8) }
         const long long tile = t_begin + (long long)it * TPI + (TPI == 2 ? grp : 0);
         unsigned tapmask = 0x1ffu;                         // per-lane tap validity (PADDED)
         if (PADDED) {
@@ -370,9 +385,6 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
                 if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) tapmask |= 1u << t;
             }
         }
-        float16_t acc_main[1][1], acc_corr[1][1];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { acc_main[0][0][j] = 0.f; acc_corr[0][0][j] = 0.f; }
         int wbase = wstart + lrow0;                        // < 2 * ring
         half8_t fa_[2][2][2];
 // the four fragments of a tap: K-slice 0 hi at the swizzled chunk (lane >> 5), K-slice 1 = chunk ^ 2, lo = chunk ^ 4
@@ -400,33 +412,56 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
             acc_main[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[TAP][s2][0], fa_[BUF][s2][0], acc_main[0][0], 0, 0, 0); \
             acc_corr[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[TAP][s2][0], fa_[BUF][s2][1], acc_corr[0][0], 0, 0, 0); \
         }
-        const bool live = wrap_guard(tile, ntiles);
-        if (live) {
-            RW32_READS(0, 0)
-#pragma unroll
-            for (int tap = 0; tap < ntaps; ++tap) {
-                if (tap + 1 < ntaps) {
-                    if ((tap + 1) & 1) { RW32_READS(tap + 1, 1) } else { RW32_READS(tap + 1, 0) }
-                }
-                if (tap & 1) { RW32_MFMAS(tap, 1) } else { RW32_MFMAS(tap, 0) }
-            }
+// all nine taps of this wave's 32 pixels x 32 couts into (acc_main, acc_corr)
+#define RW32_TAPS()                                                                                       \
+        {                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 16; ++j) { acc_main[0][0][j] = 0.f; acc_corr[0][0][j] = 0.f; } \
+            if (!(DBG && (p.nseg & 0x200))) {                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            RW32_READS(0, 0)                                                                               \
+            _Pragma("unroll") for (int tap = 0; tap < ntaps; ++tap) {                                      \
+                if (tap + 1 < ntaps) {                                                                     \
+                    if ((tap + 1) & 1) { RW32_READS(tap + 1, 1) } else { RW32_READS(tap + 1, 0) }          \
+                }                                                                                          \
+                if (tap & 1) { RW32_MFMAS(tap, 1) } else { RW32_MFMAS(tap, 0) }                            \
+            }                                                                                              \
+            /* issue order: the four fragment reads of tap t + 1, THEN the six MFMAs of tap t (left to itself the    \
+               scheduler put every read right in front of its MFMA and an lgkmcnt(0) between them: the LDS latency  \
+               was exposed eighteen times per tile) */                                                     \
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                             \
+            _Pragma("unroll") for (int tap = 0; tap + 1 < ntaps; ++tap) {                                  \
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                         \
+                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                         \
+            }                                                                                              \
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+            }                                                                                              \
         }
+#define RW32_EPI(TILE, N_, Y_, X_)                                                                        \
+        if (!(DBG && (p.nseg & 0x400))) {                                                                  \
+            const unsigned nyx[3] = {N_, Y_, X_};                                                          \
+            conv_epi::store_tiles_desc<1, 1, true, COUT>(p, acc_main, acc_corr, stage, epi_area, (TILE) * 128 + ms * 32, \
+                                                         COUT == 64 ? grp * 4 : 0, nyx);                   \
+        }
+        const bool live = wrap_guard(tile, ntiles);
+        // advance of the grid coordinates by STEP pixels
+#define RW32_ADVANCE()                                                                                    \
+        {                                                                                                  \
+            ex += sx; ey += sy; en += sn;                                                                  \
+            if (ex >= W_) { ex -= W_; ++ey; }                                                              \
+            if (ey >= H_) { ey -= H_; ++en; }                                                              \
+        }
+        if (live) RW32_TAPS()
         // the rows of the next iteration have landed.  PF = 2: they were issued one iteration ago and only this
         // iteration's DMA is younger;  PF = 1: they are this iteration's DMA (issued before the taps above)
         if (PF == 2 && ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (live) {
-            const unsigned nyx[3] = {en, ey, ex};
-            conv_epi::store_tiles_desc<1, 1, true, COUT>(p, acc_main, acc_corr, stage, epi_area, tile * 128 + ms * 32,
-                                                         COUT == 64 ? grp * 4 : 0, nyx);
-        }
-        // next iteration: ring positions and grid coordinates STEP pixels further
+        if (live) RW32_EPI(tile, en, ey, ex)
+        RW32_ADVANCE()
+        // next iteration: ring positions STEP rows further
         wstart += STEP; wstart = wstart >= ring ? wstart - ring : wstart;
         pnew += STEP; pnew = pnew >= ring ? pnew - ring : pnew;
         relnew += STEP;
-        ex += sx; ey += sy; en += sn;
-        if (ex >= W_) { ex -= W_; ++ey; }
-        if (ey >= H_) { ey -= H_; ++en; }
         if (PADDED) {
             cx += sx; cy += sy;
             if (cx >= W_) { cx -= W_; ++cy; }
@@ -434,9 +469,12 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
         }
         __syncthreads();
     }
+#undef RW32_ADVANCE
 #undef RW32_ROWS
 #undef RW32_READS
 #undef RW32_MFMAS
+#undef RW32_TAPS
+#undef RW32_EPI
 }
 
 template <int COUT, bool PADDED>
@@ -473,6 +511,12 @@ int launch_regw32(const ConvArgs* a, hipStream_t st) {
     const long long niter = (ntiles + tpi - 1) / tpi;
     const long long grid = niter < ncu_cached ? niter : ncu_cached;
     const bool padded = (a->PH | a->PW) != 0;
+    if (a->nseg & 0x700) {                                     // tools/conv_ablate.py: the instrumented instances
+        if (padded) return TISE_ERR_INVALID_ARG;
+        hipLaunchKernelGGL((conv_regw32_kernel<64, false, true>), dim3((unsigned)grid), dim3(512), lds, st, *a, R16, ntiles);
+        TISE_LAUNCH_CHECK();
+        return a->Cout == 64 ? TISE_OK : TISE_ERR_INVALID_ARG;
+    }
     if (a->Cout == 32)
         return padded ? launch_regw32_inst<32, true>(a, R16, ntiles, grid, lds, st) : launch_regw32_inst<32, false>(a, R16, ntiles, grid, lds, st);
     return padded ? launch_regw32_inst<64, true>(a, R16, ntiles, grid, lds, st) : launch_regw32_inst<64, false>(a, R16, ntiles, grid, lds, st);

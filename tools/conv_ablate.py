@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tise_toolbox_amd.conv_split import SplitConv, split
 
-LAYERS = [("2b", 147, 32, 64, 3, 3, 1, (1, 1)), ("5c3x3", 35, 96, 96, 3, 3, 1, (1, 1)),
+LAYERS = [("2bv", 149, 32, 64, 3, 3, 1, (0, 0))] if (len(sys.argv) > 2 and sys.argv[2] == "34") else [("2b", 147, 32, 64, 3, 3, 1, (1, 1)), ("5c3x3", 35, 96, 96, 3, 3, 1, (1, 1)),
           ("6b1x1", 17, 768, 704, 1, 1, 1, (0, 0)), ("7c3x3", 8, 448, 384, 3, 3, 1, (1, 1)),
           ("5b1x1", 35, 192, 208, 1, 1, 1, (0, 0)), ("6a", 35, 288, 384, 3, 3, 2, (0, 0)),
           ("6e7x1", 17, 192, 192, 7, 1, 1, (3, 0))]
