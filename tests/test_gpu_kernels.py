@@ -552,9 +552,6 @@ def test_conv_rowwin_kernel_matches_fp64_conv(dev, case):
         assert got[..., :16].abs().max().item() == 0 and got[..., 32:64].abs().max().item() == 0
         if first is None:
             first = (out.clone(), raw.clone())
-            out_g, raw_g = torch.zeros_like(out), torch.zeros_like(raw)
-            generic(xs, [(a, c, out_g if m == 0 else raw_g, off, m) for (a, c, _, off, m) in segs])
-            assert torch.equal(out, out_g) and torch.equal(raw, raw_g)
         else:
             assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
 
@@ -753,6 +750,9 @@ def test_conv_win32_sliding_window_kernel(dev, case, cfg):
         assert got[..., :16].abs().max().item() == 0 and got[..., 32:64].abs().max().item() == 0
         if first is None:
             first = (out.clone(), raw.clone())
+            out_g, raw_g = torch.zeros_like(out), torch.zeros_like(raw)
+            generic(xs, [(a, c, out_g if m == 0 else raw_g, off, m) for (a, c, _, off, m) in segs])
+            assert torch.equal(out, out_g) and torch.equal(raw, raw_g)
         else:
             assert torch.equal(out, first[0]) and torch.equal(raw, first[1])
 

@@ -124,23 +124,39 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float1
     for (int t0 = 0; t0 < TNW; t0 += TW) {
         const int nt = (TNW - t0) < TW ? (TNW - t0) : TW;
         unsigned char* trow = tw + (lane & 31) * PITCH;
+        // mode, scale and bias of the group's 4 * nt chunks are requested in ONE batch before any of them is used: read
+        // chunk by chunk inside the conversion loop, every chunk exposed two or three LDS round trips (scale, mode,
+        // bias behind the mode branch) -- some 300 cycles x 16 chunks per wave and tile at TN = 4, the larger part of the
+        // epilogue's 10-30 % share of a launch (profiles/r01g_conv_ablation.txt)
+        int modes[TW * 4];
+        float4_t scs[TW * 4], bss[TW * 4];
+#pragma unroll
+        for (int u = 0; u < TW; ++u) {
+            if (u >= nt) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int chunk = chunk0 + (t0 + u) * 4 + g;
+                const int ch = chunk * 8 + 4 * (lane >> 5);
+                modes[u * 4 + g] = *reinterpret_cast<const int*>(area + EpiArea<BN>::DESC + chunk * 32 + 24);
+                scs[u * 4 + g] = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::SCALE + ch * 4);
+                bss[u * 4 + g] = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::BIAS + ch * 4);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < TW; ++u) {
             if (u >= nt) continue;
             const int t = t0 + u;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int chunk = chunk0 + t * 4 + g;
-                const int mode = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int*>(area + EpiArea<BN>::DESC + chunk * 32 + 24));
-                const int ch = chunk * 8 + 4 * (lane >> 5);
-                const float4_t sc = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::SCALE + ch * 4);
+                const int mode = __builtin_amdgcn_readfirstlane(modes[u * 4 + g]);
+                const float4_t sc = scs[u * 4 + g];
                 float4_t v;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     v[k] = (acc_main[0][t][4 * g + k] + acc_corr[0][t][4 * g + k] * (1.0f / 2048.0f)) * sc[k];
                 unsigned char* slot = trow + u * 128 + g * 32;
                 if (mode == 0) {
-                    const float4_t bs = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::BIAS + ch * 4);
+                    const float4_t bs = bss[u * 4 + g];
                     half4_t hi, lo;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -161,14 +177,22 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float1
         const int row0 = lane / lpr, q = lane % lpr;
         const ChunkDesc cd = *reinterpret_cast<const ChunkDesc*>(area + EpiArea<BN>::DESC + (chunk0 + t0 * 4 + (q >> 1)) * 32);
         const unsigned char* src = tw + row0 * PITCH + q * 16;
+        // all staged rows of the group are read back in one batch, THEN stored (a read right in front of each
+        // conditional store exposed one LDS round trip per pass)
+        constexpr int NPASS = 32 * TW / 8;
+        u32x4_t vals[NPASS];
+#pragma unroll
+        for (int r4 = 0; r4 < NPASS; ++r4) {
+            if (r4 * rows_per_pass >= 32) continue;
+            vals[r4] = *reinterpret_cast<const u32x4_t*>(src + r4 * rows_per_pass * PITCH);
+        }
         if (!GRID) {
             unsigned char* d = reinterpret_cast<unsigned char*>(cd.base + (m0w + row0) * cd.row_stride + ((q & 1) ? cd.second : 0));
             const long long step = rows_per_pass * cd.row_stride;
 #pragma unroll
-            for (int r4 = 0; r4 < 32 * TW / 8; ++r4) {
+            for (int r4 = 0; r4 < NPASS; ++r4) {
                 if (r4 * rows_per_pass >= 32) continue;
-                const u32x4_t val = *reinterpret_cast<const u32x4_t*>(src + r4 * rows_per_pass * PITCH);
-                if (cd.valid && row0 + r4 * rows_per_pass < rows_ok) *reinterpret_cast<u32x4_t*>(d) = val;
+                if (cd.valid && row0 + r4 * rows_per_pass < rows_ok) *reinterpret_cast<u32x4_t*>(d) = vals[r4];
                 d += step;
             }
         } else {
@@ -185,13 +209,12 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float1
             const long long half_off = (q & 1) ? cd.second : 0;
             const int ohp = p.out_hp ? p.out_hp : p.OH, owp = p.out_hp ? p.out_wp : p.OW;      // destination image pitch
 #pragma unroll
-            for (int r4 = 0; r4 < 32 * TW / 8; ++r4) {
+            for (int r4 = 0; r4 < NPASS; ++r4) {
                 if (r4 * rows_per_pass >= 32) continue;
-                const u32x4_t val = *reinterpret_cast<const u32x4_t*>(src + r4 * rows_per_pass * PITCH);
                 const bool ok = cd.valid && row0 + r4 * rows_per_pass < rows_ok && y < (unsigned)p.OH && x < (unsigned)p.OW;
                 if (ok) {
                     const long long pp = ((long long)n * ohp + y) * owp + x;
-                    *reinterpret_cast<u32x4_t*>(cd.base + pp * cd.row_stride + half_off) = val;
+                    *reinterpret_cast<u32x4_t*>(cd.base + pp * cd.row_stride + half_off) = vals[r4];
                 }
                 x += rows_per_pass;                               // next pass: rows_per_pass grid pixels further (W >= 8)
                 if (x >= (unsigned)p.W) { x -= (unsigned)p.W; if (++y == (unsigned)p.H) { y = 0; ++n; } }
