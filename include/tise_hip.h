@@ -274,7 +274,8 @@ int tise_gather_rows_f16(const void* x_dev, const int64_t* index_dev, int64_t n,
  *        weights as for 16.
  *   256  (round 3) POOLED INPUT: the convolution (1x1, stride 1, no padding, Cin % 32 == 0, weights as for 128) reads
  *        max_pool2d(x, 3, stride 2): args->H, W describe the UN-pooled tensor x, args->OH, OW the pooled grid
- *        ((H - 3) / 2 + 1), which is also the output grid; M = N * OH * OW; tn in {2, 3, 4}.  The pool is taken while
+ *        ((H - 3) / 2 + 1), which is also the output grid; M = N * OH * OW; the low bits of tn are ignored (tiles of 64 pixels x 128 couts when
+ *        Cout <= 128, else x 256 couts; weights, scale and bias zero-padded to that many rows).  The pool is taken while
  *        the pixel operand is loaded (torchvision's MaxPool2d(3, 2) before Conv2d_3b_1x1 and before Mixed_5b,
  *        image_realism/FID/inception.py:61-71); bit-identical to tise_maxpool3s2_split_nhwc followed by variant 128.
  *   (Round 1's variants 0 / 32 and the other pipe configurations tied with 128 and were removed.)

@@ -233,6 +233,8 @@ class SplitConv:
         if pooled_input:
             assert (self.kh, self.kw, self.stride, self.padding) == (1, 1, (1, 1), (0, 0)) and self.cin % 32 == 0
             assert self.variant == "fast" and self.w_fast is not None and h >= 3 and w >= 3
+            # the kernel's cout tiles: one of 128 couts, else tiles of 256 (weights / scale / bias are zero-padded to cout_pad rows)
+            assert self.cout_pad >= (128 if self.cout <= 128 else -(-self.cout // 256) * 256)
             oh, ow = self.pooled_out_hw(h, w)
         if self.variant == "rowwin" and not rowwin_fits(ow, self.kw):
             # rows so short that the window of a 128-pixel tile needs more than the kernel's six pieces per wave (OW < 7

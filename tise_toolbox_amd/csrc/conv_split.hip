@@ -743,12 +743,19 @@ static int launch_rowwin_any(const ConvArgs* a, int tn, hipStream_t st) {
 // read, and two to three workgroups per CU overlap one another's load and MFMA phases).
 // Geometry in the argument struct: H, W = the UN-pooled input, OH, OW = the pooled grid = the convolution's output
 // grid, KH = KW = 1, M = N * OH * OW.
-template <int TN>
-__global__ __launch_bounds__(256, 2) void conv_poolin_kernel(const ConvArgs p) {
-    constexpr int BN = 32 * TN;
-    constexpr int A_BYTES = CS_BM * 128, B_BYTES = BN * 128;
+// Tile = 64 pooled pixels x 64 * TNW couts per 256-thread workgroup, waves 2 (pixels) x 2 (couts): every thread owns ONE
+// (pixel, 8-channel) item per K-step -- its 18 loads go out together and the step costs one memory round trip (the
+// first version, 128 pixels x 32 TN couts with two items per thread, spent two round trips per step with its loads
+// split in two batches by register pressure and re-pooled Mixed_5b's input once per 128-cout tile: 2.4 TB/s of input
+// against the stand-alone pool kernel's 4.8, profiles/r03d_trunk_conv_layers.txt).  TNW = 2: 128 couts (Conv2d_3b's
+// 80), three workgroups per CU;  TNW = 4: 256 couts (Mixed_5b's 208 in ONE tile: pooled once), two per CU.
+template <int TNW>
+__global__ __launch_bounds__(256, TNW == 2 ? 3 : 2) void conv_poolin_kernel(const ConvArgs p) {
+    constexpr int PM = 64;                                    // pooled pixels per tile
+    constexpr int BN = 64 * TNW;
+    constexpr int A_BYTES = PM * 128, B_BYTES = BN * 128;
     constexpr int OPER = A_BYTES + 2 * B_BYTES;
-    constexpr int ETW = TN > 1 ? 2 : 1;
+    constexpr int ETW = 2;
     constexpr int EPI0 = 4 * conv_epi::Staging<ETW>::BYTES;
     constexpr int EPI_BYTES = EPI0 + conv_epi::EpiArea<BN>::BYTES;
     constexpr int LDS_BYTES = OPER > EPI_BYTES ? OPER : EPI_BYTES;
@@ -756,6 +763,7 @@ __global__ __launch_bounds__(256, 2) void conv_poolin_kernel(const ConvArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wn = wave >> 1;
     const unsigned tiles_n = (unsigned)(p.Cout + BN - 1) / BN;
     const unsigned nwg = gridDim.x;
     unsigned bid = blockIdx.x;
@@ -765,45 +773,41 @@ __global__ __launch_bounds__(256, 2) void conv_poolin_kernel(const ConvArgs p) {
     }
     const unsigned tile_m = bid / tiles_n;
     const int tile_n = (int)(bid - tile_m * tiles_n);
-    const long long m0 = (long long)tile_m * CS_BM;
+    const long long m0 = (long long)tile_m * PM;
     const int n0 = tile_n * BN;
     const int pix_bytes = p.Cin * 4;
 
-    // producer role: items (row, 8-channel pair c): row = (tid >> 2) + 64 * it, c = tid & 3 -- the four lanes of a row
-    // read 64 contiguous bytes of the hi half and 64 of the lo half of a pixel's 128-byte block line
+    // producer role: thread = (row = tid >> 2, 8-channel pair c = tid & 3): the four lanes of a row read 64 contiguous
+    // bytes of the hi half and 64 of the lo half of a pixel's 128-byte block line
     const int pc = tid & 3;
-    const unsigned char* src0[2];                             // top-left tap of the item's pooled pixel, channel pair c, block 0
-    int arow_off[2];                                          // byte offset of the item's hi chunk inside the A buffer
+    const unsigned char* src0;                                // top-left tap of the pooled pixel, channel pair c, block 0
+    int arow_off;                                             // byte offset of the hi chunk inside the A buffer
     {
         const unsigned ohw = (unsigned)(p.OH * p.OW), M32 = (unsigned)p.M;
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int row = (tid >> 2) + 64 * it;
-            const unsigned pix = tile_m * CS_BM + row;
-            const unsigned pp = pix < M32 ? pix : 0u;         // rows beyond M compute pixel 0 and are dropped by the epilogue
-            const unsigned n = pp / ohw;
-            const unsigned rem = pp - n * ohw;
-            const unsigned oh = rem / (unsigned)p.OW, ow = rem - oh * (unsigned)p.OW;
-            src0[it] = reinterpret_cast<const unsigned char*>(p.x) +
-                       (((long long)n * p.H + 2 * oh) * p.W + 2 * ow) * pix_bytes + pc * 16;
-            arow_off[it] = row * 128 + ((pc ^ ((row >> 1) & 7)) * 16);
-        }
+        const int row = tid >> 2;
+        const unsigned pix = tile_m * PM + row;
+        const unsigned pp = pix < M32 ? pix : 0u;             // rows beyond M compute pixel 0 and are dropped by the epilogue
+        const unsigned n = pp / ohw;
+        const unsigned rem = pp - n * ohw;
+        const unsigned oh = rem / (unsigned)p.OW, ow = rem - oh * (unsigned)p.OW;
+        src0 = reinterpret_cast<const unsigned char*>(p.x) + (((long long)n * p.H + 2 * oh) * p.W + 2 * ow) * pix_bytes + pc * 16;
+        arow_off = row * 128 + ((pc ^ ((row >> 1) & 7)) * 16);
     }
-    // weights: as in the default kernel
+    // weights: 8-cout DMA pieces, 2 * TNW per wave and K-step (as in the default kernel: scalar base + 32-bit lane offset)
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (long long)n0 * p.Kpad * 4;
-    unsigned pb[TN];
-    int pb_off[TN];
+    unsigned pb[2 * TNW];
+    int pb_off[2 * TNW];
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-        const int q = wave * TN + i;
+    for (int i = 0; i < 2 * TNW; ++i) {
+        const int q = wave * 2 * TNW + i;
         const int r = q * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((r >> 1) & 7);
         pb[i] = (unsigned)r * (unsigned)p.Kpad * 4u + c * 16;
         pb_off[i] = A_BYTES + q * 1024;
     }
-    float16_t acc_main[1][TN], acc_corr[1][TN];
+    float16_t acc_main[1][TNW], acc_corr[1][TNW];
 #pragma unroll
-    for (int t = 0; t < TN; ++t)
+    for (int t = 0; t < TNW; ++t)
 #pragma unroll
         for (int j = 0; j < 16; ++j) { acc_main[0][t][j] = 0.f; acc_corr[0][t][j] = 0.f; }
     conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
@@ -814,12 +818,12 @@ __global__ __launch_bounds__(256, 2) void conv_poolin_kernel(const ConvArgs p) {
     const int bswz = ((lane & 31) >> 1) & 7;
     const int fb0 = (lane & 31) * 128 + (((lane >> 5)) ^ bswz) * 16;
     const int fb1 = (lane & 31) * 128 + ((2 + (lane >> 5)) ^ bswz) * 16;
-    const unsigned char* fa = lds + wave * 32 * 128;
+    const unsigned char* fa = lds + wm * 32 * 128;
     const int row_bytes = p.W * pix_bytes;
     const int nsteps = p.Cin / CS_BK;
 
 #define PI_B_ISSUE(BOFF)                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                                       \
+    _Pragma("unroll") for (int i = 0; i < 2 * TNW; ++i) {                                                  \
         const unsigned char* sw_ = wbase + pb[i];                                                          \
         __builtin_amdgcn_global_load_lds(sw_, (lds_ptr_t)(lds + (BOFF) + pb_off[i]), 16, 0, 0);            \
         pb[i] += 128;                                                                                      \
@@ -827,11 +831,10 @@ __global__ __launch_bounds__(256, 2) void conv_poolin_kernel(const ConvArgs p) {
     PI_B_ISSUE(0)
     for (int step = 0; step < nsteps; ++step) {
         const int bcur = (step & 1) * B_BYTES;
-        // ---- pooled pixel operand of this K-step: 2 items x 9 taps x (hi, lo) 16-byte loads ------------------
-        half8_t ph[2], pl[2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const unsigned char* s0 = src0[it] + step * 128;
+        // ---- pooled pixel operand of this K-step: 9 taps x (hi, lo) 16-byte loads, all in flight together ----------
+        half8_t ph, pl;
+        {
+            const unsigned char* s0 = src0 + step * 128;
             half8_t vh[9], vl[9];
 #pragma unroll
             for (int dh = 0; dh < 3; ++dh)
@@ -850,16 +853,13 @@ __global__ __launch_bounds__(256, 2) void conv_poolin_kernel(const ConvArgs p) {
                 for (int i = 0; i < 8; ++i) bv[i] = fmaxf(bv[i], (float)vh[t][i] + (float)vl[t][i] * (1.f / 2048.f));
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                ph[it][i] = (_Float16)bv[i];
-                pl[it][i] = (_Float16)((bv[i] - (float)ph[it][i]) * 2048.f);
+                ph[i] = (_Float16)bv[i];
+                pl[i] = (_Float16)((bv[i] - (float)ph[i]) * 2048.f);
             }
         }
         __syncthreads();                                      // the previous step's fragment reads of the A buffer are done
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            *reinterpret_cast<half8_t*>(lds + arow_off[it]) = ph[it];
-            *reinterpret_cast<half8_t*>(lds + (arow_off[it] ^ 64)) = pl[it];
-        }
+        *reinterpret_cast<half8_t*>(lds + arow_off) = ph;
+        *reinterpret_cast<half8_t*>(lds + (arow_off ^ 64)) = pl;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this step's weights have landed (issued one step ago)
         __syncthreads();
         // next step's weights into the other stage (last read by the MFMAs of step - 1, which ended before the first
@@ -872,8 +872,8 @@ __global__ __launch_bounds__(256, 2) void conv_poolin_kernel(const ConvArgs p) {
             const half8_t a_hi = *reinterpret_cast<const half8_t*>(fa + fbo);
             const half8_t a_lo = *reinterpret_cast<const half8_t*>(fa + (fbo ^ 64));
 #pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const unsigned char* bb = lds + A_BYTES + bcur + t * 32 * 128;
+            for (int t = 0; t < TNW; ++t) {
+                const unsigned char* bb = lds + A_BYTES + bcur + (wn * TNW + t) * 32 * 128;
                 const half8_t b_hi = *reinterpret_cast<const half8_t*>(bb + fbo);
                 const half8_t b_lo = *reinterpret_cast<const half8_t*>(bb + (fbo ^ 64));
                 acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo, a_hi, acc_corr[0][t], 0, 0, 0);
@@ -886,7 +886,8 @@ __global__ __launch_bounds__(256, 2) void conv_poolin_kernel(const ConvArgs p) {
     __syncthreads();
     conv_epi::prepare<BN>(p, lds + EPI0, n0, sc_pre, bs_pre);
     __syncthreads();
-    conv_epi::store_tiles_desc<TN, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, lds + EPI0, m0 + wave * 32);
+    conv_epi::store_tiles_desc<TNW, ETW, false, BN>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, lds + EPI0,
+                                                    m0 + wm * 32, wn * TNW * 4);
 }
 
 static int launch_poolin(const ConvArgs* a, int tn, hipStream_t st) {
@@ -894,16 +895,14 @@ static int launch_poolin(const ConvArgs* a, int tn, hipStream_t st) {
         a->OH != (a->H - 3) / 2 + 1 || a->OW != (a->W - 3) / 2 + 1 || a->M != (long long)a->N * a->OH * a->OW || a->M >= 0x7fffff00LL ||
         (long long)a->W * a->Cin * 4 * 3 >= 0x7fffffffLL)
         return TISE_ERR_INVALID_ARG;
-    const int bn = 32 * tn;
-    const long long tiles = ((a->M + CS_BM - 1) / CS_BM) * ((a->Cout + bn - 1) / bn);
+    (void)tn;                                                 // the tile width follows from Cout: one 128-cout tile, else 256-cout tiles
+    const int tnw = a->Cout <= 128 ? 2 : 4;
+    const int bn = 64 * tnw;
+    const long long tiles = ((a->M + 63) / 64) * ((a->Cout + bn - 1) / bn);
     if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)tiles), block(256);
-    switch (tn) {
-        case 2: hipLaunchKernelGGL(conv_poolin_kernel<2>, grid, block, 0, st, *a); break;
-        case 3: hipLaunchKernelGGL(conv_poolin_kernel<3>, grid, block, 0, st, *a); break;
-        case 4: hipLaunchKernelGGL(conv_poolin_kernel<4>, grid, block, 0, st, *a); break;
-        default: return TISE_ERR_INVALID_ARG;
-    }
+    if (tnw == 2) hipLaunchKernelGGL(conv_poolin_kernel<2>, grid, block, 0, st, *a);
+    else hipLaunchKernelGGL(conv_poolin_kernel<4>, grid, block, 0, st, *a);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
