@@ -183,28 +183,42 @@ __global__ __launch_bounds__(256) void avgpool3_bias_relu_split_colwalk_kernel(c
     _Float16* obase = out + ((size_t)n * H * W + w) * (size_t)(2 * out_C) + tise_ilv_off(ch, out_C);
     const int osecond = tise_ilv_second(ch, out_C);
     const size_t ostride = (size_t)W * 2 * out_C;
-    float hs[3][8];                                           // horizontal sums of rows y - 1, y, y + 1 (rotating)
-#define AP_HSUM(DST, ROW)                                                                                  \
+    // raw taps (left, centre, right; 8 channels each) of one input row, and their horizontal sum
+    struct Taps { float4 l0, l1, c0, c1, r0, r1; };
+#define AP_LOAD(T, ROW)                                                                                    \
     {                                                                                                      \
         const float4* q = reinterpret_cast<const float4*>(base + (size_t)(ROW) * rstride);                  \
-        const float4 c0 = q[0], c1 = q[1];                                                                  \
-        float4 l0 = make_float4(0.f, 0.f, 0.f, 0.f), l1 = l0, r0 = l0, r1 = l0;                             \
-        if (hasl) { const float4* ql = reinterpret_cast<const float4*>(base + (size_t)(ROW) * rstride - x_ld); l0 = ql[0]; l1 = ql[1]; } \
-        if (hasr) { const float4* qr = reinterpret_cast<const float4*>(base + (size_t)(ROW) * rstride + x_ld); r0 = qr[0]; r1 = qr[1]; } \
-        DST[0] = (l0.x + c0.x) + r0.x; DST[1] = (l0.y + c0.y) + r0.y; DST[2] = (l0.z + c0.z) + r0.z; DST[3] = (l0.w + c0.w) + r0.w; \
-        DST[4] = (l1.x + c1.x) + r1.x; DST[5] = (l1.y + c1.y) + r1.y; DST[6] = (l1.z + c1.z) + r1.z; DST[7] = (l1.w + c1.w) + r1.w; \
+        T.c0 = q[0]; T.c1 = q[1];                                                                           \
+        T.l0 = T.l1 = T.r0 = T.r1 = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
+        if (hasl) { const float4* ql = reinterpret_cast<const float4*>(base + (size_t)(ROW) * rstride - x_ld); T.l0 = ql[0]; T.l1 = ql[1]; } \
+        if (hasr) { const float4* qr = reinterpret_cast<const float4*>(base + (size_t)(ROW) * rstride + x_ld); T.r0 = qr[0]; T.r1 = qr[1]; } \
     }
+#define AP_HSUM(DST, T)                                                                                    \
+    {                                                                                                      \
+        DST[0] = (T.l0.x + T.c0.x) + T.r0.x; DST[1] = (T.l0.y + T.c0.y) + T.r0.y; DST[2] = (T.l0.z + T.c0.z) + T.r0.z; DST[3] = (T.l0.w + T.c0.w) + T.r0.w; \
+        DST[4] = (T.l1.x + T.c1.x) + T.r1.x; DST[5] = (T.l1.y + T.c1.y) + T.r1.y; DST[6] = (T.l1.z + T.c1.z) + T.r1.z; DST[7] = (T.l1.w + T.c1.w) + T.r1.w; \
+    }
+    float hs[3][8];                                           // horizontal sums of rows y - 1, y, y + 1 (rotating)
+    Taps tn, tnn;                                             // raw taps of rows y + 1 and y + 2: requested one row ahead of their use
+    tn.l0 = tn.l1 = tn.c0 = tn.c1 = tn.r0 = tn.r1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    tnn = tn;
 #pragma unroll
     for (int i = 0; i < 8; ++i) hs[0][i] = 0.f;               // the row above the image
-    AP_HSUM(hs[1], 0)
+    {
+        Taps t0;
+        AP_LOAD(t0, 0)
+        if (H > 1) AP_LOAD(tn, 1)
+        AP_HSUM(hs[1], t0)
+    }
     float vmax = 0.f;
+    const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
     for (int y = 0; y < H; ++y) {
-        if (y + 1 < H) { AP_HSUM(hs[2], y + 1) }
+        if (y + 2 < H) AP_LOAD(tnn, y + 2)                    // in flight while row y is finished below
+        if (y + 1 < H) { AP_HSUM(hs[2], tn) }
         else {
 #pragma unroll
             for (int i = 0; i < 8; ++i) hs[2][i] = 0.f;
         }
-        const float bs[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         half8v hi, lo;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -218,7 +232,9 @@ __global__ __launch_bounds__(256) void avgpool3_bias_relu_split_colwalk_kernel(c
         *reinterpret_cast<half8v*>(d + osecond) = lo;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { hs[0][i] = hs[1][i]; hs[1][i] = hs[2][i]; }
+        tn = tnn;
     }
+#undef AP_LOAD
 #undef AP_HSUM
     tise_flag_split_overflow(vmax);
 }
@@ -233,14 +249,18 @@ __global__ __launch_bounds__(256) void avgpool3_bias_relu_split_colwalk_kernel(c
 __global__ __launch_bounds__(256) void maxpool3s2_split_kernel(const _Float16* __restrict__ x, int x_C, int x_off,
                                                                int N, int H, int W, int C8,
                                                                _Float16* __restrict__ out, int out_C, int out_off) {
+    // one (pooled pixel, 8 channels) element per thread, image = blockIdx.y: two 32-bit divisions per thread (the
+    // grid-stride form spent ~330 of its ~560 vector instructions per element on four 64-bit divisions)
     const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
-    const int64_t total = (int64_t)N * OH * OW * C8;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p = e / C8;
-        const int c8 = (int)(e - p * C8);
-        const int ow = (int)(p % OW);
-        const int oh = (int)((p / OW) % OH);
-        const int64_t n = p / ((int64_t)OW * OH);
+    const unsigned per_img = (unsigned)OH * (unsigned)OW * (unsigned)C8;
+    const unsigned e = blockIdx.x * 256u + threadIdx.x;
+    if (e >= per_img) return;
+    const unsigned pix = e / (unsigned)C8;
+    const int c8 = (int)(e - pix * (unsigned)C8);
+    const unsigned oh = pix / (unsigned)OW, ow = pix - oh * (unsigned)OW;
+    const int64_t n = blockIdx.y;
+    const int64_t p = n * OH * OW + pix;
+    {
         const int64_t base = (n * H + 2 * oh) * W + 2 * ow;
         const int xo = tise_ilv_off(x_off + 8 * c8, x_C), xs = tise_ilv_second(x_off + 8 * c8, x_C);
         float bv[8];
@@ -415,25 +435,24 @@ __global__ __launch_bounds__(256) void stem_conv3x3s2_split_u8_kernel(const uint
 // last block): thread = (image, 8 channels), fixed summation order.
 __global__ __launch_bounds__(256) void split_mean_kernel(const _Float16* __restrict__ x, int N, int HW,
                                                          int C8, float* __restrict__ out) {
-    const int64_t total = (int64_t)N * C8;
     const int C = C8 * 8;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = e / C8;
-        const int c8 = (int)(e - n * C8);
-        float acc[8];
+    const int c8 = blockIdx.x * 256 + threadIdx.x;            // one (image = blockIdx.y, 8 channels) element per thread
+    if (c8 >= C8) return;
+    const int64_t n = blockIdx.y;
+    float acc[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-        const _Float16* q = x + n * HW * (int64_t)C * 2 + tise_ilv_off(c8 * 8, C);
-        for (int s = 0; s < HW; ++s) {
-            const half8v vh = *reinterpret_cast<const half8v*>(q + (int64_t)s * C * 2);
-            const half8v vl = *reinterpret_cast<const half8v*>(q + (int64_t)s * C * 2 + 32);
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    const _Float16* q = x + n * HW * (int64_t)C * 2 + tise_ilv_off(c8 * 8, C);
+#pragma unroll 4
+    for (int s = 0; s < HW; ++s) {
+        const half8v vh = *reinterpret_cast<const half8v*>(q + (int64_t)s * C * 2);
+        const half8v vl = *reinterpret_cast<const half8v*>(q + (int64_t)s * C * 2 + 32);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] += (float)vh[i] + (float)vl[i] * (1.f / 2048.f);
-        }
-        float* d = out + n * (int64_t)C + c8 * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] = acc[i] / (float)HW;
+        for (int i = 0; i < 8; ++i) acc[i] += (float)vh[i] + (float)vl[i] * (1.f / 2048.f);
     }
+    float* d = out + n * (int64_t)C + c8 * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = acc[i] / (float)HW;
 }
 
 inline int grid_for(int64_t total) {
@@ -520,7 +539,8 @@ int tise_maxpool3s2_split_nhwc(const void* x_dev, int64_t x_ld, int x_off, int n
         return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
     const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3s2_split_kernel, dim3(grid_for((int64_t)n * oh * ow * (C / 8))), dim3(256), 0,
+    if (n > 65535 || (int64_t)oh * ow * (C / 8) >= 0x7fffff00LL) return TISE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(maxpool3s2_split_kernel, dim3((unsigned)(((int64_t)oh * ow * (C / 8) + 255) / 256), (unsigned)n), dim3(256), 0,
                        (hipStream_t)stream, reinterpret_cast<const _Float16*>(x_dev), (int)x_ld, x_off, n, h, w, C / 8,
                        reinterpret_cast<_Float16*>(out_dev), (int)out_ld, out_off);
     TISE_LAUNCH_CHECK();
@@ -552,7 +572,8 @@ int tise_stem_conv3x3s2_split_u8(const uint8_t* x_dev, const float* lut_dev, int
 int tise_split_mean_nhwc(const void* x_dev, int n, int hw, int C, float* out_dev, void* stream) {
     if (!x_dev || !out_dev || n < 0 || hw <= 0 || C <= 0 || C % 32) return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
-    hipLaunchKernelGGL(split_mean_kernel, dim3(grid_for((int64_t)n * (C / 8))), dim3(256), 0, (hipStream_t)stream,
+    if (n > 65535) return TISE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(split_mean_kernel, dim3((unsigned)((C / 8 + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const _Float16*>(x_dev), n, hw, C / 8, out_dev);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
