@@ -69,6 +69,7 @@ struct tise_frechet {
     hipEvent_t ev[6];         // start | pchol end | gemm end | sytrd end | bisect end | finish end
     hipEvent_t evp[2];        // tise_frechet_prefactor: start | end (on the stream it ran on)
     int prefactored;          // h->lt holds the factor of the matrix given to tise_frechet_prefactor
+    int lt_tri;               // h->lt came from the unpivoted factorisation: LT[a][i] = 0 for i < 64 * (a / 64)
     int pf_rank;
     int last_rank;
 };
@@ -480,6 +481,45 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const double* __restrict_
     const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * GT_BN;
     gemm_tile_64x64<double, double>(A, sam, sak, B, sbk, sbn, M, N, K, m0, n0, acc, lds);
     gemm_tile_store<0>(C, ldc, M, N, m0, n0, acc);
+}
+
+// The two GEMMs of the distance when L^T is block upper triangular (unpivoted factor: LT[a][i] = 0 for i < 64 (a / 64)):
+// the contraction of output row tile m0 starts at k = m0 (half the flops of T1^T = L^T S2), and of M = L^T T1 only the
+// tiles on and above the diagonal are computed (M is symmetric; mirror_upper_kernel fills the rest): a third of its
+// flops.  UPPER = 1: skip tiles with n0 < m0.
+template <int UPPER>
+__global__ __launch_bounds__(256) void gemm_f64_tri_kernel(const double* __restrict__ A, int64_t sam, int64_t sak,
+                                                           const double* __restrict__ B, int64_t sbk, int64_t sbn,
+                                                           double* __restrict__ C, int64_t ldc, int M, int N, int K) {
+    const int m0 = blockIdx.y * GT_BM, n0 = blockIdx.x * GT_BN;
+    if (UPPER && n0 < m0) return;
+    __shared__ double lds[GT_LDS_DOUBLES];
+    double4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int k0 = m0 < K ? m0 : K;                            // rows m0.. of L^T are zero in columns < m0
+    gemm_tile_64x64<double, double>(A + (int64_t)k0 * sak, sam, sak, B + (int64_t)k0 * sbk, sbk, sbn, M, N, K - k0, m0, n0, acc, lds);
+    gemm_tile_store<0>(C, ldc, M, N, m0, n0, acc);
+}
+
+// M (n x n, ld = n): tiles above the diagonal are mirrored into the tiles below it; inside a diagonal tile the two
+// independently computed halves are averaged (as symmetrize_kernel does for a full product)
+__global__ void mirror_upper_kernel(double* __restrict__ M, int n) {
+    const int64_t total = (int64_t)n * n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / n), j = (int)(e % n);
+        if (i <= j) continue;
+        if ((i >> 6) == (j >> 6)) {
+            const double a = M[(int64_t)i * n + j], b = M[(int64_t)j * n + i];
+            const double s2 = 0.5 * (a + b);
+            M[(int64_t)i * n + j] = s2;
+            M[(int64_t)j * n + i] = s2;
+        } else {
+            M[(int64_t)i * n + j] = M[(int64_t)j * n + i];
+        }
+    }
 }
 
 int launch_gemm(const double* A, int64_t sam, int64_t sak, const double* B, int64_t sbk, int64_t sbn, double* C,
@@ -1032,7 +1072,7 @@ int run_chol(tise_frechet* h, const double* S, double off, int* rank_out, hipStr
             TISE_LAUNCH_CHECK();
             TISE_HIP_CHECK(hipMemcpyAsync(&f0, fail, sizeof(int), hipMemcpyDeviceToHost, st));
             TISE_HIP_CHECK(hipStreamSynchronize(st));
-            if (!f0) { *rank_out = d; return TISE_OK; }
+            if (!f0) { *rank_out = d; h->lt_tri = 1; return TISE_OK; }
         }
     }
     return run_pchol(h, S, off, rank_out, st);
@@ -1040,6 +1080,7 @@ int run_chol(tise_frechet* h, const double* S, double off, int* rank_out, hipStr
 
 int run_pchol(tise_frechet* h, const double* S, double off, int* rank_out, hipStream_t st) {
     const int d = h->d;
+    h->lt_tri = 0;                                             // pivoted: the columns of L come in pivot order
     if (d <= 2048) {                                   // blocked path: working copy lives in h->t1
         FrState hs;
         hipLaunchKernelGGL(pchol_copy_kernel, dim3(2048), dim3(256), 0, st, S, d, off, h->t1);
@@ -1278,16 +1319,26 @@ static int frechet_core(tise_frechet_t* h, const double* mu1_dev, const double* 
     int rc = TISE_OK;
     if (r > 0) {
         // T1^T (r x d) = L^T (r x d) * S2 (d x d)
-        rc = launch_gemm(h->lt, d, 1, sigma2_dev, d, 1, h->t1, d, r, d, d, st);
+        const bool tri = h->lt_tri && r == d && getenv("TISE_FRECHET_FULL_GEMM") == nullptr;   // A/B switch: the full products
+        if (tri) hipLaunchKernelGGL(gemm_f64_tri_kernel<0>, dim3(ceil_div(d, GT_BN), ceil_div(r, GT_BM)), dim3(256), 0, st, h->lt,
+                                    (int64_t)d, (int64_t)1, sigma2_dev, (int64_t)d, (int64_t)1, h->t1, (int64_t)d, r, d, d);
+        else rc = launch_gemm(h->lt, d, 1, sigma2_dev, d, 1, h->t1, d, r, d, d, st);
         if (rc != TISE_OK) return rc;
+        TISE_LAUNCH_CHECK();
         if (diag_offset != 0.0) {   // (S2 + off I): T1^T += off * L^T
             hipLaunchKernelGGL(axpy_kernel, dim3(1024), dim3(256), 0, st, h->t1, h->lt, diag_offset, (int64_t)r * d);
             TISE_LAUNCH_CHECK();
         }
         // M (r x r) = L^T * T1 :  M[a][b] = sum_i LT[a][i] * T1T[b][i]
-        rc = launch_gemm(h->lt, d, 1, h->t1, 1, d, h->m, r, r, r, d, st);
-        if (rc != TISE_OK) return rc;
-        hipLaunchKernelGGL(symmetrize_kernel, dim3(1024), dim3(256), 0, st, h->m, r);
+        if (tri) {
+            hipLaunchKernelGGL(gemm_f64_tri_kernel<1>, dim3(ceil_div(r, GT_BN), ceil_div(r, GT_BM)), dim3(256), 0, st, h->lt,
+                               (int64_t)d, (int64_t)1, h->t1, (int64_t)1, (int64_t)d, h->m, (int64_t)r, r, r, d);
+            hipLaunchKernelGGL(mirror_upper_kernel, dim3(1024), dim3(256), 0, st, h->m, r);
+        } else {
+            rc = launch_gemm(h->lt, d, 1, h->t1, 1, d, h->m, r, r, r, d, st);
+            if (rc != TISE_OK) return rc;
+            hipLaunchKernelGGL(symmetrize_kernel, dim3(1024), dim3(256), 0, st, h->m, r);
+        }
         TISE_LAUNCH_CHECK();
         if (h->profiling && r > 1) TISE_HIP_CHECK(hipEventRecord(h->ev[2], st));
         rc = run_eigvalsh_inplace(h, r, st);
