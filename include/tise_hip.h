@@ -204,6 +204,14 @@ int tise_stem_conv3x3s2_split(const float* x_dev, int n, int h, int w, const flo
  * while loading; bit-identical to the fp32 entry point on the table's values. */
 int tise_stem_conv3x3s2_split_u8(const uint8_t* x_dev, const float* lut_dev, int n, int h, int w, const float* w_dev,
                                  const float* bias_dev, void* out_dev, void* stream);
+/* Round 3: the same layer on the matrix cores (K = 27 padded to 32 = one K-step of the split-precision scheme).
+ * wsplit_dev: fp16 [2][32 couts][32 k] (hi plane, lo plane) of the BatchNorm-folded weights, each cout pre-scaled by a
+ * power of two, in the kernel's K order: k = 16 (u / 8) + 8 h + u % 8 for half h in {0, 1} and slot u in 0..15, where
+ * (h = 0, u < 9) = tap (kh 0, t = u), (0, u >= 9) = (kh 1, t = u - 9), (1, u < 9) = (kh 2, t = u), (1, u = 9, 10) = (kh 1,
+ * t = 7, 8), all other slots zero; t = 3 kw + cin.  scale_dev[32] undoes the pre-scaling, bias_dev[32]; w >= 5, x_dev
+ * 4-byte aligned.  Same values as the entry point above to split-precision accuracy (not the same bits). */
+int tise_stem_conv3x3s2_split_u8_mfma(const uint8_t* x_dev, const float* lut_dev, int n, int h, int w, const void* wsplit_dev,
+                                      const float* scale_dev, const float* bias_dev, void* out_dev, void* stream);
 /* Global average of a split tensor (n, hw, C), C % 32 == 0 -> fp32 (n, C): AdaptiveAvgPool2d((1,1)) of the last block. */
 int tise_split_mean_nhwc(const void* x_dev, int n, int hw, int C, float* out_dev, void* stream);
 

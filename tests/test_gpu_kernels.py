@@ -680,6 +680,36 @@ def test_split_trunk_fused_pools_do_not_change_a_bit(dev, monkeypatch):
     assert torch.equal(fused(x), plain(x))
 
 
+def test_stem_mfma_kernel_matches_fp64_and_the_fma_kernel(dev):
+    """The stem layer on the matrix cores (stem_mfma_u8_kernel: K = 27 taps as ONE split-precision K-step, weights in
+    registers, the byte -> (hi, lo) table as one LDS gather per value) against an fp64 convolution of the table values and
+    against the fp32-FMA kernel: odd sizes, the last pixels of the tensor (byte-wise run loader), M tails, one image."""
+    import ctypes
+    from tise_toolbox_amd import _lib
+    from tise_toolbox_amd.conv_split import merge
+    from tise_toolbox_amd.trunk import pack_stem_mfma
+    g = torch.Generator(device="cpu").manual_seed(5)
+    st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    for (n, H, W) in [(3, 299, 299), (1, 3, 5), (2, 9, 7), (5, 31, 64), (1, 300, 299)]:
+        u8 = torch.randint(0, 256, (n, H, W, 3), generator=g, dtype=torch.uint8).to(dev)
+        lut = (torch.rand(3 * 256, generator=g) * 2.4 - 1.2).to(dev)
+        w = (torch.randn((32, 3, 3, 3), generator=g) * (2.0 / 27) ** 0.5 * torch.exp2(torch.randint(-3, 4, (32, 1, 1, 1), generator=g).float())).to(dev)
+        b = (torch.randn(32, generator=g) * 0.2).to(dev)
+        oh, ow = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+        wsp, scale = pack_stem_mfma(w, dev)
+        out = torch.full((n, oh, ow, 64), 3.0, dtype=torch.float16, device=dev)
+        _lib.call("tise_stem_conv3x3s2_split_u8_mfma", P(u8), P(lut), n, H, W, P(wsp), P(scale), P(b), P(out), st())
+        wf = w.permute(2, 3, 1, 0).contiguous()
+        out_f = torch.full_like(out, 3.0)
+        _lib.call("tise_stem_conv3x3s2_split_u8", P(u8), P(lut), n, H, W, P(wf), P(b), P(out_f), st())
+        x = torch.stack([lut.view(3, 256)[c][u8[..., c].long()] for c in range(3)], 1).double()         # (n, 3, H, W)
+        ref = torch.relu(torch.conv2d(x, w.double(), b.double(), 2)).permute(0, 2, 3, 1)
+        scale_ref = ref.abs().max().item()
+        assert (merge(out).double() - ref).abs().max().item() <= 4e-6 * scale_ref, (n, H, W)
+        assert (merge(out_f).double() - ref).abs().max().item() <= 4e-6 * scale_ref
+
+
 def test_split_trunk_batch_sizes_and_determinism(dev):
     """pool3 features must not depend on how images are batched, and must repeat bit for bit."""
     from tise_toolbox_amd.inception import InceptionV3

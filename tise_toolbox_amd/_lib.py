@@ -82,6 +82,8 @@ SIGNATURES = {
     "tise_stem_conv3x3s2_split": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "tise_stem_conv3x3s2_split_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                               c_void_p]),
+    "tise_stem_conv3x3s2_split_u8_mfma": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                                   c_void_p, c_void_p]),
     "tise_split_mean_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "tise_conv_split_f16": (c_int, [c_void_p, c_int, c_void_p]),
     "tise_split_overflow_check": (c_int, [POINTER(c_int), c_void_p]),

@@ -10,6 +10,7 @@
 // within +-3 % of the default `fast` kernel in the bench (profiles/r01g_conv_pipe_probe.txt, r01i_conv_spec_probe.txt)
 // and were removed in round 2 together with their tests; the measurements stay in profiles/ and DESIGN.md.
 #include <stdlib.h>
+#include <string.h>
 #include <hip/hip_fp16.h>
 #include "common.h"
 #include "conv_epilogue.h"
@@ -555,7 +556,166 @@ int launch_win32(const ConvArgs* a, hipStream_t st) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Stem convolution Conv2d_1a_3x3 (3 -> 32 channels, 3x3, stride 2, valid; inception.py:60) on the matrix cores, from
+// the Pillow-exact uint8 image of the resize kernel.  The fp32-FMA form (trunk_ops.hip) spends, per output pixel, 108
+// table look-ups and 216 weight reads in LDS: it is bound by LDS operations (~80 per wave and 16 pixels), not by its
+// 2.8 GB of output per 1000 images.  Here K = 27 taps padded to 32 is ONE K-step of the split-precision MFMA scheme of
+// every other layer: the weights are 4 B-fragments in registers, and an input value costs one LDS gather -- the table
+// holds the (hi, lo) fp16 pair of a byte's value as one dword -- and one v_perm per pair.
+// K layout (chosen so that a lane's bytes sit at compile-time positions of two short runs): lane half h = lane >> 5
+// of pixel (lane & 31) owns 16 slots u:  h = 0: u < 9 -> tap (kh 0, t = u), u >= 9 -> (kh 1, t = u - 9);  h = 1: u < 9 ->
+// (kh 2, t = u), u = 9, 10 -> (kh 1, t = 7, 8), the rest zero weights;  t = 3 kw + cin;  MFMA k = 16 (u / 8) + 8 h + u % 8.
+// The host packs the weights in that order (trunk.py: pack_stem_mfma).  Results are those of a split-precision layer
+// (error ~1e-6 of the scale against fp64, like the other layers), not the bits of the fp32-FMA form.
+__global__ __launch_bounds__(256) void stem_mfma_u8_kernel(const uint8_t* __restrict__ x, const float* __restrict__ lut,
+                                                           int N, int H, int W, const _Float16* __restrict__ wsp,
+                                                           const ConvArgs p) {
+    constexpr int STG = conv_epi::Staging<1>::BYTES;
+    __shared__ unsigned lut2[3 * 256];                       // (hi | lo << 16) of the network input value per channel and byte
+    __shared__ __attribute__((aligned(16))) unsigned char epi[2048 + 4 * STG];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 3 * 256; i += 256) {
+        const float v = lut[i];
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)((v - (float)hi) * 2048.0f);
+        lut2[i] = (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+    }
+    {
+        conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
+        if (tid < 8) {
+            sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + 4 * tid);
+            bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + 4 * tid);
+        }
+        conv_epi::prepare<32>(p, epi, 0, sc_pre, bs_pre);
+    }
+    // weight fragments: cout = lane & 31, k = 16 s + 8 (lane >> 5) + 0..7; planes hi / lo of [32 couts][32 k]
+    half8_t bw[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        bw[s2][0] = *reinterpret_cast<const half8_t*>(wsp + (lane & 31) * 32 + s2 * 16 + (lane >> 5) * 8);
+        bw[s2][1] = *reinterpret_cast<const half8_t*>(wsp + 1024 + (lane & 31) * 32 + s2 * 16 + (lane >> 5) * 8);
+    }
+    __syncthreads();
+    const int OH = (H - 3) / 2 + 1, OW = (W - 3) / 2 + 1;
+    const unsigned M32 = (unsigned)p.M, ohw = (unsigned)(OH * OW);
+    const unsigned ntiles = (M32 + 31u) / 32u;
+    const int h = lane >> 5;
+    const int row_bytes = W * 3;
+    const uint8_t* x_end = x + (int64_t)N * H * W * 3;
+    const unsigned lutb = (unsigned)(unsigned long long)(lds_ptr_t)lut2;
+    unsigned char* stage = epi + 2048 + wave * STG;
+// the two runs of this lane for tile T: REQUESTED one tile ahead of their use (raw aligned dwords + shift; the funnel
+// shift that consumes them runs at the top of the next iteration): the chain load -> gather -> MFMA -> epilogue -> store
+// of a tile is ~2 us of latency, and with the next tile's bytes already in flight the waves overlap it
+#define STEM_FETCH(T, D1, S1, D2, S2)                                                                      \
+    {                                                                                                      \
+        const unsigned pix = (T) * 32u + (unsigned)(lane & 31);                                            \
+        const unsigned pp = pix < M32 ? pix : 0u;             /* rows beyond M compute pixel 0 and are dropped by the epilogue */ \
+        const unsigned n = pp / ohw;                                                                       \
+        const unsigned rem = pp - n * ohw;                                                                 \
+        const unsigned oh = rem / (unsigned)OW, ow = rem - oh * (unsigned)OW;                              \
+        const uint8_t* base = x + (((int64_t)n * H + 2 * oh) * W + 2 * ow) * 3;                            \
+        /* run 1: 9 bytes of row 0 (h = 0) / row 2 (h = 1);  run 2: row 1 from byte 0 (h = 0: 7 used) / byte 7 (h = 1: 2 used) */ \
+        const uint8_t* q1 = base + (h ? 2 * row_bytes : 0);                                                \
+        const uint8_t* q2 = base + row_bytes + (h ? 7 : 0);                                                \
+        STEM_RUN(D1, S1, q1)                                                                               \
+        STEM_RUN(D2, S2, q2)                                                                               \
+    }
+// four aligned dwords that contain the 12 bytes from Q, and the bit offset of Q inside them; the few runs whose aligned
+// window would reach past the end of the tensor are read byte by byte (bytes past the end read as 0: their slots carry
+// no weight)
+#define STEM_RUN(D, S, Q)                                                                                  \
+        {                                                                                                  \
+            const uintptr_t a = reinterpret_cast<uintptr_t>(Q);                                            \
+            const unsigned* w4 = reinterpret_cast<const unsigned*>(a & ~(uintptr_t)3);                     \
+            if (reinterpret_cast<const uint8_t*>(w4) + 16 <= x_end) {                                      \
+                D[0] = w4[0]; D[1] = w4[1]; D[2] = w4[2]; D[3] = w4[3];                                    \
+                S = (int)(a & 3) * 8;                                                                      \
+            } else {                                                                                       \
+                D[0] = D[1] = D[2] = D[3] = 0u;                                                            \
+                for (int bb = 0; bb < 12; ++bb)                                                            \
+                    if ((Q) + bb < x_end) D[bb >> 2] |= (unsigned)(Q)[bb] << (8 * (bb & 3));               \
+                S = 0;                                                                                     \
+            }                                                                                              \
+        }
+#define STEM_ALIGN(R, D, S)                                                                                \
+        {                                                                                                  \
+            const unsigned long long lo64 = ((unsigned long long)D[1] << 32) | D[0], mid64 = ((unsigned long long)D[2] << 32) | D[1], \
+                                     hi64 = ((unsigned long long)D[3] << 32) | D[2];                       \
+            R[0] = (unsigned)(lo64 >> S); R[1] = (unsigned)(mid64 >> S); R[2] = (unsigned)(hi64 >> S);     \
+        }
+    unsigned r1[3], r2[3], d1[4] = {0u, 0u, 0u, 0u}, d2[4] = {0u, 0u, 0u, 0u};
+    int s1 = 0, s2s = 0;
+    const unsigned tile0 = blockIdx.x * 4u + (unsigned)wave, tstep = gridDim.x * 4u;
+    if (tile0 < ntiles) STEM_FETCH(tile0, d1, s1, d2, s2s)
+    for (unsigned tile = tile0; tile < ntiles; tile += tstep) {
+        STEM_ALIGN(r1, d1, s1)
+        STEM_ALIGN(r2, d2, s2s)
+        if (tile + tstep < ntiles) STEM_FETCH(tile + tstep, d1, s1, d2, s2s)
+        // 16 slots -> LUT gathers: slot u < 9: run 1 byte u, channel u % 3;  u >= 9: run 2 byte b = u - 9, channel b % 3
+        // (h = 0) or (b + 1) % 3 (h = 1: its run 2 starts at t = 7; only its first two slots carry weights)
+        unsigned wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int b = u < 9 ? u : u - 9;
+            const unsigned word = (u < 9 ? r1 : r2)[b >> 2];
+            const unsigned byte4 = ((word >> (8 * (b & 3))) & 0xffu) << 2;
+            unsigned addr;
+            if (u < 9) addr = lutb + (unsigned)((u % 3) * 1024) + byte4;
+            else addr = lutb + byte4 + (h ? (unsigned)(((b + 1) % 3) * 1024) : (unsigned)((b % 3) * 1024));
+            asm volatile("ds_read_b32 %0, %1" : "=v"(wv[u]) : "v"(addr));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wv[0]), "+v"(wv[1]), "+v"(wv[2]), "+v"(wv[3]), "+v"(wv[4]), "+v"(wv[5]), "+v"(wv[6]), "+v"(wv[7]),
+                     "+v"(wv[8]), "+v"(wv[9]), "+v"(wv[10]), "+v"(wv[11]), "+v"(wv[12]), "+v"(wv[13]), "+v"(wv[14]), "+v"(wv[15]));
+        float16_t acc_main[1][1], acc_corr[1][1];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { acc_main[0][0][j] = 0.f; acc_corr[0][0][j] = 0.f; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4_t ah, al;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned w0 = wv[s2 * 8 + 2 * q], w1 = wv[s2 * 8 + 2 * q + 1];
+                ah[q] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);     // [w0.lo16, w1.lo16] = hi halves of slots 2q, 2q + 1
+                al[q] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);     // [w0.hi16, w1.hi16] = lo halves
+            }
+            const half8_t a_hi = __builtin_bit_cast(half8_t, ah), a_lo = __builtin_bit_cast(half8_t, al);
+            acc_corr[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[s2][1], a_hi, acc_corr[0][0], 0, 0, 0);
+            acc_main[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[s2][0], a_hi, acc_main[0][0], 0, 0, 0);
+            acc_corr[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[s2][0], a_lo, acc_corr[0][0], 0, 0, 0);
+        }
+        conv_epi::store_tiles_desc<1, 1, false, 32>(p, acc_main, acc_corr, stage, epi, (long long)tile * 32);
+    }
+#undef STEM_FETCH
+#undef STEM_RUN
+#undef STEM_ALIGN
+}
+
 }  // namespace
+
+extern "C" int tise_stem_conv3x3s2_split_u8_mfma(const uint8_t* x_dev, const float* lut_dev, int n, int h, int w, const void* wsplit_dev,
+                                                 const float* scale_dev, const float* bias_dev, void* out_dev, void* stream) {
+    if (!x_dev || !lut_dev || !wsplit_dev || !scale_dev || !bias_dev || !out_dev || n < 0 || h < 3 || w < 5) return TISE_ERR_INVALID_ARG;
+    if (n == 0) return TISE_OK;
+    const int oh = (h - 3) / 2 + 1, ow = (w - 3) / 2 + 1;
+    const long long M = (long long)n * oh * ow;
+    if (M >= 0x7fffff00LL || (long long)n * h * w * 3 < 32 || (reinterpret_cast<uintptr_t>(x_dev) & 3) != 0) return TISE_ERR_UNSUPPORTED;
+    tise_conv_args a;
+    memset(&a, 0, sizeof(a));
+    a.scale = scale_dev; a.bias = bias_dev;
+    a.N = n; a.H = h; a.W = w; a.Cin = 3; a.KH = 3; a.KW = 3; a.SH = 2; a.SW = 2; a.OH = oh; a.OW = ow;
+    a.Cout = 32; a.K = 27; a.Kpad = 32; a.M = M; a.nseg = 1;
+    a.seg[0].c0 = 0; a.seg[0].c1 = 32; a.seg[0].dst = out_dev; a.seg[0].ld = 32; a.seg[0].off = 0; a.seg[0].mode = 0;
+    const long long tiles = (M + 31) / 32;
+    long long grid = (tiles + 3) / 4;
+    if (grid > 8192) grid = 8192;                              // the tables are built once per workgroup
+    hipLaunchKernelGGL(stem_mfma_u8_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x_dev, lut_dev, n, h, w,
+                       reinterpret_cast<const _Float16*>(wsplit_dev), a);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
 
 // cfg 33: LDS-resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; 32 couts per launch).
 // cfg 34: register-resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; Cout = 32 or 64, one launch).

@@ -238,6 +238,32 @@ class FusedTrunk:
         return a.permute(0, 3, 1, 2)
 
 
+def pack_stem_mfma(w, device):
+    """BatchNorm-folded stem weights (32, 3, 3, 3) [cout][cin][kh][kw] -> (fp16 (2, 32, 32) hi / lo planes in the K order of
+    stem_mfma_u8_kernel, fp32 (32,) un-scaling).  Per cout a power-of-two pre-scale keeps both halves normal fp16 (as
+    conv_split.SplitConv); slot u of lane half h: (h 0, u < 9) = (kh 0, t u), (0, u >= 9) = (kh 1, t u - 9), (1, u < 9) =
+    (kh 2, t u), (1, u in 9, 10) = (kh 1, t 7, 8), others zero; t = 3 kw + cin; k = 16 (u // 8) + 8 h + u % 8."""
+    from .conv_split import split_planes
+    w = w.detach().float().cpu()
+    assert tuple(w.shape) == (32, 3, 3, 3)
+    amax = w.abs().reshape(32, -1).amax(1).clamp_min(1e-30)
+    pre = torch.exp2(-torch.floor(torch.log2(amax)))
+    wt = (w * pre.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(32, 3, 9)           # [cout][kh][t = 3 kw + cin]
+    wk = torch.zeros((32, 32), dtype=torch.float32)
+    for h in (0, 1):
+        for u in range(16):
+            if h == 0:
+                kh, t = (0, u) if u < 9 else (1, u - 9)
+            elif u < 9:
+                kh, t = 2, u
+            elif u < 11:
+                kh, t = 1, u - 9 + 7
+            else:
+                continue
+            wk[:, 16 * (u // 8) + 8 * h + u % 8] = wt[:, kh, t]
+    return split_planes(wk).to(device).contiguous(), (1.0 / pre).to(device).contiguous()
+
+
 class SplitTrunk(FusedTrunk):
     """Same graph as ``FusedTrunk`` with every convolution after the Cin=3 stem layer on the hand-written
     split-precision fp16-MFMA kernel (``csrc/conv_split.hip``): activations travel between layers as split
@@ -276,6 +302,9 @@ class SplitTrunk(FusedTrunk):
         # stem weights for the direct kernel: [kh][kw][cin][cout] fp32
         self.stem_w = self.c1a.w.permute(2, 3, 1, 0).contiguous().float()
         assert tuple(self.stem_w.shape) == (3, 3, 3, 32) and self.c1a.stride == (2, 2) and self.c1a.padding == (0, 0)
+        # the stem layer on the matrix cores (csrc/conv_pipe.hip stem_mfma_u8_kernel); TISE_STEM=fma: the fp32-FMA kernel
+        self.stem_mfma = os.environ.get("TISE_STEM", "mfma") == "mfma"
+        self.stem_wsplit, self.stem_scale = pack_stem_mfma(self.c1a.w, self.device)
         self.sblocks = [(kind, {k: sc(v) for k, v in P.items()}) for kind, P in self.blocks]
         # the two stem max-pools are taken inside the operand load of the 1x1 convolutions that consume them
         # (Conv2d_3b; Mixed_5b's fused 1x1): conv_poolin_kernel, bit-identical to pooling first.  TISE_POOL_FUSE=0: separate kernels
@@ -410,8 +439,12 @@ class SplitTrunk(FusedTrunk):
         n, h, w, _ = u8_nhwc.shape
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
         a = self._new(n, oh, ow, 32, u8_nhwc.device)
-        _lib.call("tise_stem_conv3x3s2_split_u8", _p(u8_nhwc), _p(lut_dev), n, h, w, _p(self.stem_w), _p(self.c1a.b), _p(a),
-                  _stream())
+        if self.stem_mfma and w >= 5:
+            _lib.call("tise_stem_conv3x3s2_split_u8_mfma", _p(u8_nhwc), _p(lut_dev), n, h, w, _p(self.stem_wsplit), _p(self.stem_scale),
+                      _p(self.c1a.b), _p(a), _stream())
+        else:
+            _lib.call("tise_stem_conv3x3s2_split_u8", _p(u8_nhwc), _p(lut_dev), n, h, w, _p(self.stem_w), _p(self.c1a.b), _p(a),
+                      _stream())
         return self._after_stem(a)
 
     def _zero_bordered(self, n, hp, wp, c, dev):

@@ -57,3 +57,6 @@ a = torch.rand((N, 8, 8, 4096), device=dev).half()
 f = torch.empty((N, 2048), device=dev)
 print(f"split_mean         {timed(lambda: _lib.call('tise_split_mean_nhwc', p(a), N, 64, 2048, p(f), st())):7.3f} ms")
 print(f"resize u8          {timed(lambda: device.resize_u8_only(u8[:, :256, :256].contiguous(), (299, 299))):7.3f} ms")
+from tise_toolbox_amd.trunk import pack_stem_mfma  # noqa: E402
+wsp, sc = pack_stem_mfma(w.view(3, 3, 3, 32).permute(3, 2, 0, 1).contiguous(), dev)
+print(f"stem u8 (MFMA)     {timed(lambda: _lib.call('tise_stem_conv3x3s2_split_u8_mfma', p(u8), p(lut), N, 299, 299, p(wsp), p(sc), p(b), p(out), st())):7.3f} ms")
