@@ -278,8 +278,8 @@ int tise_gather_rows_f16(const void* x_dev, const int64_t* index_dev, int64_t n,
  *        pixel operand); tn in {2, 3, 4}; weights fp16 [Cout_pad][Kpad / 32][hi x32 | lo x32] in the K order
  *        (kh, 32-channel block, kw), and per kh -- Cin % 32 == 16 -- the 16-channel tails two taps per 32-wide step
  *        last.  Same accuracy as 16 / 128, not the same bits (fp32 summation order).
- *   512  conv_pipe.hip configuration 33: resident-weights sliding-window kernel for Cin = 32 3x3 stride 1;
- *        weights as for 16.
+ *   512  | 34: conv_pipe.hip configuration 34, register-resident-weights sliding-window kernel for Cin = 32, 3x3,
+ *        stride 1, Cout = 32 or 64; weights as for 16.
  *   256  (round 3) POOLED INPUT: the convolution (1x1, stride 1, no padding, Cin % 32 == 0, weights as for 128) reads
  *        max_pool2d(x, 3, stride 2): args->H, W describe the UN-pooled tensor x, args->OH, OW the pooled grid
  *        ((H - 3) / 2 + 1), which is also the output grid; M = N * OH * OW; the low bits of tn are ignored (tiles of 64 pixels x 128 couts when

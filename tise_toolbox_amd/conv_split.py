@@ -124,8 +124,8 @@ def rowwin_fits(ow, kw):
     return -(-rows // 32) in (5, 6)
 
 
-# conv_pipe.hip: configuration 33 = resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1), 32 couts per launch
-PIPE_BN = {33: 32, 34: 64}
+# conv_pipe.hip: configuration 34 = register-resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1), up to 64 couts per launch
+PIPE_BN = {34: 64}
 
 
 class SplitConv:
@@ -146,7 +146,7 @@ class SplitConv:
         self._fallback, self._orig = None, None
         # kernel variant: "fast" = LDS-DMA staging with hoisted addressing (default); "glds" = its generic form
         # (addresses recomputed per K-step, natural K order, any M: the reference kernel of the tests);
-        # "pipe" = conv_pipe.hip configuration 33 (Conv2d_2a)
+        # "pipe" = conv_pipe.hip configuration 34 (Conv2d_2a, Conv2d_2b)
         # "rowwin" = row-window kernel (the kw taps of a filter row share one fetch of the pixel operand); "auto" (the
         # default) = rowwin where it applies and measured faster (tools/conv_rowwin_probe.py), else fast
         self.variant = variant or os.environ.get("TISE_CONV_VARIANT", "auto")
@@ -157,7 +157,7 @@ class SplitConv:
         # rows of zero weights / scale / bias up to the widest tile grid any tile width may use
         self.cout_pad = max(-(-cout // (32 * t)) * 32 * t for t in (1, 2, 3, 4, 5))
         if self.variant == "pipe":                              # resident-weights sliding-window kernel (conv_pipe.hip)
-            self.pipe_cfg = 33 if pipe_cfg is None else pipe_cfg
+            self.pipe_cfg = 34 if pipe_cfg is None else pipe_cfg
         self.k = kh * kw * cin
         self.kpad = -(-self.k // 32) * 32
         w = weight.detach().float().cpu()

@@ -13,6 +13,7 @@
 // No workgroup barrier: a wave's LDS operations execute in order, and nothing else touches its staging area.
 #pragma once
 #include <hip/hip_fp16.h>
+#include <type_traits>
 #include "common.h"
 
 namespace conv_epi {
@@ -21,6 +22,22 @@ typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+// Accumulator of a 32-pixel x 32-cout wave tile held as four 16 x 16 blocks of v_mfma_f32_16x16x32_f16 (weight fragment
+// first): v[ci][pi] = couts 16 ci .. +15 x pixels 16 pi .. +15; a lane holds pixel 16 pi + (lane & 15) and the four
+// CONSECUTIVE couts 16 ci + 4 (lane >> 4) + k, i.e. half ((lane >> 4) & 1) of the tile's 8-cout chunk 2 ci + (lane >> 5).
+// (float16_t = the 32 x 32 block of v_mfma_f32_32x32x16_f16: pixel (lane & 31), couts 8 g + 4 (lane >> 5) + k.)
+struct Acc16 {
+    float4_t v[2][2];
+};
+__device__ __forceinline__ void acc_zero(Acc16& a) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.v[i >> 1][i & 1] = float4_t{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void acc_zero(float16_t& a) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = 0.f;
+}
 
 
 // Tile row -> output pixel index (or -1).  GRID = false: tile rows are output pixels.  GRID = true (window
@@ -109,11 +126,12 @@ __device__ __forceinline__ void prepare(const tise_conv_args& p, unsigned char* 
 // BN_AREA: tile width the descriptor area was prepared for (default: this wave's TNW tiles are the whole tile);
 // chunk0: first 8-cout chunk of this wave inside the tile (wave layouts with more than one wave along the couts).
 // nyx (GRID only): {n, y, x} of grid pixel m0w + (lane / lanes-per-row), when the caller tracks it incrementally.
-template <int TNW, int TW, bool GRID = false, int BN_AREA = 32 * TNW>
-__device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float16_t (&acc_main)[1][TNW],
-                                                 float16_t (&acc_corr)[1][TNW], unsigned char* tw,
+template <int TNW, int TW, bool GRID = false, int BN_AREA = 32 * TNW, class ACC = float16_t>
+__device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, ACC (&acc_main)[1][TNW],
+                                                 ACC (&acc_corr)[1][TNW], unsigned char* tw,
                                                  const unsigned char* area, long long m0w, int chunk0 = 0,
                                                  const unsigned* nyx = nullptr) {
+    constexpr bool L16 = std::is_same<ACC, Acc16>::value;        // accumulator layout (see Acc16)
     constexpr int BN = BN_AREA;
     constexpr int PITCH = Staging<TW>::PITCH;
     const int lane = threadIdx.x & 63;
@@ -123,52 +141,105 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, float1
 #pragma unroll
     for (int t0 = 0; t0 < TNW; t0 += TW) {
         const int nt = (TNW - t0) < TW ? (TNW - t0) : TW;
-        unsigned char* trow = tw + (lane & 31) * PITCH;
-        // mode, scale and bias of the group's 4 * nt chunks are requested in ONE batch before any of them is used: read
-        // chunk by chunk inside the conversion loop, every chunk exposed two or three LDS round trips (scale, mode,
-        // bias behind the mode branch) -- some 300 cycles x 16 chunks per wave and tile at TN = 4, the larger part of the
-        // epilogue's 10-30 % share of a launch (profiles/r01g_conv_ablation.txt)
-        int modes[TW * 4];
-        float4_t scs[TW * 4], bss[TW * 4];
-#pragma unroll
-        for (int u = 0; u < TW; ++u) {
-            if (u >= nt) continue;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int chunk = chunk0 + (t0 + u) * 4 + g;
-                const int ch = chunk * 8 + 4 * (lane >> 5);
-                modes[u * 4 + g] = *reinterpret_cast<const int*>(area + EpiArea<BN>::DESC + chunk * 32 + 24);
-                scs[u * 4 + g] = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::SCALE + ch * 4);
-                bss[u * 4 + g] = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::BIAS + ch * 4);
+        if constexpr (!L16) {
+            unsigned char* trow = tw + (lane & 31) * PITCH;
+            // mode, scale and bias of the group's 4 * nt chunks are requested in ONE batch before any of them is used: read
+            // chunk by chunk inside the conversion loop, every chunk exposed two or three LDS round trips (scale, mode,
+            // bias behind the mode branch) -- some 300 cycles x 16 chunks per wave and tile at TN = 4, the larger part of the
+            // epilogue's 10-30 % share of a launch (profiles/r01g_conv_ablation.txt)
+            int modes[TW * 4];
+            float4_t scs[TW * 4], bss[TW * 4];
+    #pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                if (u >= nt) continue;
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int chunk = chunk0 + (t0 + u) * 4 + g;
+                    const int ch = chunk * 8 + 4 * (lane >> 5);
+                    modes[u * 4 + g] = *reinterpret_cast<const int*>(area + EpiArea<BN>::DESC + chunk * 32 + 24);
+                    scs[u * 4 + g] = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::SCALE + ch * 4);
+                    bss[u * 4 + g] = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::BIAS + ch * 4);
+                }
             }
-        }
-#pragma unroll
-        for (int u = 0; u < TW; ++u) {
-            if (u >= nt) continue;
-            const int t = t0 + u;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int mode = __builtin_amdgcn_readfirstlane(modes[u * 4 + g]);
-                const float4_t sc = scs[u * 4 + g];
-                float4_t v;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    v[k] = (acc_main[0][t][4 * g + k] + acc_corr[0][t][4 * g + k] * (1.0f / 2048.0f)) * sc[k];
-                unsigned char* slot = trow + u * 128 + g * 32;
-                if (mode == 0) {
-                    const float4_t bs = bss[u * 4 + g];
-                    half4_t hi, lo;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float r = fmaxf(v[k] + bs[k], 0.f);
-                        vmax = fmaxf(vmax, r);
-                        hi[k] = (_Float16)r;
-                        lo[k] = (_Float16)((r - (float)hi[k]) * 2048.0f);
+    #pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                if (u >= nt) continue;
+                const int t = t0 + u;
+    #pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int mode = __builtin_amdgcn_readfirstlane(modes[u * 4 + g]);
+                    const float4_t sc = scs[u * 4 + g];
+                    float4_t v;
+    #pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        v[k] = (acc_main[0][t][4 * g + k] + acc_corr[0][t][4 * g + k] * (1.0f / 2048.0f)) * sc[k];
+                    unsigned char* slot = trow + u * 128 + g * 32;
+                    if (mode == 0) {
+                        const float4_t bs = bss[u * 4 + g];
+                        half4_t hi, lo;
+    #pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float r = fmaxf(v[k] + bs[k], 0.f);
+                            vmax = fmaxf(vmax, r);
+                            hi[k] = (_Float16)r;
+                            lo[k] = (_Float16)((r - (float)hi[k]) * 2048.0f);
+                        }
+                        *reinterpret_cast<half4_t*>(slot + (lane >> 5) * 8) = hi;
+                        *reinterpret_cast<half4_t*>(slot + 16 + (lane >> 5) * 8) = lo;
+                    } else {
+                        *reinterpret_cast<float4_t*>(slot + (lane >> 5) * 16) = v;
                     }
-                    *reinterpret_cast<half4_t*>(slot + (lane >> 5) * 8) = hi;
-                    *reinterpret_cast<half4_t*>(slot + 16 + (lane >> 5) * 8) = lo;
-                } else {
-                    *reinterpret_cast<float4_t*>(slot + (lane >> 5) * 16) = v;
+                }
+            }
+        } else {
+            // 16 x 16 blocks: per tile and cout half ci a lane owns ONE half-chunk (4 couts) of chunk 2 ci + (lane >> 5), for the
+            // two pixels (lane & 15) and 16 + (lane & 15).  Segments start on multiples of 8 couts, so the two chunks a wave
+            // converts together may belong to segments of different modes: the mode is per lane (exec-masked branches)
+            unsigned char* trow = tw + (lane & 15) * PITCH;
+            const int sub = (lane >> 4) & 1;
+            int modes[TW * 2];
+            float4_t scs[TW * 2], bss[TW * 2];
+#pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                if (u >= nt) continue;
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    const int chunk = chunk0 + (t0 + u) * 4 + ci * 2 + (lane >> 5);
+                    const int ch = chunk * 8 + 4 * sub;
+                    modes[u * 2 + ci] = *reinterpret_cast<const int*>(area + EpiArea<BN>::DESC + chunk * 32 + 24);
+                    scs[u * 2 + ci] = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::SCALE + ch * 4);
+                    bss[u * 2 + ci] = *reinterpret_cast<const float4_t*>(area + EpiArea<BN>::BIAS + ch * 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TW; ++u) {
+                if (u >= nt) continue;
+                const int t = t0 + u;
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    const int mode = modes[u * 2 + ci];
+                    const float4_t sc = scs[u * 2 + ci], bs = bss[u * 2 + ci];
+#pragma unroll
+                    for (int pi = 0; pi < 2; ++pi) {
+                        float4_t v;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = (acc_main[0][t].v[ci][pi][k] + acc_corr[0][t].v[ci][pi][k] * (1.0f / 2048.0f)) * sc[k];
+                        unsigned char* slot = trow + pi * 16 * PITCH + u * 128 + (ci * 2 + (lane >> 5)) * 32;
+                        if (mode == 0) {
+                            half4_t hi, lo;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float r = fmaxf(v[k] + bs[k], 0.f);
+                                vmax = fmaxf(vmax, r);
+                                hi[k] = (_Float16)r;
+                                lo[k] = (_Float16)((r - (float)hi[k]) * 2048.0f);
+                            }
+                            *reinterpret_cast<half4_t*>(slot + sub * 8) = hi;
+                            *reinterpret_cast<half4_t*>(slot + 16 + sub * 8) = lo;
+                        } else {
+                            *reinterpret_cast<float4_t*>(slot + sub * 16) = v;
+                        }
+                    }
                 }
             }
         }

@@ -1,14 +1,16 @@
-// Persistent, wave-specialised form of the split-precision convolution (conv_split.hip explains the arithmetic:
-// v ~= hi + lo * 2^-11, three fp16 MFMAs per product, fp32 accumulate; same activation layout, same results up
-// to fp32 summation order).  One kernel lives here:
+// Sliding-window forms of the split-precision convolution for the 32-channel 3x3 layers of the stem, and the stem layer
+// itself (conv_split.hip explains the arithmetic: v ~= hi + lo * 2^-11, three fp16 MFMAs per product, fp32 accumulate; same
+// activation layout, same results):
 //
-//   conv_win32_kernel   (configuration 33)  resident-weights sliding-window kernel for Cin = 32, 3x3, stride 1:
-//                       the default for Conv2d_2a (1.34 -> 1.05 ms at batch 500).
+//   conv_regw32_kernel   (configuration 34)  register-resident-weights sliding-window kernel for Cin = 32, 3x3, stride 1
+//                        (Conv2d_2a, Conv2d_2b)
+//   stem_mfma_u8_kernel                       Conv2d_1a (3 -> 32, 3x3 stride 2) straight from the uint8 pixels
 //
-// Round 1 also carried a 3-stage persistent kernel (ping-pong and lockstep schedules, configurations 0-10), its
-// window-resident form (7, 11-15) and wave-specialised 128- / 256-pixel configurations (40-47).  All of them measured
-// within +-3 % of the default `fast` kernel in the bench (profiles/r01g_conv_pipe_probe.txt, r01i_conv_spec_probe.txt)
-// and were removed in round 2 together with their tests; the measurements stay in profiles/ and DESIGN.md.
+// Removed, with their measurements kept in profiles/ and DESIGN.md: round 1's 3-stage persistent kernels (configurations
+// 0-15, 40-47; within +-3 % of the default kernel); round 2's LDS-resident-weights window kernel (configuration 33; 1.05 ms
+// per 500 images of Conv2d_2a against 0.85 for configuration 34); round 3's two re-phased forms of configuration 34
+// (configuration 35: two independent four-wave workgroups per CU 1.55 ms, the halves of one workgroup locked in anti-phase
+// by the barrier 1.73 ms, against 1.59-1.65 ms for Conv2d_2b: DESIGN 4b).
 #include <stdlib.h>
 #include <string.h>
 #include <hip/hip_fp16.h>
@@ -33,224 +35,21 @@ __device__ __attribute__((aligned(64))) unsigned char g_pipe_zero_page[64];
 __device__ __forceinline__ bool wrap_guard(long long tile, long long ntiles) { return tile < ntiles; }
 
 // ------------------------------------------------------------------------------------------------
-// Resident-weights sliding-window kernel for the two 32-channel 3x3 layers of the stem (Conv2d_2a 149^2 x 32 -> 32
-// valid, Conv2d_2b 147^2 x 32 -> 64 padded, as two 32-cout launches; 3.0 of the trunk's 21.5 conv ms).  With
-// Cin = 32 a K-step is one tap, 6 MFMAs per wave per 32 couts, and the per-tap implicit GEMM moves 16 KB of pixels
-// + 4 KB of weights for it: 5-6x more DMA cycles than MFMA cycles.  Here, per workgroup (8 waves, one per CU,
-// persistent over a CONTIGUOUS run of 128-pixel tiles of the input grid):
-//   * the weights of all 9 taps (36 KB) are DMA'd once and stay in LDS;
-//   * the input lives in a RING of 128 + 2W + 2 (+ 256) grid pixels, one 128-byte line [hi x32 | lo x32] each (the
-//     activation layout itself: a DMA piece is 1 KB of consecutive memory): a tap is a row offset (kh-PH)*W + (kw-PW)
-//     into it, and a new tile only adds the 128 grid pixels behind the previous window (16 KB instead of 9 x 16 KB
-//     per tile), fetched two tiles ahead;
-//   * waves 0-3 (one per SIMD) do nothing but fragment reads and MFMAs -- 54 back-to-back MFMAs per tile, the next
-//     tap's fragments requested before the current tap's MFMAs -- and hand the combined fp32 accumulators to LDS;
-//   * waves 4-7 issue the DMA (an LDS-DMA instruction holds its wave ~125 cycles once the queue is full) and run
-//     the epilogue of the PREVIOUS tile from the hand-off buffer (scale, bias, ReLU, re-split, 16-byte stores),
-//     so neither ever stalls the MFMA stream;
-//   * one workgroup barrier per tile.
-// Ordering per tile `it` (barrier X(it) at the end of the iteration):
-//   compute waves:  taps(it) from ring rows [128 it, 128 it + R16)  ->  hand-off buffer it & 1
-//   service waves:  epilogue(it-1) from hand-off (it-1) & 1;  DMA of the rows of tile it+2 (they replace the oldest
-//                   128 rows of tile it-1, whose taps ended before X(it-1));  vmcnt(4): the rows of tile it+1 have
-//                   landed (loads return in order, and the only younger loads are the four just issued; the
-//                   epilogue's stores were issued BEFORE them, so they can only make the wait longer)
-// Border handling as the other window kernels (valid: grid pixels without an output are computed and dropped;
-// padded: fragments masked per lane and tap).
-template <int KHC, int KWC>
-__global__ __launch_bounds__(512, 1) void conv_win32_kernel(const ConvArgs p, const int R16, const long long ntiles,
-                                                            const int n0) {
-    constexpr int BN = 32;
-    constexpr int B_PLANE = BN * 64;                      // one plane of one tap's weight tile
-    constexpr int B_TAP = 2 * B_PLANE;
-    constexpr int ntaps = KHC * KWC;                      // compile-time filter: the tap loop is fully unrolled
-    constexpr int HAND = conv_epi::Staging<1>::BYTES;     // hand-off bytes per wave and buffer (>= 4 KB; doubles as staging)
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ring = R16 + 256;                           // rows (a multiple of 16)
-    const int win_bytes = ring * 128;
-    unsigned char* bres = lds;                            // resident weights
-    unsigned char* wbuf = lds + ntaps * B_TAP;            // window ring
-    unsigned char* epi_area = wbuf + win_bytes;           // chunk descriptors + scale / bias, prepared once
-    unsigned char* hand = epi_area + 2048;                // 2 buffers x 4 waves x HAND
-
-    const long long G = (long long)gridDim.x;
-    const long long slot = blockIdx.x;
-    const long long mgrid = (long long)p.N * p.H * p.W;
-    const int minoff = -p.PH * p.W - p.PW;
-    const int cl = (lane & 3) ^ ((lane >> 4) & 3);        // weights: 64-byte rows per plane, chunk ^ (row >> 2) & 3
-    const unsigned char* xg = reinterpret_cast<const unsigned char*>(p.x);
-    const _Float16* wgt = reinterpret_cast<const _Float16*>(p.w);
-    const unsigned char* zp = g_pipe_zero_page;
-
-    // a workgroup walks a contiguous run of tiles
-    const long long per = (ntiles + G - 1) / G;
-    const long long t_begin = slot * per, t_end = (t_begin + per < ntiles) ? t_begin + per : ntiles;
-    if (t_begin >= ntiles) return;
-    const long long g_base = t_begin * 128 + minoff;      // grid pixel of relative row 0
-    const long long ntl = t_end - t_begin;
-
-    // resident weights: tap t, plane, 16-row block rb  ->  bres + t * B_TAP + plane * B_PLANE + rb * 1024
-    for (int q = wave; q < ntaps * 4; q += 8) {
-        const int t = q >> 2, r = q & 3;
-        const int plane = r >> 1, rb = r & 1;
-        const _Float16* src = wgt + (plane ? p.w_plane : 0) + (long long)(n0 + rb * 16 + (lane >> 2)) * p.Kpad + t * CP_BK + cl * 8;
-        unsigned char* dst = bres + t * B_TAP + plane * B_PLANE + rb * 1024;
-        __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);
-    }
-// DMA of 2 * NPC 8-row pieces (16 * NPC rows of 128 B) starting at relative row REL0 (relative to g_base; a multiple
-// of 16); physical row = relative row mod ring.  Lane i fills row (i >> 3), physical chunk (i & 7) of its piece and
-// fetches the logical chunk (i & 7) ^ ((physical row >> 1) & 7); chunks 0-3 = hi, 4-7 = lo.
-#define W32_ROWS(REL0, NPC, Q0, QS)                                                                       \
-    {                                                                                                     \
-        for (int q = (Q0); q < 2 * (NPC); q += (QS)) {                                                     \
-            const long long rel = (REL0) + q * 8;                                                          \
-            const long long g = g_base + rel + (lane >> 3);                                                \
-            const bool ok = g >= 0 && g < mgrid;                                                           \
-            const int prow = (int)(rel % ring);                                                            \
-            const int c = (lane & 7) ^ ((((prow >> 3) & 1) << 2) | (lane >> 4));                           \
-            const unsigned char* src = xg + g * 128 + c * 16;                                              \
-            src = ok ? src : zp;                                                                           \
-            unsigned char* dst = wbuf + prow * 128;                                                        \
-            __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)dst, 16, 0, 0);                               \
-        }                                                                                                  \
-    }
-    // window of the first tile and the new rows of the second (R16 + 128 rows), by all eight waves
-    W32_ROWS(0, (R16 >> 4) + 8, wave, 8)
-    {
-        conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
-        if (tid < BN / 4) {
-            sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + n0 + 4 * tid);
-            bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + n0 + 4 * tid);
-        }
-        static_assert(conv_epi::EpiArea<BN>::BYTES <= 2048, "epilogue area");
-        conv_epi::prepare<BN>(p, epi_area, n0, sc_pre, bs_pre);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-
-    if (wave >= 4) {
-        // ---- service waves: DMA two tiles ahead, epilogue one tile behind ------------------------------------
-        const int cw = wave - 4;                           // the compute wave whose tiles this wave finishes
-        for (long long it = 0; it <= ntl; ++it) {          // iteration ntl only drains the last epilogue
-            if (it >= 1 && !(p.nseg & 0x400)) {
-                const unsigned char* hb = hand + ((it - 1) & 1) * 4 * HAND + cw * HAND;
-                float16_t am[1][1], ac[1][1];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const conv_epi::float4_t v = *reinterpret_cast<const conv_epi::float4_t*>(hb + (g * 64 + lane) * 16);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { am[0][0][4 * g + k] = v[k]; ac[0][0][4 * g + k] = 0.f; }
-                }
-                // the hand-off bytes of this wave are consumed (LDS operations of a wave execute in order): reuse them
-                // as the staging tile of the stores
-                conv_epi::store_tiles_desc<1, 1, true>(p, am, ac, const_cast<unsigned char*>(hb), epi_area,
-                                                       (t_begin + it - 1) * 128 + cw * 32);
-            }
-            if (it + 2 < ntl) { W32_ROWS((long long)R16 + (it + 1) * 128, 8, cw, 4) }
-            if (it < ntl) {
-                if (it + 2 < ntl) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();              // X(it)
-                asm volatile("" ::: "memory");
-            }
-        }
-        return;
-    }
-    // ---- compute waves ------------------------------------------------------------------------------------------
-    const int fswz = ((lane & 31) >> 2) & 3;
-    const int fb0 = (lane & 31) * 64 + ((lane >> 5) ^ fswz) * 16;
-    const int fb1 = (lane & 31) * 64 + ((2 + (lane >> 5)) ^ fswz) * 16;
-    const int lrow0 = wave * 32 + (lane & 31) - minoff;   // window row of this lane's tile row at offset 0
-    const unsigned hw = (unsigned)(p.H * p.W);
-    for (long long it = 0; it < ntl; ++it) {
-        const long long tile = t_begin + it;
-        unsigned tapmask = 0xffffffffu;                    // per-lane tap validity (padded convolutions)
-        if (p.PH | p.PW) {
-            const unsigned g = (unsigned)(tile * 128) + wave * 32 + (lane & 31);      // grid pixels < 2^31 (launcher)
-            const unsigned rem = g % hw;
-            const int y = (int)(rem / (unsigned)p.W), x = (int)rem - y * p.W;
-            tapmask = 0u;
-#pragma unroll
-            for (int t = 0; t < ntaps; ++t) {
-                const int yy = y + t / KWC - p.PH, xx = x + t % KWC - p.PW;
-                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) tapmask |= 1u << t;
-            }
-        }
-        float16_t acc_main, acc_corr;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { acc_main[j] = 0.f; acc_corr[j] = 0.f; }
-        const int wstart = (int)((it * 128) % ring);       // physical row of this tile's window row 0
-        half8_t fa_[2][2][2], fb_[2][2][2];
-#define W32_READS(TAP, BUF)                                                                               \
-        {                                                                                                  \
-            const int kh_ = (TAP) / KWC, kw_ = (TAP) % KWC;                                                \
-            int wrow = wstart + lrow0 + (kh_ - p.PH) * p.W + (kw_ - p.PW);                                 \
-            wrow = wrow >= ring ? wrow - ring : wrow;                                                      \
-            const int aswz = (wrow >> 1) & 7;                                                              \
-            const unsigned char* ap = wbuf + wrow * 128;                                                   \
-            const unsigned char* bb = bres + (TAP) * B_TAP;                                                \
-            const unsigned am = (tapmask >> (TAP)) & 1u ? 0xffffffffu : 0u;                                \
-            _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                \
-                const int ao = ((2 * s + (lane >> 5)) ^ aswz) * 16;                                        \
-                u32x4_t ah = *reinterpret_cast<const u32x4_t*>(ap + ao);                                   \
-                u32x4_t al = *reinterpret_cast<const u32x4_t*>(ap + (ao ^ 64));                            \
-                ah &= am; al &= am;                                                                        \
-                fa_[BUF][s][0] = __builtin_bit_cast(half8_t, ah);                                          \
-                fa_[BUF][s][1] = __builtin_bit_cast(half8_t, al);                                          \
-                const unsigned char* bp = bb + (s ? fb1 : fb0);                                            \
-                fb_[BUF][s][0] = *reinterpret_cast<const half8_t*>(bp);                                    \
-                fb_[BUF][s][1] = *reinterpret_cast<const half8_t*>(bp + B_PLANE);                          \
-            }                                                                                              \
-        }
-#define W32_MFMAS(BUF)                                                                                    \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
-            acc_corr = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[BUF][s][1], fa_[BUF][s][0], acc_corr, 0, 0, 0); \
-            acc_main = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[BUF][s][0], fa_[BUF][s][0], acc_main, 0, 0, 0); \
-            acc_corr = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[BUF][s][0], fa_[BUF][s][1], acc_corr, 0, 0, 0); \
-        }
-        if (!(p.nseg & 0x200)) {
-        W32_READS(0, 0)
-#pragma unroll
-        for (int tap = 0; tap < ntaps; ++tap) {
-            if (tap + 1 < ntaps) {
-                if ((tap + 1) & 1) { W32_READS(tap + 1, 1) } else { W32_READS(tap + 1, 0) }
-            }
-            if (tap & 1) { W32_MFMAS(1) } else { W32_MFMAS(0) }
-        }
-        }
-        // hand the combined accumulator over: value j of lane l -> float4 slot (j >> 2) * 64 + l
-        unsigned char* hb = hand + (it & 1) * 4 * HAND + wave * HAND;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            conv_epi::float4_t v;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = acc_main[4 * g + k] + acc_corr[4 * g + k] * (1.0f / 2048.0f);
-            *reinterpret_cast<conv_epi::float4_t*>(hb + (g * 64 + lane) * 16) = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                      // X(it)
-        asm volatile("" ::: "memory");
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Register-resident-weights sliding-window kernel (configuration 34, round 3) for the same two layers: Conv2d_2a
 // (149^2 x 32 -> 32) and Conv2d_2b (147^2 x 32 -> 64, padded).  With Cin = 32 the whole filter of 32 couts is
-// 9 taps x 2 K-slices x (hi, lo) = 36 MFMA B-fragments = 144 VGPRs: every wave keeps the weights of ITS 32 couts in
-// registers for its whole life, so the only operand that moves is the input, once: the ring of conv_win32_kernel
+// 9 taps x 2 cout halves x (hi, lo) = 36 MFMA B-fragments (16 couts x 32 channels each) = 144 VGPRs: every wave keeps the weights of ITS 32 couts in
+// registers for its whole life, so the only operand that moves is the input, once: a sliding ring of grid pixels in LDS
 // (a tile adds the 128 grid pixels behind the previous window: 16 KB of LDS-DMA per 128-pixel tile, against 51 KB of
 // window + 72 KB of weights per tile for the row-window kernel that served Conv2d_2b, where the weight stream alone
 // kept the DMA path as busy as the matrix cores).  No weight tile in LDS also means no hand-off buffer is needed:
 // all eight waves compute AND run their own epilogue, two per SIMD, so one wave's epilogue runs under the other's MFMAs.
 //   wave w: pixel slice (w & 3) of a 128-pixel tile;  COUT = 64: group (w >> 2) owns couts 32*(w >> 2) .. +31 of the
 //   SAME tile (both groups read the same A fragments);  COUT = 32: group (w >> 2) owns tile 2*it + (w >> 2).
-// Per iteration (one barrier): DMA of the new rows two iterations ahead (2 or 4 pieces per wave), 9 taps x 6 MFMAs with
+// Per iteration (one barrier): DMA of the new rows two iterations ahead (2 or 4 pieces per wave), 9 taps x 12 MFMAs (16x16x32) with
 // the next tap's A fragments requested first, `s_waitcnt vmcnt` for the rows of the next iteration, epilogue.
 // Same K order and MFMA sequence as the generic kernel => bit-identical results.  Grid-pixel tiling, border handling
-// and ring arithmetic as conv_win32_kernel above.
+// and ring arithmetic: the tile is 128 consecutive pixels of the INPUT grid (n, y, x); grid pixels without an output are
+// computed and dropped (valid) or their out-of-image taps masked per lane (PADDED).
 // Instruction diet (profiles/r03d_conv_mfma_util.md: the first version ran at VALU:MFMA 13, MFMA util 0.33 -- bound by
 // vector issue, not by the matrix cores or the DMA): tap masks only in the PADDED instance (Conv2d_2b runs UNPADDED on a
 // zero-bordered copy of its input, which Conv2d_2a writes directly: args->out_hp), ring positions and the (n, y, x) of a
@@ -289,17 +88,17 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
     const int nit = (int)(i_end - i_begin);
 
     // ---- this wave's weights -> registers -------------------------------------------------------------------
-    half8_t bw[ntaps][2][2];                              // [tap][K-slice][hi / lo]
+    half8_t bw[ntaps][2][2];                              // [tap][16-cout half][hi / lo]: 16 couts x the tap's 32 channels
     {
         const _Float16* wgt = reinterpret_cast<const _Float16*>(p.w);
-        const int cout = (COUT == 64 ? grp * 32 : 0) + (lane & 31);
-        const _Float16* wrow = wgt + (long long)cout * p.Kpad + (lane >> 5) * 8;
+        const int cout = (COUT == 64 ? grp * 32 : 0) + (lane & 15);
+        const _Float16* wrow = wgt + (long long)cout * p.Kpad + (lane >> 4) * 8;
 #pragma unroll
         for (int t = 0; t < ntaps; ++t)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                bw[t][s2][0] = *reinterpret_cast<const half8_t*>(wrow + t * CP_BK + s2 * 16);
-                bw[t][s2][1] = *reinterpret_cast<const half8_t*>(wrow + p.w_plane + t * CP_BK + s2 * 16);
+                bw[t][s2][0] = *reinterpret_cast<const half8_t*>(wrow + (long long)s2 * 16 * p.Kpad + t * CP_BK);
+                bw[t][s2][1] = *reinterpret_cast<const half8_t*>(wrow + (long long)s2 * 16 * p.Kpad + p.w_plane + t * CP_BK);
             }
         // the loads above must be COMPLETE, and known to the compiler to be complete, before the loop: an empty asm that
         // reads and rewrites every fragment makes it wait here.  (Otherwise the wait for these loads is sunk to their
@@ -344,8 +143,8 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
     const unsigned sx = (unsigned)STEP % W_, syf = (unsigned)STEP / W_;
     const unsigned sy = syf % H_, sn = syf / H_;
     // (n, y, x) of the first grid pixel this lane STORES in an iteration (row (lane >> 3) of its 32-pixel slice) and
-    // (y, x) of the pixel it COMPUTES (row (lane & 31); PADDED only: tap validity)
-    unsigned en, ey, ex, cy = 0, cx = 0;
+    // (y, x) of the two pixels it COMPUTES (rows (lane & 15) and 16 + (lane & 15); PADDED only: tap validity)
+    unsigned en, ey, ex, cy[2] = {0, 0}, cx[2] = {0, 0};
     {
         const unsigned hw = H_ * W_;
         const unsigned g0 = (unsigned)(t_begin * 128) + (TPI == 2 ? grp * 128 : 0) + ms * 32;     // grid pixels < 2^31 (launcher)
@@ -354,21 +153,24 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
         const unsigned rem = ge - en * hw;
         ey = rem / W_; ex = rem - ey * W_;
         if (PADDED) {
-            const unsigned gc = g0 + (lane & 31);
-            const unsigned remc = gc % hw;
-            cy = remc / W_; cx = remc - cy * W_;
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+                const unsigned gc = g0 + pi * 16 + (lane & 15);
+                const unsigned remc = gc % hw;
+                cy[pi] = remc / W_; cx[pi] = remc - cy[pi] * W_;
+            }
         }
     }
     // tap offsets in ring rows (scalars) and this lane's window row at ring position 0
     int toff[ntaps];
 #pragma unroll
     for (int t = 0; t < ntaps; ++t) toff[t] = (t / KWC - p.PH) * p.W + (t % KWC - p.PW);
-    const int lrow0 = (TPI == 2 ? grp * 128 : 0) + ms * 32 + (lane & 31) - minoff;   // window row of this lane's tile row at offset 0
-    const int l5 = lane >> 5;
+    const int lrow0 = (TPI == 2 ? grp * 128 : 0) + ms * 32 + (lane & 15) - minoff;   // window row of this lane's first tile row at offset 0
+    const int l4 = lane >> 4;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    float16_t acc_main[1][1], acc_corr[1][1];
+    conv_epi::Acc16 acc_main[1][1], acc_corr[1][1];
     int wstart = 0;                                        // physical row of this iteration's window row 0: (it * STEP) mod ring
     int pnew = (R16 + (PF - 1) * STEP) % ring;             // physical row of the rows DMA'd in this iteration
     long long relnew = (long long)R16 + (PF - 1) * STEP;
@@ -377,30 +179,36 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
         const bool ahead = it + PF < nit;
         if (ahead && !(DBG && (p.nseg & 0x100))) { RW32_ROWS(relnew, pnew, 16 * TPI, wave, 8) }
         const long long tile = t_begin + (long long)it * TPI + (TPI == 2 ? grp : 0);
-        unsigned tapmask = 0x1ffu;                         // per-lane tap validity (PADDED)
+        unsigned tapmask[2] = {0x1ffu, 0x1ffu};            // per-lane tap validity of its two pixels (PADDED)
         if (PADDED) {
-            tapmask = 0u;
 #pragma unroll
-            for (int t = 0; t < ntaps; ++t) {
-                const int yy = (int)cy + t / KWC - p.PH, xx = (int)cx + t % KWC - p.PW;
-                if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) tapmask |= 1u << t;
+            for (int pi = 0; pi < 2; ++pi) {
+                tapmask[pi] = 0u;
+#pragma unroll
+                for (int t = 0; t < ntaps; ++t) {
+                    const int yy = (int)cy[pi] + t / KWC - p.PH, xx = (int)cx[pi] + t % KWC - p.PW;
+                    if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) tapmask[pi] |= 1u << t;
+                }
             }
         }
         int wbase = wstart + lrow0;                        // < 2 * ring
-        half8_t fa_[2][2][2];
-// the four fragments of a tap: K-slice 0 hi at the swizzled chunk (lane >> 5), K-slice 1 = chunk ^ 2, lo = chunk ^ 4
+        half8_t fa_[2][2][2];                              // [buffer][pixel half][hi / lo]
+// the four fragments of a tap (16 pixels x 32 channels each): pixel half 0 hi at the swizzled chunk (lane >> 4), lo = chunk ^ 4;
+// pixel half 1 sixteen ring rows further (same swizzle: the ring is a multiple of 16 rows), wrapped on its own
 #define RW32_READS(TAP, BUF)                                                                              \
         {                                                                                                  \
             int wrow = wbase + toff[TAP];                                                                  \
             wrow = wrow >= ring ? wrow - ring : wrow;         /* wbase + toff < 2 * ring */                   \
-            const int a0 = wrow * 128 + ((l5 ^ ((wrow >> 1) & 7)) << 4);                                   \
+            const int a0 = wrow * 128 + ((l4 ^ ((wrow >> 1) & 7)) << 4);                                   \
+            const int a1 = a0 + (wrow + 16 >= ring ? (16 - ring) * 128 : 16 * 128);                        \
             u32x4_t ah0 = *reinterpret_cast<const u32x4_t*>(wbuf + a0);                                    \
             u32x4_t al0 = *reinterpret_cast<const u32x4_t*>(wbuf + (a0 ^ 64));                             \
-            u32x4_t ah1 = *reinterpret_cast<const u32x4_t*>(wbuf + (a0 ^ 32));                             \
-            u32x4_t al1 = *reinterpret_cast<const u32x4_t*>(wbuf + (a0 ^ 96));                             \
+            u32x4_t ah1 = *reinterpret_cast<const u32x4_t*>(wbuf + a1);                                    \
+            u32x4_t al1 = *reinterpret_cast<const u32x4_t*>(wbuf + (a1 ^ 64));                             \
             if (PADDED) {                                                                                  \
-                const unsigned am = (tapmask >> (TAP)) & 1u ? 0xffffffffu : 0u;                            \
-                ah0 &= am; al0 &= am; ah1 &= am; al1 &= am;                                                \
+                const unsigned am0 = (tapmask[0] >> (TAP)) & 1u ? 0xffffffffu : 0u;                        \
+                const unsigned am1 = (tapmask[1] >> (TAP)) & 1u ? 0xffffffffu : 0u;                        \
+                ah0 &= am0; al0 &= am0; ah1 &= am1; al1 &= am1;                                            \
             }                                                                                              \
             fa_[BUF][0][0] = __builtin_bit_cast(half8_t, ah0);                                             \
             fa_[BUF][0][1] = __builtin_bit_cast(half8_t, al0);                                             \
@@ -408,15 +216,18 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
             fa_[BUF][1][1] = __builtin_bit_cast(half8_t, al1);                                             \
         }
 #define RW32_MFMAS(TAP, BUF)                                                                              \
-        _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                 \
-            acc_corr[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[TAP][s2][1], fa_[BUF][s2][0], acc_corr[0][0], 0, 0, 0); \
-            acc_main[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[TAP][s2][0], fa_[BUF][s2][0], acc_main[0][0], 0, 0, 0); \
-            acc_corr[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bw[TAP][s2][0], fa_[BUF][s2][1], acc_corr[0][0], 0, 0, 0); \
-        }
+        _Pragma("unroll") for (int ci = 0; ci < 2; ++ci)                                                   \
+            _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) {                                             \
+                float4_t& cm = acc_main[0][0].v[ci][pi];                                                   \
+                float4_t& cc = acc_corr[0][0].v[ci][pi];                                                   \
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bw[TAP][ci][1], fa_[BUF][pi][0], cc, 0, 0, 0); \
+                cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(bw[TAP][ci][0], fa_[BUF][pi][0], cm, 0, 0, 0); \
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(bw[TAP][ci][0], fa_[BUF][pi][1], cc, 0, 0, 0); \
+            }
 // all nine taps of this wave's 32 pixels x 32 couts into (acc_main, acc_corr)
 #define RW32_TAPS()                                                                                       \
         {                                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < 16; ++j) { acc_main[0][0][j] = 0.f; acc_corr[0][0][j] = 0.f; } \
+            conv_epi::acc_zero(acc_main[0][0]); conv_epi::acc_zero(acc_corr[0][0]);                        \
             if (!(DBG && (p.nseg & 0x200))) {                                                              \
             __builtin_amdgcn_sched_barrier(0);                                                             \
             RW32_READS(0, 0)                                                                               \
@@ -426,15 +237,15 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
                 }                                                                                          \
                 if (tap & 1) { RW32_MFMAS(tap, 1) } else { RW32_MFMAS(tap, 0) }                            \
             }                                                                                              \
-            /* issue order: the four fragment reads of tap t + 1, THEN the six MFMAs of tap t (left to itself the    \
+            /* issue order: the four fragment reads of tap t + 1, THEN the twelve MFMAs of tap t (left to itself the \
                scheduler put every read right in front of its MFMA and an lgkmcnt(0) between them: the LDS latency  \
                was exposed eighteen times per tile) */                                                     \
             __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                             \
             _Pragma("unroll") for (int tap = 0; tap + 1 < ntaps; ++tap) {                                  \
                 __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                         \
-                __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                         \
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                        \
             }                                                                                              \
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                                             \
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);                                            \
             __builtin_amdgcn_sched_barrier(0);                                                             \
             }                                                                                              \
         }
@@ -464,9 +275,12 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
         pnew += STEP; pnew = pnew >= ring ? pnew - ring : pnew;
         relnew += STEP;
         if (PADDED) {
-            cx += sx; cy += sy;
-            if (cx >= W_) { cx -= W_; ++cy; }
-            if (cy >= H_) cy -= H_;
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+                cx[pi] += sx; cy[pi] += sy;
+                if (cx[pi] >= W_) { cx[pi] -= W_; ++cy[pi]; }
+                if (cy[pi] >= H_) cy[pi] -= H_;
+            }
         }
         __syncthreads();
     }
@@ -522,39 +336,6 @@ int launch_regw32(const ConvArgs* a, hipStream_t st) {
         return padded ? launch_regw32_inst<32, true>(a, R16, ntiles, grid, lds, st) : launch_regw32_inst<32, false>(a, R16, ntiles, grid, lds, st);
     return padded ? launch_regw32_inst<64, true>(a, R16, ntiles, grid, lds, st) : launch_regw32_inst<64, false>(a, R16, ntiles, grid, lds, st);
 }
-
-int launch_win32(const ConvArgs* a, hipStream_t st) {
-    if (a->Cin != 32 || a->SH != 1 || a->SW != 1 || a->KH != 3 || a->KW != 3 || a->Kpad != 9 * 32 || a->W < 8 ||
-        (long long)a->N * a->H * a->W >= 0x7fffff00LL)
-        return TISE_ERR_INVALID_ARG;
-    const int R = 128 + 2 * a->W + 2;
-    const int R16 = (R + 15) & ~15;
-    const size_t lds = 9 * 32 * 128 + (size_t)(R16 + 256) * 128 + 2048 + 8 * (size_t)conv_epi::Staging<1>::BYTES;
-    if (lds > 160 * 1024) return TISE_ERR_UNSUPPORTED;
-    static size_t attr_lds = 0;
-    if (lds > attr_lds) {
-        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_win32_kernel<3, 3>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_lds = lds;
-    }
-    const long long mg = (long long)a->N * a->H * a->W;
-    const long long ntiles = (mg + 127) / 128;
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        TISE_HIP_CHECK(hipGetDevice(&dev));
-        TISE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const long long grid = ntiles < ncu ? ntiles : ncu;
-    for (int n0 = 0; n0 < a->Cout; n0 += 32) {            // 32 couts per launch (the weights of 9 taps x 32 couts stay in LDS)
-        hipLaunchKernelGGL((conv_win32_kernel<3, 3>), dim3((unsigned)grid), dim3(512), lds, st, *a, R16, ntiles, n0);
-    }
-    TISE_LAUNCH_CHECK();
-    return TISE_OK;
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // Stem convolution Conv2d_1a_3x3 (3 -> 32 channels, 3x3, stride 2, valid; inception.py:60) on the matrix cores, from
@@ -717,14 +498,12 @@ extern "C" int tise_stem_conv3x3s2_split_u8_mfma(const uint8_t* x_dev, const flo
     return TISE_OK;
 }
 
-// cfg 33: LDS-resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; 32 couts per launch).
 // cfg 34: register-resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; Cout = 32 or 64, one launch).
 int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream) {
     if (a->out_hp && (a->out_y0 < 0 || a->out_x0 < 0 || a->out_y0 + a->OH > a->out_hp || a->out_x0 + a->OW > a->out_wp))
         return TISE_ERR_INVALID_ARG;
-    if (cfg == 34) return launch_regw32(a, (hipStream_t)stream);
-    if (cfg != 33) return TISE_ERR_INVALID_ARG;
-    return launch_win32(a, (hipStream_t)stream);
+    if (cfg != 34) return TISE_ERR_INVALID_ARG;
+    return launch_regw32(a, (hipStream_t)stream);
 }
 
 TISE_DEFINE_SPLIT_FLAG_READER(tise_internal_split_flag_conv_pipe)

@@ -28,6 +28,7 @@
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float float16_t __attribute__((ext_vector_type(16)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));   // native vector: stays in registers (SROA)
 
 #define CS_BM 128
@@ -124,11 +125,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs 
         if (a_c >= p.Cin) { a_c -= p.Cin; if (++a_kw == p.KW) { a_kw = 0; ++a_kh; } }                      \
     }
 
-    float16_t acc_main[1][TN], acc_corr[1][TN];
+    conv_epi::Acc16 acc_main[1][TN], acc_corr[1][TN];
 #pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { acc_main[0][t][j] = 0.f; acc_corr[0][t][j] = 0.f; }
+    for (int t = 0; t < TN; ++t) { conv_epi::acc_zero(acc_main[0][t]); conv_epi::acc_zero(acc_corr[0][t]); }
     // scale / bias of this tile's couts, 4 per thread, fetched now so that the epilogue never waits on global memory
     conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
     if (tid < BN / 4) {
@@ -137,30 +136,36 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs 
     }
 
     const int nsteps = p.Kpad / CS_BK;
-    // fragment read: row (lane & 31) of a 32-row block, logical chunk 2*s + (lane >> 5), swizzled
-    const int frow = (lane & 31) * 64;
-    const int fswz = ((lane & 31) >> 2) & 3;
+    // fragment read (v_mfma_f32_16x16x32_f16: 16 rows x 32 K): row (lane & 15) of a 16-row half, logical chunk (lane >> 4),
+    // swizzled by (row >> 2) & 3 (unchanged by the +16 rows of the second half)
+    const int frow = (lane & 15) * 64;
+    const int choff = (((lane >> 4)) ^ (((lane & 15) >> 2) & 3)) * 16;
     CG_ISSUE(0, lds)
     for (int step = 0; step < nsteps; ++step) {
         unsigned char* cur = lds + (step & 1) * STAGE;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my DMA pieces of this stage have landed
         __syncthreads();                                       // everyone's have; everyone left the other stage
         if (step + 1 < nsteps) CG_ISSUE(step + 1, lds + ((step + 1) & 1) * STAGE)
+        half8_t a_[2][2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int choff = ((2 * s + (lane >> 5)) ^ fswz) * 16;
-            const unsigned char* ap = cur + wave * 32 * 64 + frow + choff;
-            const half8_t a_hi = *reinterpret_cast<const half8_t*>(ap);
-            const half8_t a_lo = *reinterpret_cast<const half8_t*>(ap + A_PLANE);
+        for (int pi = 0; pi < 2; ++pi) {
+            const unsigned char* ap = cur + (wave * 32 + pi * 16) * 64 + frow + choff;
+            a_[pi][0] = *reinterpret_cast<const half8_t*>(ap);
+            a_[pi][1] = *reinterpret_cast<const half8_t*>(ap + A_PLANE);
+        }
 #pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const unsigned char* bp = cur + 2 * A_PLANE + t * 32 * 64 + frow + choff;
-                const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);
-                const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);
+        for (int g = 0; g < 2 * TN; ++g) {
+            const unsigned char* bp = cur + 2 * A_PLANE + g * 16 * 64 + frow + choff;
+            const half8_t b_hi = *reinterpret_cast<const half8_t*>(bp);
+            const half8_t b_lo = *reinterpret_cast<const half8_t*>(bp + B_PLANE);
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
                 // weight fragment first: the accumulator is D[cout][pixel] (conv_epilogue.h)
-                acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_hi, acc_main[0][t], 0, 0, 0);
-                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo, a_hi, acc_corr[0][t], 0, 0, 0);
-                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_lo, acc_corr[0][t], 0, 0, 0);
+                float4_t& cm = acc_main[0][g >> 1].v[g & 1][pi];
+                float4_t& cc = acc_corr[0][g >> 1].v[g & 1][pi];
+                cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(b_hi, a_[pi][0], cm, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b_lo, a_[pi][0], cc, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b_hi, a_[pi][1], cc, 0, 0, 0);
             }
         }
     }
@@ -313,11 +318,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         }                                                                                                  \
     }
 
-    float16_t acc_main[1][TN], acc_corr[1][TN];
+    conv_epi::Acc16 acc_main[1][TN], acc_corr[1][TN];
 #pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { acc_main[0][t][j] = 0.f; acc_corr[0][t][j] = 0.f; }
+    for (int t = 0; t < TN; ++t) { conv_epi::acc_zero(acc_main[0][t]); conv_epi::acc_zero(acc_corr[0][t]); }
     // scale / bias of this tile's couts, 4 per thread, fetched now so that the epilogue never waits on global memory
     // (TN = 5 has no eight registers to hold them through the K loop: it fetches them afterwards)
     constexpr bool PRE = TN < 5;
@@ -328,70 +331,54 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     }
 
     const int nsteps = nA + nB;
-    // fragments of both operands: 128-byte rows, row (lane & 31), hi chunk 2*s + (lane >> 5), lo chunk = hi chunk + 4,
-    // both XOR (row >> 1) & 7
-    const int bswz = ((lane & 31) >> 1) & 7;
-    const int fb0 = (lane & 31) * 128 + (((lane >> 5)) ^ bswz) * 16;
-    const int fb1 = (lane & 31) * 128 + ((2 + (lane >> 5)) ^ bswz) * 16;
+    // fragments of both operands (v_mfma_f32_16x16x32_f16: a fragment is 16 rows x 32 K): 128-byte rows, row (lane & 15) of
+    // a 16-row half, hi chunk (lane >> 4), lo chunk = hi chunk + 4, both XOR (row >> 1) & 7; the second half of a 32-row
+    // tile is 2048 bytes further (16 rows leave the swizzle unchanged), the next tile 4096
+    const int f16o = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4);
     const unsigned char* fa = lds + wave * 32 * 128;
-    half8_t h_a0, h_a1, h_b0, h_b1;
+    half8_t h_a[2][2], h_b[2];                                // a: [pixel half][hi / lo], b: (tile 0, cout half 0)[hi / lo]
 
-// One K-step of MFMAs.  All fragment reads of the step are written first and the MFMAs after them; the
-// sched_group_barrier sequence then tells the scheduler to emit them interleaved (first operand pair, then
-// "next pair of reads + 3 MFMAs" repeatedly), so that LDS latency is covered by the wave's own MFMAs instead
-// of four exposed lgkmcnt(0) waits per step (cdna guide T19).
-// the four fragments the step's first MFMA triple needs are requested BEFORE the step's DMA is issued (CF_HEAD): the
+// One K-step of MFMAs: 2 TN groups (tile, cout half) of 6 -- per pixel half corr(b_lo, a_hi), main(b_hi, a_hi),
+// corr(b_hi, a_lo) -- each preceded in issue order by the two fragment reads of the NEXT group (sched_group_barrier), so
+// the LDS latency of a weight fragment passes under the six MFMAs (96 cycles) before its own.
+// The six fragments the step's first group needs are requested BEFORE the step's DMA is issued (CF_HEAD): the
 // ~100-150 cycles of LDS latency then pass under the ~740 cycles the wave spends issuing its global_load_lds
 // instructions (profiles/r02q_conv_kstep_stamps.txt) instead of in front of the first MFMA.
 #define CF_HEAD(STAGEOFF)                                                                                 \
     {                                                                                                     \
-        h_a0 = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + fb0);                                   \
-        h_a1 = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + (fb0 ^ 64));                            \
-        h_b0 = *reinterpret_cast<const half8_t*>(lds + (STAGEOFF) + A_BYTES + fb0);                        \
-        h_b1 = *reinterpret_cast<const half8_t*>(lds + (STAGEOFF) + A_BYTES + (fb0 ^ 64));                 \
+        _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) {                                                 \
+            h_a[pi][0] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + pi * 2048 + f16o);            \
+            h_a[pi][1] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + pi * 2048 + (f16o ^ 64));     \
+        }                                                                                                  \
+        h_b[0] = *reinterpret_cast<const half8_t*>(lds + (STAGEOFF) + A_BYTES + f16o);                     \
+        h_b[1] = *reinterpret_cast<const half8_t*>(lds + (STAGEOFF) + A_BYTES + (f16o ^ 64));              \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
     }
 #define CF_COMPUTE(STAGEOFF)                                                                              \
     {                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        half8_t fa_[2][2], fb_[2][TN][2];                                                                  \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
-            const int fbo = s ? fb1 : fb0;                                                                 \
-            if (s == 0) { fa_[0][0] = h_a0; fa_[0][1] = h_a1; }                                            \
+        half8_t fb_[2 * TN][2];                                                                            \
+        _Pragma("unroll") for (int g = 0; g < 2 * TN; ++g) {                                               \
+            if (g == 0) { fb_[0][0] = h_b[0]; fb_[0][1] = h_b[1]; }                                        \
             else {                                                                                         \
-                fa_[s][0] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + fbo);                      \
-                fa_[s][1] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + (fbo ^ 64));               \
-            }                                                                                              \
-            _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
-                const unsigned char* bb = lds + (STAGEOFF) + A_BYTES + t * 32 * 128;                       \
-                if (s == 0 && t == 0) { fb_[0][0][0] = h_b0; fb_[0][0][1] = h_b1; }                        \
-                else {                                                                                     \
-                    fb_[s][t][0] = *reinterpret_cast<const half8_t*>(bb + fbo);                            \
-                    fb_[s][t][1] = *reinterpret_cast<const half8_t*>(bb + (fbo ^ 64));                     \
-                }                                                                                          \
+                const unsigned char* bb = lds + (STAGEOFF) + A_BYTES + g * 2048;                           \
+                fb_[g][0] = *reinterpret_cast<const half8_t*>(bb + f16o);                                  \
+                fb_[g][1] = *reinterpret_cast<const half8_t*>(bb + (f16o ^ 64));                           \
             }                                                                                              \
         }                                                                                                  \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \
-            _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
-                /* weight fragment first: the accumulator is D[cout][pixel] (conv_epilogue.h).  The two    \
-                   updates of acc_corr[t] are kept one MFMA apart (TN > 1: by the next tile's main MFMA) so  \
-                   that no MFMA waits on the result of the one issued just before it */                    \
-                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][1], fa_[s][0], acc_corr[0][t], 0, 0, 0); \
-                acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][0], acc_main[0][t], 0, 0, 0); \
-                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][1], acc_corr[0][t], 0, 0, 0); \
+        _Pragma("unroll") for (int g = 0; g < 2 * TN; ++g)                                                 \
+            _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) {                                             \
+                /* weight fragment first: the accumulator is D[cout][pixel] (conv_epilogue.h) */           \
+                float4_t& cm = acc_main[0][g >> 1].v[g & 1][pi];                                           \
+                float4_t& cc = acc_corr[0][g >> 1].v[g & 1][pi];                                           \
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb_[g][1], h_a[pi][0], cc, 0, 0, 0);           \
+                cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb_[g][0], h_a[pi][0], cm, 0, 0, 0);           \
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb_[g][0], h_a[pi][1], cc, 0, 0, 0);           \
             }                                                                                              \
-        /* a(s0), b(s0, t0) are already in registers (CF_HEAD) */                                          \
-        _Pragma("unroll") for (int i = 0; i < TN - 1; ++i) {                                               \
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);         /* b(s0, t i+1) */                  \
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);         /* MFMAs (s0, t i) */               \
+        _Pragma("unroll") for (int g = 0; g < 2 * TN; ++g) {                                               \
+            if (g + 1 < 2 * TN) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     /* b(g + 1) */      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                         /* MFMAs (g) */     \
         }                                                                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);             /* a(s1), b(s1, t0) */              \
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);             /* MFMAs (s0, t TN-1) */            \
-        _Pragma("unroll") for (int i = 0; i < TN - 1; ++i) {                                               \
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                             \
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                             \
-        }                                                                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                 \
     }
 
     // ablation switches for tools/conv_ablate.py (bits above the segment count; never set by the product path):
@@ -536,23 +523,22 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
         pb[i] = (unsigned)r * (unsigned)p.Kpad * 4u + c * 16;
         pb_off[i] = q * 1024;
     }
-    // fragment rows: this lane's pixel i = 32 wave + (lane & 31) sits at window row i + j(i) * (KW - 1)
-    int arow;
-    {
-        const int i = wave * 32 + (lane & 31);
+    // fragment rows (v_mfma_f32_16x16x32_f16: 16 pixels x 32 K per fragment): this lane's pixels
+    // i = 32 wave + 16 pi + (lane & 15), pi = 0, 1, sit at window rows i + j(i) * (KW - 1)
+    int arow[2];
+#pragma unroll
+    for (int pi = 0; pi < 2; ++pi) {
+        const int i = wave * 32 + pi * 16 + (lane & 15);
         const unsigned inv_w = 65536u / (unsigned)p.OW + 1u;
         const unsigned ji = ((unsigned)(x0 + i) * inv_w) >> 16;          // (x0 + i) / OW, x0 + i < OW + 128
-        arow = i + (int)ji * (p.KW - 1);
+        arow[pi] = i + (int)ji * (p.KW - 1);
     }
-    const int bswz = ((lane & 31) >> 1) & 7;
-    const int fb0 = (lane & 31) * 128 + (((lane >> 5)) ^ bswz) * 16;
-    const int fb1 = (lane & 31) * 128 + ((2 + (lane >> 5)) ^ bswz) * 16;
+    // weight fragments: row (lane & 15) of a 16-cout half, chunk (lane >> 4); next half 2048 bytes further (as the default kernel)
+    const int f16o = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4);
 
-    float16_t acc_main[1][TN], acc_corr[1][TN];
+    conv_epi::Acc16 acc_main[1][TN], acc_corr[1][TN];
 #pragma unroll
-    for (int t = 0; t < TN; ++t)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { acc_main[0][t][j] = 0.f; acc_corr[0][t][j] = 0.f; }
+    for (int t = 0; t < TN; ++t) { conv_epi::acc_zero(acc_main[0][t]); conv_epi::acc_zero(acc_corr[0][t]); }
     conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
     if (tid < BN / 4) {
         sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + n0 + 4 * tid);
@@ -589,18 +575,19 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
     {                                                                                                     \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
         __syncthreads();                                                                                   \
-        /* K-slice 0 / 1: full group: the two 16-channel halves of tap kw's row; tail group: taps 2 kw and 2 kw + 1 */ \
-        const int row = arow + (cur_tail ? 2 * kw : kw);                                                   \
-        const int row1 = row + cur_tail;                                                                   \
-        const unsigned char* ap = lds + acur + row * 128;                                                  \
-        const unsigned char* ap1 = lds + acur + row1 * 128;                                                \
-        const int ao0 = (((lane >> 5)) ^ ((row >> 1) & 7)) * 16;                                           \
-        const int ao1 = (((cur_tail ? 0 : 2) + (lane >> 5)) ^ ((row1 >> 1) & 7)) * 16;                     \
-        half8_t fa_[2][2], fb_[2][TN][2];                                                                  \
-        fa_[0][0] = *reinterpret_cast<const half8_t*>(ap + ao0);                                           \
-        fa_[0][1] = *reinterpret_cast<const half8_t*>(ap + (ao0 ^ 64));                                    \
-        fb_[0][0][0] = *reinterpret_cast<const half8_t*>(lds + (BCUR) + fb0);                              \
-        fb_[0][0][1] = *reinterpret_cast<const half8_t*>(lds + (BCUR) + (fb0 ^ 64));                       \
+        /* a lane's K group (lane >> 4) of the step's 32: full group: chunk (lane >> 4) of tap kw's row; tail group: K groups  \
+           0, 1 = the 16 channels (chunks 0, 1) of tap 2 kw, K groups 2, 3 = those of tap 2 kw + 1, one row further */          \
+        const int rsel = cur_tail ? 2 * kw + (lane >> 5) : kw;                                             \
+        const int csel = cur_tail ? ((lane >> 4) & 1) : (lane >> 4);                                       \
+        half8_t fa_[2][2], fb_[2 * TN][2];                                                                 \
+        _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) {                                                 \
+            const int row = arow[pi] + rsel;                                                               \
+            const unsigned char* ap = lds + acur + row * 128 + ((csel ^ ((row >> 1) & 7)) << 4);           \
+            fa_[pi][0] = *reinterpret_cast<const half8_t*>(ap);                                            \
+            fa_[pi][1] = *reinterpret_cast<const half8_t*>(lds + acur + row * 128 + (((csel ^ ((row >> 1) & 7)) << 4) ^ 64)); \
+        }                                                                                                  \
+        fb_[0][0] = *reinterpret_cast<const half8_t*>(lds + (BCUR) + f16o);                                \
+        fb_[0][1] = *reinterpret_cast<const half8_t*>(lds + (BCUR) + (f16o ^ 64));                         \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         if (step + 1 < nsteps) RW_B_ISSUE(BNEXT)                                                           \
         if (gnext < ngroups) {                                                                             \
@@ -608,37 +595,23 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
                 if ((cur_tail ? tmodt[t] : tmodf[t]) == kw) RW_A_PIECE(t, nkh, ncb, anext)                 \
         }                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s) {                                                    \
-            const int fbo = s ? fb1 : fb0;                                                                 \
-            if (s == 1) {                                                                                  \
-                fa_[1][0] = *reinterpret_cast<const half8_t*>(ap1 + ao1);                                  \
-                fa_[1][1] = *reinterpret_cast<const half8_t*>(ap1 + (ao1 ^ 64));                           \
-            }                                                                                              \
-            _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
-                const unsigned char* bb = lds + (BCUR) + t * 32 * 128;                                     \
-                if (s != 0 || t != 0) {                                                                    \
-                    fb_[s][t][0] = *reinterpret_cast<const half8_t*>(bb + fbo);                            \
-                    fb_[s][t][1] = *reinterpret_cast<const half8_t*>(bb + (fbo ^ 64));                     \
-                }                                                                                          \
-            }                                                                                              \
+        _Pragma("unroll") for (int g = 1; g < 2 * TN; ++g) {                                               \
+            const unsigned char* bb = lds + (BCUR) + g * 2048;                                             \
+            fb_[g][0] = *reinterpret_cast<const half8_t*>(bb + f16o);                                      \
+            fb_[g][1] = *reinterpret_cast<const half8_t*>(bb + (f16o ^ 64));                               \
         }                                                                                                  \
-        _Pragma("unroll") for (int s = 0; s < 2; ++s)                                                      \
-            _Pragma("unroll") for (int t = 0; t < TN; ++t) {                                               \
-                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][1], fa_[s][0], acc_corr[0][t], 0, 0, 0); \
-                acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][0], acc_main[0][t], 0, 0, 0); \
-                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb_[s][t][0], fa_[s][1], acc_corr[0][t], 0, 0, 0); \
+        _Pragma("unroll") for (int g = 0; g < 2 * TN; ++g)                                                 \
+            _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) {                                             \
+                float4_t& cm = acc_main[0][g >> 1].v[g & 1][pi];                                           \
+                float4_t& cc = acc_corr[0][g >> 1].v[g & 1][pi];                                           \
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb_[g][1], fa_[pi][0], cc, 0, 0, 0);           \
+                cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb_[g][0], fa_[pi][0], cm, 0, 0, 0);           \
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb_[g][0], fa_[pi][1], cc, 0, 0, 0);           \
             }                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < TN - 1; ++i) {                                               \
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                             \
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                             \
+        _Pragma("unroll") for (int g = 0; g < 2 * TN; ++g) {                                               \
+            if (g + 1 < 2 * TN) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     /* b(g + 1) */      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                         /* MFMAs (g) */     \
         }                                                                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                                                 \
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                 \
-        _Pragma("unroll") for (int i = 0; i < TN - 1; ++i) {                                               \
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                             \
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                             \
-        }                                                                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
         ++step;                                                                                            \
         if (++kw == (cur_tail ? tail_steps : p.KW)) {         /* next group */                             \
@@ -805,19 +778,16 @@ __global__ __launch_bounds__(256, TNW == 2 ? 3 : 2) void conv_poolin_kernel(cons
         pb[i] = (unsigned)r * (unsigned)p.Kpad * 4u + c * 16;
         pb_off[i] = A_BYTES + q * 1024;
     }
-    float16_t acc_main[1][TNW], acc_corr[1][TNW];
+    conv_epi::Acc16 acc_main[1][TNW], acc_corr[1][TNW];
 #pragma unroll
-    for (int t = 0; t < TNW; ++t)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { acc_main[0][t][j] = 0.f; acc_corr[0][t][j] = 0.f; }
+    for (int t = 0; t < TNW; ++t) { conv_epi::acc_zero(acc_main[0][t]); conv_epi::acc_zero(acc_corr[0][t]); }
     conv_epi::float4_t sc_pre = {0.f, 0.f, 0.f, 0.f}, bs_pre = {0.f, 0.f, 0.f, 0.f};
     if (tid < BN / 4) {
         sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + n0 + 4 * tid);
         bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + n0 + 4 * tid);
     }
-    const int bswz = ((lane & 31) >> 1) & 7;
-    const int fb0 = (lane & 31) * 128 + (((lane >> 5)) ^ bswz) * 16;
-    const int fb1 = (lane & 31) * 128 + ((2 + (lane >> 5)) ^ bswz) * 16;
+    // fragments (16 rows x 32 K): row (lane & 15), chunk (lane >> 4) XOR (row >> 1) & 7; the next 16 rows 2048 bytes further
+    const int f16o = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4);
     const unsigned char* fa = lds + wm * 32 * 128;
     const int row_bytes = p.W * pix_bytes;
     const int nsteps = p.Cin / CS_BK;
@@ -866,19 +836,24 @@ __global__ __launch_bounds__(256, TNW == 2 ? 3 : 2) void conv_poolin_kernel(cons
         // barrier above); issued AFTER the barrier, whose fence would otherwise wait for them
         if (step + 1 < nsteps) PI_B_ISSUE(((step + 1) & 1) * B_BYTES)
         // ---- MFMAs: the default kernel's order (bit-identical accumulation) ---------------------------------
+        half8_t a_[2][2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int fbo = s ? fb1 : fb0;
-            const half8_t a_hi = *reinterpret_cast<const half8_t*>(fa + fbo);
-            const half8_t a_lo = *reinterpret_cast<const half8_t*>(fa + (fbo ^ 64));
+        for (int pi = 0; pi < 2; ++pi) {
+            a_[pi][0] = *reinterpret_cast<const half8_t*>(fa + pi * 2048 + f16o);
+            a_[pi][1] = *reinterpret_cast<const half8_t*>(fa + pi * 2048 + (f16o ^ 64));
+        }
 #pragma unroll
-            for (int t = 0; t < TNW; ++t) {
-                const unsigned char* bb = lds + A_BYTES + bcur + (wn * TNW + t) * 32 * 128;
-                const half8_t b_hi = *reinterpret_cast<const half8_t*>(bb + fbo);
-                const half8_t b_lo = *reinterpret_cast<const half8_t*>(bb + (fbo ^ 64));
-                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_lo, a_hi, acc_corr[0][t], 0, 0, 0);
-                acc_main[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_hi, acc_main[0][t], 0, 0, 0);
-                acc_corr[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b_hi, a_lo, acc_corr[0][t], 0, 0, 0);
+        for (int g = 0; g < 2 * TNW; ++g) {
+            const unsigned char* bb = lds + A_BYTES + bcur + (wn * 2 * TNW + g) * 2048;
+            const half8_t b_hi = *reinterpret_cast<const half8_t*>(bb + f16o);
+            const half8_t b_lo = *reinterpret_cast<const half8_t*>(bb + (f16o ^ 64));
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+                float4_t& cm = acc_main[0][g >> 1].v[g & 1][pi];
+                float4_t& cc = acc_corr[0][g >> 1].v[g & 1][pi];
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b_lo, a_[pi][0], cc, 0, 0, 0);
+                cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(b_hi, a_[pi][0], cm, 0, 0, 0);
+                cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(b_hi, a_[pi][1], cc, 0, 0, 0);
             }
         }
     }

@@ -287,18 +287,15 @@ class SplitTrunk(FusedTrunk):
         self._padbufs = {}
         # Conv2d_2a (149^2 x 32 -> 32) and Conv2d_2b (147^2 x 32 -> 64, padded): Cin = 32 means a wave can hold the whole
         # filter of 32 couts in registers (conv_pipe.hip configuration 34): the input streams through a sliding LDS ring
-        # once, nothing else moves.  TISE_CONV_REGW=0: round 2's kernels (configuration 33 for 2a, row window for 2b)
-        if os.environ.get("TISE_CONV_VARIANT", "auto") in ("auto", "fast") and os.environ.get("TISE_CONV_WIN32", "1") != "0":
-            regw = os.environ.get("TISE_CONV_REGW", "1") != "0"
-            self.s2a = SplitConv(self.c2a.w, self.c2a.b, self.c2a.stride, self.c2a.padding, self.device, variant="pipe",
-                                 pipe_cfg=34 if regw else 33)
+        # once, nothing else moves.  TISE_CONV_REGW=0: the default kernels (2a: fast, 2b: row window)
+        if os.environ.get("TISE_CONV_VARIANT", "auto") in ("auto", "fast") and os.environ.get("TISE_CONV_REGW", "1") != "0":
+            self.s2a = SplitConv(self.c2a.w, self.c2a.b, self.c2a.stride, self.c2a.padding, self.device, variant="pipe", pipe_cfg=34)
             # Conv2d_2b's zero padding made physical: Conv2d_2a writes into the interior of a zero-bordered buffer (out_pad)
             # and Conv2d_2b runs as a VALID convolution over it -- no per-lane tap masks in the kernel (bit-identical:
             # the masked taps contributed zeros).  TISE_CONV_PADBUF=0: the padded kernel instance on the plain tensor
-            self.pad2b = regw and os.environ.get("TISE_CONV_PADBUF", "1") != "0" and tuple(self.c2b.padding) == (1, 1)
-            if regw:
-                self.s2b = SplitConv(self.c2b.w, self.c2b.b, self.c2b.stride, (0, 0) if self.pad2b else self.c2b.padding,
-                                     self.device, variant="pipe", pipe_cfg=34)
+            self.pad2b = os.environ.get("TISE_CONV_PADBUF", "1") != "0" and tuple(self.c2b.padding) == (1, 1)
+            self.s2b = SplitConv(self.c2b.w, self.c2b.b, self.c2b.stride, (0, 0) if self.pad2b else self.c2b.padding,
+                                 self.device, variant="pipe", pipe_cfg=34)
         # stem weights for the direct kernel: [kh][kw][cin][cout] fp32
         self.stem_w = self.c1a.w.permute(2, 3, 1, 0).contiguous().float()
         assert tuple(self.stem_w.shape) == (3, 3, 3, 32) and self.c1a.stride == (2, 2) and self.c1a.padding == (0, 0)
