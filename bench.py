@@ -54,6 +54,9 @@ if ROOT not in sys.path:
 PEAK_HBM_GBS = 8000.0
 PEAK_F64_MFMA_TFLOPS = 78.6
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: "Peak BF16/FP16 MFMA ~2.5 PF dense"
+# what the bare split-precision inner loop sustains under the chip's power limit (16x16x32, 32 px x 128 couts per wave, two
+# waves per SIMD; profiles/r03k_mfma_shape_probe.txt): reported next to the roofline, never used as its peak
+SUSTAINED_F16_MFMA_TFLOPS = 1585.0
 JOB_IMAGES = 30000         # BASELINE.json metric / configs[1]: 30k images (README.md:214-219 of the reference)
 DEVICE_BATCH = 1000        # images per device batch when it divides a rank's share (tools/batch_sweep.sh: 500 / 750 / 1000 / 1500
                            # -> 20.04 / 20.07 / 20.27 / 20.22 k images/s on one box: fewer launch gaps and tile tails per image)
@@ -402,9 +405,14 @@ def main():
             # algorithmic flop (hi*hi, hi*lo, lo*hi), so its ceiling is the dense fp16 MFMA peak / 3.
             kern["conv_split_fast_kernel"] = {
                 "instances": "all convolution launches of a device batch, as rocprofv3 lists them (conv_split_fast_kernel<TN>, "
-                             "conv_split_rowwin_kernel<TN, NP>, conv_win32_kernel; profiles/r02*_kernel_stats.md)",
-                "clock_note": "the image loop runs at 95-97 % of the 1400 W package power limit (profiles/r02w_power_during_bench.txt; "
-                              "in-kernel stamps: 1.34-1.8 GHz while the MFMAs are busy); peak below is the 2.4 GHz datasheet figure / 3",
+                             "conv_split_rowwin_kernel<TN, NP>, conv_regw32_kernel<COUT>, conv_poolin_kernel<TNW>; "
+                             "profiles/r03*_kernel_stats.md)",
+                "clock_note": "the chip is power-limited on this loop: the bare inner loop (LDS fragment reads + 3 MFMAs per product, "
+                              "nothing else; tools/probes/mfma_shape_probe.hip, profiles/r03k_mfma_shape_probe.txt) sustains "
+                              "1.57-1.69 PFLOP/s of fp16 MFMA with v_mfma_f32_16x16x32_f16 at 1.79 GHz (1.39-1.48 at 1.52 GHz with "
+                              "32x32x16) of the 2.5 PFLOP/s datasheet peak at 2.4 GHz; peak below is the datasheet figure / 3",
+                "sustained_mfma_f16_probe": SUSTAINED_F16_MFMA_TFLOPS,
+                "frac_of_sustained": 3.0 * conv_flop / (conv_ms * 1e-3) / 1e12 / SUSTAINED_F16_MFMA_TFLOPS,
                 "bound": "mfma", "achieved": conv_flop / (conv_ms * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3.0,
                 "unit": "TFLOP/s", "avg_ms": conv_ms / timed_steps, "avg_launch_ms": conv_ms / n_launch,
                 "launches_per_batch": n_launch / timed_steps, "algorithmic_flop_per_batch": conv_flop / timed_steps,

@@ -318,9 +318,19 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
         }                                                                                                  \
     }
 
-    conv_epi::Acc16 acc_main[1][TN], acc_corr[1][TN];
+    // wave layout.  TN = 4: 2 x 2 -- a wave owns 64 pixels x 64 couts (16 fragment reads per K-step instead of the 20 of
+    // 32 pixels x 128 couts; the probe puts 6-7 % between the two at the power limit, profiles/r03k_mfma_shape_probe.txt);
+    // other widths: 4 x 1 -- 32 pixels x all TN * 32 couts
+    constexpr bool W22 = TN == 4;
+    constexpr int NPH = W22 ? 4 : 2;                          // 16-pixel fragment halves per wave
+    constexpr int NCH = W22 ? TN : 2 * TN;                    // 16-cout fragment halves per wave
+    constexpr int RG = NPH / 2, TNW = NCH / 2;                // as 32 x 32 tiles: row groups x cout tiles
+    const int wm = W22 ? (wave & 1) : wave, wn = W22 ? (wave >> 1) : 0;
+    conv_epi::Acc16 acc_main[RG][1][TNW], acc_corr[RG][1][TNW];
 #pragma unroll
-    for (int t = 0; t < TN; ++t) { conv_epi::acc_zero(acc_main[0][t]); conv_epi::acc_zero(acc_corr[0][t]); }
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+        for (int t = 0; t < TNW; ++t) { conv_epi::acc_zero(acc_main[r][0][t]); conv_epi::acc_zero(acc_corr[r][0][t]); }
     // scale / bias of this tile's couts, 4 per thread, fetched now so that the epilogue never waits on global memory
     // (TN = 5 has no eight registers to hold them through the K loop: it fetches them afterwards)
     constexpr bool PRE = TN < 5;
@@ -335,49 +345,50 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     // a 16-row half, hi chunk (lane >> 4), lo chunk = hi chunk + 4, both XOR (row >> 1) & 7; the second half of a 32-row
     // tile is 2048 bytes further (16 rows leave the swizzle unchanged), the next tile 4096
     const int f16o = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4);
-    const unsigned char* fa = lds + wave * 32 * 128;
-    half8_t h_a[2][2], h_b[2];                                // a: [pixel half][hi / lo], b: (tile 0, cout half 0)[hi / lo]
+    const unsigned char* fa = lds + wm * NPH * 2048;
+    const int fbw = A_BYTES + wn * NCH * 2048;                // this wave's first cout half in the stage
+    half8_t h_a[NPH][2], h_b[2];                              // a: [pixel half][hi / lo], b: (cout half 0)[hi / lo]
 
-// One K-step of MFMAs: 2 TN groups (tile, cout half) of 6 -- per pixel half corr(b_lo, a_hi), main(b_hi, a_hi),
+// One K-step of MFMAs: NCH groups (one 16-cout half each) of 3 NPH -- per pixel half corr(b_lo, a_hi), main(b_hi, a_hi),
 // corr(b_hi, a_lo) -- each preceded in issue order by the two fragment reads of the NEXT group (sched_group_barrier), so
-// the LDS latency of a weight fragment passes under the six MFMAs (96 cycles) before its own.
-// The six fragments the step's first group needs are requested BEFORE the step's DMA is issued (CF_HEAD): the
+// the LDS latency of a weight fragment passes under the MFMAs (96 / 192 cycles) before its own.
+// The fragments the step's first group needs are requested BEFORE the step's DMA is issued (CF_HEAD): the
 // ~100-150 cycles of LDS latency then pass under the ~740 cycles the wave spends issuing its global_load_lds
 // instructions (profiles/r02q_conv_kstep_stamps.txt) instead of in front of the first MFMA.
 #define CF_HEAD(STAGEOFF)                                                                                 \
     {                                                                                                     \
-        _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) {                                                 \
+        _Pragma("unroll") for (int pi = 0; pi < NPH; ++pi) {                                               \
             h_a[pi][0] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + pi * 2048 + f16o);            \
             h_a[pi][1] = *reinterpret_cast<const half8_t*>(fa + (STAGEOFF) + pi * 2048 + (f16o ^ 64));     \
         }                                                                                                  \
-        h_b[0] = *reinterpret_cast<const half8_t*>(lds + (STAGEOFF) + A_BYTES + f16o);                     \
-        h_b[1] = *reinterpret_cast<const half8_t*>(lds + (STAGEOFF) + A_BYTES + (f16o ^ 64));              \
+        h_b[0] = *reinterpret_cast<const half8_t*>(lds + (STAGEOFF) + fbw + f16o);                         \
+        h_b[1] = *reinterpret_cast<const half8_t*>(lds + (STAGEOFF) + fbw + (f16o ^ 64));                  \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
     }
 #define CF_COMPUTE(STAGEOFF)                                                                              \
     {                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                 \
-        half8_t fb_[2 * TN][2];                                                                            \
-        _Pragma("unroll") for (int g = 0; g < 2 * TN; ++g) {                                               \
+        half8_t fb_[NCH][2];                                                                               \
+        _Pragma("unroll") for (int g = 0; g < NCH; ++g) {                                                  \
             if (g == 0) { fb_[0][0] = h_b[0]; fb_[0][1] = h_b[1]; }                                        \
             else {                                                                                         \
-                const unsigned char* bb = lds + (STAGEOFF) + A_BYTES + g * 2048;                           \
+                const unsigned char* bb = lds + (STAGEOFF) + fbw + g * 2048;                               \
                 fb_[g][0] = *reinterpret_cast<const half8_t*>(bb + f16o);                                  \
                 fb_[g][1] = *reinterpret_cast<const half8_t*>(bb + (f16o ^ 64));                           \
             }                                                                                              \
         }                                                                                                  \
-        _Pragma("unroll") for (int g = 0; g < 2 * TN; ++g)                                                 \
-            _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) {                                             \
+        _Pragma("unroll") for (int g = 0; g < NCH; ++g)                                                    \
+            _Pragma("unroll") for (int pi = 0; pi < NPH; ++pi) {                                           \
                 /* weight fragment first: the accumulator is D[cout][pixel] (conv_epilogue.h) */           \
-                float4_t& cm = acc_main[0][g >> 1].v[g & 1][pi];                                           \
-                float4_t& cc = acc_corr[0][g >> 1].v[g & 1][pi];                                           \
+                float4_t& cm = acc_main[pi >> 1][0][g >> 1].v[g & 1][pi & 1];                              \
+                float4_t& cc = acc_corr[pi >> 1][0][g >> 1].v[g & 1][pi & 1];                              \
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb_[g][1], h_a[pi][0], cc, 0, 0, 0);           \
                 cm = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb_[g][0], h_a[pi][0], cm, 0, 0, 0);           \
                 cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb_[g][0], h_a[pi][1], cc, 0, 0, 0);           \
             }                                                                                              \
-        _Pragma("unroll") for (int g = 0; g < 2 * TN; ++g) {                                               \
-            if (g + 1 < 2 * TN) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     /* b(g + 1) */      \
-            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);                         /* MFMAs (g) */     \
+        _Pragma("unroll") for (int g = 0; g < NCH; ++g) {                                                  \
+            if (g + 1 < NCH) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);        /* b(g + 1) */      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NPH, 0);                   /* MFMAs (g) */     \
         }                                                                                                  \
     }
 
@@ -435,7 +446,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     }
     conv_epi::prepare<BN>(p, lds + EPI0, n0, sc_pre, bs_pre);
     __syncthreads();
-    conv_epi::store_tiles_desc<TN, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, lds + EPI0, m0 + wave * 32);
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+        conv_epi::store_tiles_desc<TNW, ETW, false, BN>(p, acc_main[r], acc_corr[r], lds + wave * conv_epi::Staging<ETW>::BYTES, lds + EPI0,
+                                                        m0 + wm * NPH * 16 + r * 32, wn * NCH * 2);
 }
 
 
