@@ -480,18 +480,38 @@ def test_split_pool_ops(dev):
         assert not torch.cat([got[..., :off], got[..., off + c:]], -1).any()
 
 
-def test_split_trunk_matches_module_graph(dev):
+@pytest.mark.parametrize("dims", [2048, 768, 192, 64])
+def test_split_trunk_matches_module_graph(dev, dims, monkeypatch):
+    """The all-HIP trunk at every --dims of the reference (inception.py:14-19; the map of blocks 0-2 averaged as
+    fid_score.py:110-111 does) against the fp32 module graph; with the stem max-pools fused into their consumers and as
+    separate kernels; and through the engine from uint8 images (the path the CLIs take)."""
+    import torch.nn.functional as F
+    from tise_toolbox_amd.engine import RealismEngine
     from tise_toolbox_amd.inception import InceptionV3
     from tise_toolbox_amd.trunk import SplitTrunk
     torch.backends.cudnn.benchmark = False
-    m = InceptionV3([3], seed=0).to(dev).eval()
+    m = InceptionV3([InceptionV3.BLOCK_INDEX_BY_DIM[dims]], seed=0).to(dev).eval()
     x = torch.rand((6, 3, 299, 299), device=dev).contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
-        want = m(x, prenormalized=True)[0]
+        want = F.adaptive_avg_pool2d(m(x, prenormalized=True)[0], (1, 1))
         got = SplitTrunk(m, dev)(x)
-    assert got.shape == want.shape
+        monkeypatch.setenv("TISE_POOL_FUSE", "0")
+        got_sep = SplitTrunk(m, dev)(x)
+        monkeypatch.delenv("TISE_POOL_FUSE")
+    assert got.shape == want.shape == (6, dims, 1, 1)
     err = (got - want).abs().max().item()
     assert err <= 2e-4 * want.abs().max().item(), err
+    assert torch.equal(got, got_sep)
+    eng = RealismEngine(dims=dims, seed=0)
+    assert isinstance(eng.fused, SplitTrunk)
+    u8 = torch.randint(0, 256, (5, 64, 48, 3), dtype=torch.uint8, device=dev)
+    feats, _ = eng.features_from_u8(u8)
+    assert tuple(feats.shape) == (5, dims)
+    monkeypatch.setenv("TISE_CONV", "miopen")
+    ref_eng = RealismEngine(dims=dims, seed=0)
+    assert not isinstance(ref_eng.fused, SplitTrunk)
+    ref, _ = ref_eng.features_from_u8(u8)
+    assert (feats - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
 
 
 @pytest.mark.parametrize("variant", ["glds", "fast"])

@@ -19,6 +19,10 @@ extern "C" void tise_set_last_hip_error(int e);
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+// XOR swizzle of the 16-byte chunk index inside a 128-byte LDS row of the convolution kernels' operand images (the DMA
+// applies it on the source address, the fragment reads on the LDS address): see conv_split.hip, default kernel.
+__host__ __device__ __forceinline__ int tise_lds_swz(int row) { return ((row >> 1) & 3) << 1; }
+
 // "done once per device" latch for per-kernel attributes (hipFuncSetAttribute applies to the CURRENT device): one bit
 // per device ordinal, so a process that drives several GPUs sets the attribute on each of them.
 #include <atomic>

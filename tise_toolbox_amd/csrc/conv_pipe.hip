@@ -121,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
             const bool ok = g >= 0 && g < mgrid;                                                           \
             int prow = (PROW0) + q * 8;                                                                    \
             while (prow >= ring) prow -= ring;                /* scalar; at most twice */                  \
-            const int c = (lane & 7) ^ ((((prow >> 3) & 1) << 2) | (lane >> 4));                           \
+            const int c = (lane & 7) ^ ((lane >> 4) << 1);    /* tise_lds_swz of a row inside an 8-row piece */ \
             const unsigned char* src = xg + g * 128 + c * 16;                                              \
             src = ok ? src : zp;                                                                           \
             __builtin_amdgcn_global_load_lds(src, (lds_ptr_t)(wbuf + prow * 128), 16, 0, 0);               \
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
         {                                                                                                  \
             int wrow = wbase + toff[TAP];                                                                  \
             wrow = wrow >= ring ? wrow - ring : wrow;         /* wbase + toff < 2 * ring */                   \
-            const int a0 = wrow * 128 + ((l4 ^ ((wrow >> 1) & 7)) << 4);                                   \
+            const int a0 = wrow * 128 + ((l4 ^ tise_lds_swz(wrow)) << 4);                                  \
             const int a1 = a0 + (wrow + 16 >= ring ? (16 - ring) * 128 : 16 * 128);                        \
             u32x4_t ah0 = *reinterpret_cast<const u32x4_t*>(wbuf + a0);                                    \
             u32x4_t al0 = *reinterpret_cast<const u32x4_t*>(wbuf + (a0 ^ 64));                             \

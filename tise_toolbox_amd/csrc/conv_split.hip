@@ -188,8 +188,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs 
 // rebuilt only when the tap changes (wave-uniform branch) and otherwise advance by 128 bytes; the two LDS stages
 // are addressed with compile-time offsets (loop unrolled by two).  The LDS-DMA path moves 128-byte rows at
 // 38 B/clk/CU against 30 for 64-byte rows (profiles/r01g_glds_rate_microbench.txt).  LDS rows are 128 B too; the
-// ds_read_b128 fragments stay conflict-free with the chunk index XOR-ed with (row >> 1) & 7 (eight rows of one
-// parity x eight chunk slots, two parities: the 16 lanes of a b128 group hit 16 distinct 16-byte bank groups).
+// ds_read_b128 fragments stay conflict-free with the chunk index XOR-ed with tise_lds_swz(row) = ((row >> 1) & 3) << 1
+// (common.h): a b128 group of 16 lanes reads rows r0 .. r0+3, r0+12 .. r0+15 at K group g and r0+4 .. r0+11 at g ^ 1 (the
+// 16-row x 32-K fragment of v_mfma_f32_16x16x32_f16); the four rows of one parity within 8 rows get four different chunk
+// pairs, and the row 8 further has the other K group: 16 distinct 16-byte bank groups for EVERY r0 (the window kernels
+// read at arbitrary tap offsets; round 2's (row >> 1) & 7, chosen for the 32-row fragments of 32x32x16, costs this
+// shape a 2-way conflict whenever r0 is not a multiple of 4: 19 % of all indexed-LDS cycles, profiles/r03l).
 template <int TN, bool DBG = false>
 __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs p) {
     constexpr int BN = 32 * TN;
@@ -216,8 +220,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     const int n0 = tile_n * BN;
 
     // A DMA piece = 8 rows x 128 B: lane i fills row (i >> 3), physical 16-byte chunk (i & 7) and fetches the logical
-    // chunk (i & 7) ^ ((row >> 1) & 7), chunks 0-3 = hi, 4-7 = lo.  This wave's four pixel pieces are rows
-    // 32*wave + 8*jj .., so (row >> 1) & 7 = 4*(jj & 1) + (lane >> 4): two chunk values per lane, by the parity of jj.
+    // chunk (i & 7) ^ tise_lds_swz(row), chunks 0-3 = hi, 4-7 = lo.  A piece starts on a multiple of 8 rows, so
+    // tise_lds_swz(row) = (lane >> 4) << 1 for every piece: one chunk value per lane.
     const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_conv_zero_page);
     const int pix_bytes = p.Cin * 4;
     const unsigned char* pbase[4];                            // (n, oh*SH - PH, ow*SW - PW) of the piece's pixel: tap (0, 0)
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     for (int i = 0; i < TN; ++i) {
         const int q = wave * TN + i;                                   // 8-cout block of the tile
         const int r = q * 8 + (lane >> 3);                             // cout row within the tile
-        const int c = (lane & 7) ^ ((r >> 1) & 7);                     // logical chunk: 0-3 hi, 4-7 lo
+        const int c = (lane & 7) ^ tise_lds_swz(r);                    // logical chunk: 0-3 hi, 4-7 lo
         pb[i] = (unsigned)r * (unsigned)p.Kpad * 4u + c * 16;
         pb_off[i] = A_BYTES + q * 1024;
     }
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
     const int ncblk = p.Cin / CS_BK, ntaps = p.KH * p.KW;
     const int nA = ntaps * ncblk;
     const int nB = (p.Cin & 16) ? (ntaps + 1) / 2 : 0;
-    const int cl0 = (lane & 7) ^ (lane >> 4), cl1 = cl0 ^ 4;  // logical chunk of the even / odd pieces
+    const int cl0 = (lane & 7) ^ ((lane >> 4) << 1), cl1 = cl0;   // logical chunk of this lane in every piece
 // pointers of piece JJ for tap (KH_, KW_), CHB_ bytes into the pixel
 #define CF_TAP_ONE(JJ, KH_, KW_, CHB_, VALID_)                                                            \
     {                                                                                                     \
@@ -342,9 +346,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
 
     const int nsteps = nA + nB;
     // fragments of both operands (v_mfma_f32_16x16x32_f16: a fragment is 16 rows x 32 K): 128-byte rows, row (lane & 15) of
-    // a 16-row half, hi chunk (lane >> 4), lo chunk = hi chunk + 4, both XOR (row >> 1) & 7; the second half of a 32-row
+    // a 16-row half, hi chunk (lane >> 4), lo chunk = hi chunk + 4, both XOR tise_lds_swz(row); the second half of a 32-row
     // tile is 2048 bytes further (16 rows leave the swizzle unchanged), the next tile 4096
-    const int f16o = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4);
+    const int f16o = (lane & 15) * 128 + (((lane >> 4) ^ tise_lds_swz(lane & 15)) << 4);
     const unsigned char* fa = lds + wm * NPH * 2048;
     const int fbw = A_BYTES + wn * NCH * 2048;                // this wave's first cout half in the stage
     half8_t h_a[NPH][2], h_b[2];                              // a: [pixel half][hi / lo], b: (cout half 0)[hi / lo]
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
     const unsigned char* pbase[NP];                           // source of (row, kh = 0, block 0, chunk 0)
     int oyp[NP];                                              // oy - PH + 0x4000 of the row's image line, 0 = zero row
     // every piece of a wave has the wave's parity (q = wave + 4 t), so a lane fetches ONE logical chunk in all of them
-    const int cch = (lane & 7) ^ ((((wave & 1) << 2) | (lane >> 4)));
+    const int cch = (lane & 7) ^ ((lane >> 4) << 1);           // tise_lds_swz of a row inside an 8-row piece
     const int full_off = cch * 16;                            // byte offset of that chunk inside a full block's line
     const int tail_off = (cch >> 2) * 32 + (cch & 1) * 16;    // ... inside the 64-byte tail block [hi x16 | lo x16]
     const bool tail_has = (cch & 3) < 2;                      // chunks 2, 3, 6, 7 of a tail row are zeros
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
     for (int i = 0; i < TN; ++i) {
         const int q = wave * TN + i;
         const int r = q * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int c = (lane & 7) ^ tise_lds_swz(r);
         pb[i] = (unsigned)r * (unsigned)p.Kpad * 4u + c * 16;
         pb_off[i] = q * 1024;
     }
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
         arow[pi] = i + (int)ji * (p.KW - 1);
     }
     // weight fragments: row (lane & 15) of a 16-cout half, chunk (lane >> 4); next half 2048 bytes further (as the default kernel)
-    const int f16o = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4);
+    const int f16o = (lane & 15) * 128 + (((lane >> 4) ^ tise_lds_swz(lane & 15)) << 4);
 
     conv_epi::Acc16 acc_main[1][TN], acc_corr[1][TN];
 #pragma unroll
@@ -596,9 +600,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
         half8_t fa_[2][2], fb_[2 * TN][2];                                                                 \
         _Pragma("unroll") for (int pi = 0; pi < 2; ++pi) {                                                 \
             const int row = arow[pi] + rsel;                                                               \
-            const unsigned char* ap = lds + acur + row * 128 + ((csel ^ ((row >> 1) & 7)) << 4);           \
+            const unsigned char* ap = lds + acur + row * 128 + ((csel ^ tise_lds_swz(row)) << 4);          \
             fa_[pi][0] = *reinterpret_cast<const half8_t*>(ap);                                            \
-            fa_[pi][1] = *reinterpret_cast<const half8_t*>(lds + acur + row * 128 + (((csel ^ ((row >> 1) & 7)) << 4) ^ 64)); \
+            fa_[pi][1] = *reinterpret_cast<const half8_t*>(lds + acur + row * 128 + (((csel ^ tise_lds_swz(row)) << 4) ^ 64)); \
         }                                                                                                  \
         fb_[0][0] = *reinterpret_cast<const half8_t*>(lds + (BCUR) + f16o);                                \
         fb_[0][1] = *reinterpret_cast<const half8_t*>(lds + (BCUR) + (f16o ^ 64));                         \
@@ -778,7 +782,7 @@ __global__ __launch_bounds__(256, TNW == 2 ? 3 : 2) void conv_poolin_kernel(cons
         const unsigned rem = pp - n * ohw;
         const unsigned oh = rem / (unsigned)p.OW, ow = rem - oh * (unsigned)p.OW;
         src0 = reinterpret_cast<const unsigned char*>(p.x) + (((long long)n * p.H + 2 * oh) * p.W + 2 * ow) * pix_bytes + pc * 16;
-        arow_off = row * 128 + ((pc ^ ((row >> 1) & 7)) * 16);
+        arow_off = row * 128 + ((pc ^ tise_lds_swz(row)) * 16);
     }
     // weights: 8-cout DMA pieces, 2 * TNW per wave and K-step (as in the default kernel: scalar base + 32-bit lane offset)
     const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (long long)n0 * p.Kpad * 4;
@@ -788,7 +792,7 @@ __global__ __launch_bounds__(256, TNW == 2 ? 3 : 2) void conv_poolin_kernel(cons
     for (int i = 0; i < 2 * TNW; ++i) {
         const int q = wave * 2 * TNW + i;
         const int r = q * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        const int c = (lane & 7) ^ tise_lds_swz(r);
         pb[i] = (unsigned)r * (unsigned)p.Kpad * 4u + c * 16;
         pb_off[i] = A_BYTES + q * 1024;
     }
@@ -800,8 +804,8 @@ __global__ __launch_bounds__(256, TNW == 2 ? 3 : 2) void conv_poolin_kernel(cons
         sc_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.scale + n0 + 4 * tid);
         bs_pre = *reinterpret_cast<const conv_epi::float4_t*>(p.bias + n0 + 4 * tid);
     }
-    // fragments (16 rows x 32 K): row (lane & 15), chunk (lane >> 4) XOR (row >> 1) & 7; the next 16 rows 2048 bytes further
-    const int f16o = (lane & 15) * 128 + (((lane >> 4) ^ (((lane & 15) >> 1) & 7)) << 4);
+    // fragments (16 rows x 32 K): row (lane & 15), chunk (lane >> 4) XOR tise_lds_swz(row); the next 16 rows 2048 bytes further
+    const int f16o = (lane & 15) * 128 + (((lane >> 4) ^ tise_lds_swz(lane & 15)) << 4);
     const unsigned char* fa = lds + wm * 32 * 128;
     const int row_bytes = p.W * pix_bytes;
     const int nsteps = p.Cin / CS_BK;

@@ -81,9 +81,9 @@ class RealismEngine:
             fused = os.environ.get("TISE_FUSED_TRUNK", "1") != "0"
         if fused and channels_last and isinstance(self.model, InceptionV3):
             from .trunk import FusedTrunk, SplitTrunk
-            # TISE_CONV=split (default for pool3): hand-written split-precision fp16-MFMA convolutions;
+            # TISE_CONV=split (default, every --dims): hand-written split-precision fp16-MFMA convolutions;
             # TISE_CONV=miopen: MIOpen fp32 convolutions + HIP epilogues
-            use_split = os.environ.get("TISE_CONV", "split") == "split" and self.model.last_needed_block == 3
+            use_split = os.environ.get("TISE_CONV", "split") == "split"
             self.fused = (SplitTrunk if use_split else FusedTrunk)(self.model, self.device)
         self.stats = None
         self.is_acc = None

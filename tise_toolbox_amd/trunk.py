@@ -272,17 +272,20 @@ class SplitTrunk(FusedTrunk):
     BatchNorm scale/bias and ReLU and writes straight into the consumer's channel slice, the pool branch
     gets raw fp32 from the fused 1x1 conv and ``tise_avgpool3_bias_relu_split_nhwc`` finishes it.
     Measured per layer 1.5-2.3x MIOpen's fp32 kernels at a smaller error against an fp64 reference
-    (``tools/conv_split_probe.py``).  Requires the wrapper to go to pool3 (last block 3)."""
+    (``tools/conv_split_probe.py``).  The wrapper's last block decides where the forward stops (``--dims`` 64 / 192 /
+    768 / 2048, inception.py:14-19): the output is always the GLOBAL MEAN of that block's feature map, (N, C, 1, 1) --
+    what fid_score.py:110-111's adaptive_avg_pool2d makes of the map the reference wrapper returns."""
 
     def __init__(self, model, device):
         super().__init__(model, device)
         from .conv_split import SplitConv
-        assert self.last_block == 3, "SplitTrunk implements the pool3 (dims=2048) path"
 
         def sc(c):
             return SplitConv(c.w, c.b, c.stride, c.padding, self.device)
 
-        self.s2a, self.s2b, self.s3b, self.s4a = sc(self.c2a), sc(self.c2b), sc(self.c3b), sc(self.c4a)
+        self.s2a, self.s2b = sc(self.c2a), sc(self.c2b)
+        if self.last_block >= 1:
+            self.s3b, self.s4a = sc(self.c3b), sc(self.c4a)
         self.pad2b = False
         self._padbufs = {}
         # Conv2d_2a (149^2 x 32 -> 32) and Conv2d_2b (147^2 x 32 -> 64, padded): Cin = 32 means a wave can hold the whole
@@ -466,20 +469,30 @@ class SplitTrunk(FusedTrunk):
         else:
             a = self._sconv(self.s2b, self._sconv(self.s2a, a))
         fn = {"A": self._sblock_a, "B": self._sblock_b, "C": self._sblock_c, "D": self._sblock_d, "E": self._sblock_e}
+        if self.last_block == 0:                                        # --dims 64: block 0 ends with max-pool 1
+            return self._global_mean(self._maxpool_split(a))
         if self.fuse_pool:
             n, h, w, _ = a.shape
             oh, ow = self.s3b.pooled_out_hw(h, w)
             t = self._new(n, oh, ow, self.s3b.cout, a.device)
             self.s3b(a, [(0, self.s3b.cout, t, 0, 0)], pooled_input=True)          # max-pool 1 + Conv2d_3b_1x1
             a = self._sconv(self.s4a, t)
+            if self.last_block == 1:                                    # --dims 192: block 1 ends with max-pool 2
+                return self._global_mean(self._maxpool_split(a))
             a = self._sblock_a(a, self.sblocks[0][1], pooled_input=True)           # max-pool 2 + Mixed_5b
             rest = self.sblocks[1:]
         else:
             a = self._sconv(self.s3b, self._maxpool_split(a))
             a = self._maxpool_split(self._sconv(self.s4a, a))
+            if self.last_block == 1:
+                return self._global_mean(a)
             rest = self.sblocks
-        for kind, P in rest:
+        for kind, P in rest:                                            # --dims 768 stops after Mixed_6e, 2048 after Mixed_7c
             a = fn[kind](a, P)
+        return self._global_mean(a)
+
+    @staticmethod
+    def _global_mean(a):
         n, h, w, c2 = a.shape                                           # merge + global average, one pass
         c = c2 // 2
         feat = torch.empty((n, c), dtype=torch.float32, device=a.device)
