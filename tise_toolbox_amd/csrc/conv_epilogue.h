@@ -279,16 +279,29 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, ACC (&
             }
             const long long half_off = (q & 1) ? cd.second : 0;
             const int ohp = p.out_hp ? p.out_hp : p.OH, owp = p.out_hp ? p.out_wp : p.OW;      // destination image pitch
+            // the destination address of (n, y, x) is built ONCE and then follows the coordinates: + rows_per_pass pixels per
+            // pass, + the pitch difference when x wraps into the next image row, + the rows between two images when y wraps.
+            // (Rebuilding ((n * ohp + y) * owp + x) * stride per pass cost eight quarter-rate integer multiplies per pass:
+            // a third of the register-weights kernel's epilogue.)  The increments fit 32 bits and the destination pixel index
+            // 32 bits unsigned (tise_conv_pipe_launch checks N * out_hp * out_wp and the strides).
+            const int stride = (int)cd.row_stride;
+            unsigned char* d = reinterpret_cast<unsigned char*>(cd.base) +
+                               ((unsigned long long)((n * (unsigned)ohp + y) * (unsigned)owp + x)) * (unsigned)stride + half_off;
+            const int sx = rows_per_pass * stride;                // signed: the destination image may be SMALLER than the grid
+            const int sy = (owp - p.W) * stride;
+            const int sn = (ohp - p.H) * owp * stride;
 #pragma unroll
             for (int r4 = 0; r4 < NPASS; ++r4) {
                 if (r4 * rows_per_pass >= 32) continue;
                 const bool ok = cd.valid && row0 + r4 * rows_per_pass < rows_ok && y < (unsigned)p.OH && x < (unsigned)p.OW;
-                if (ok) {
-                    const long long pp = ((long long)n * ohp + y) * owp + x;
-                    *reinterpret_cast<u32x4_t*>(cd.base + pp * cd.row_stride + half_off) = vals[r4];
-                }
+                if (ok) *reinterpret_cast<u32x4_t*>(d) = vals[r4];
                 x += rows_per_pass;                               // next pass: rows_per_pass grid pixels further (W >= 8)
-                if (x >= (unsigned)p.W) { x -= (unsigned)p.W; if (++y == (unsigned)p.H) { y = 0; ++n; } }
+                int adv = sx;
+                if (x >= (unsigned)p.W) {
+                    x -= (unsigned)p.W; adv += sy;
+                    if (++y == (unsigned)p.H) { y = 0; adv += sn; }
+                }
+                d += (long long)adv;
             }
         }
     }
