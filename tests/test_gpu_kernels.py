@@ -78,10 +78,16 @@ def test_resize_random_sizes_vs_oracle(dev, h, w):
     imgs = rng.integers(0, 256, (n, h, w, 3), dtype=np.uint8)
     out, u8 = device.resize_bilinear_u8(torch.as_tensor(imgs, device=dev), (299, 299), device.make_lut(False),
                                         channels_last=True, return_u8=True)
+    only = device.resize_u8_only(torch.as_tensor(imgs, device=dev), (299, 299))     # the product path: uint8 out only (4 bytes per lane)
     for i in range(n):
         want = resize_oracle.resize_bilinear_u8(imgs[i], 299, 299)
         np.testing.assert_array_equal(u8[i].cpu().numpy(), want)
+        np.testing.assert_array_equal(only[i].cpu().numpy(), want)
         np.testing.assert_array_equal(out[i].cpu().numpy(), resize_oracle.to_tensor(want))
+    # a destination that is not a multiple of four bytes wide and not 299: the dword stores' row tails
+    for (oh, ow) in ((61, 37), (300, 298)):
+        got = device.resize_u8_only(torch.as_tensor(imgs[:1], device=dev), (oh, ow))
+        np.testing.assert_array_equal(got[0].cpu().numpy(), resize_oracle.resize_bilinear_u8(imgs[0], oh, ow))
 
 
 def test_resize_batch_and_empty(dev):

@@ -320,6 +320,40 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
     }
     __syncthreads();
 
+    // uint8-only output (the product path: the stem convolution applies the table) with <= 3 vertical taps: FOUR output bytes
+    // per lane -- three aligned dword reads of the horizontal-pass rows instead of twelve byte reads, one (unaligned: a row is
+    // ow * 3 bytes) dword store instead of four byte stores.  Same integer arithmetic per byte.
+    if (!dst && u8_out && h != oh && ksy <= 3) {
+        const int nd = (rowlen + 3) >> 2;
+        for (int y = oy0; y < oy1; ++y) {
+            const int ymin = by[2 * y], cnt = by[2 * y + 1];
+            const int* k = ky + y * ksy;
+            const int k0 = k[0], k1 = cnt > 1 ? k[1] : 0, k2 = cnt > 2 ? k[2] : 0;
+            const unsigned char* tbase = trow + (size_t)(ymin - ys0) * tmp_pitch;
+            const int p1 = cnt > 1 ? tmp_pitch : 0, p2 = cnt > 2 ? 2 * tmp_pitch : 0;
+            uint8_t* urow = u8_out + ((size_t)img * oh + y) * (size_t)rowlen;
+            for (int dw = tid; dw < nd; dw += 256) {
+                const unsigned t0 = *reinterpret_cast<const unsigned*>(tbase + 4 * dw);
+                const unsigned t1 = *reinterpret_cast<const unsigned*>(tbase + p1 + 4 * dw);
+                const unsigned t2 = *reinterpret_cast<const unsigned*>(tbase + p2 + 4 * dw);
+                unsigned outw = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int ss = (1 << (PRECISION_BITS - 1)) + (int)((t0 >> (8 * b)) & 255u) * k0 + (int)((t1 >> (8 * b)) & 255u) * k1 +
+                                   (int)((t2 >> (8 * b)) & 255u) * k2;
+                    outw |= (unsigned)clip8(ss) << (8 * b);
+                }
+                if (4 * dw + 3 < rowlen) {
+                    __builtin_memcpy(urow + 4 * dw, &outw, 4);
+                } else {
+                    for (int b = 0; b < 4; ++b)
+                        if (4 * dw + b < rowlen) urow[4 * dw + b] = (uint8_t)(outw >> (8 * b));
+                }
+            }
+        }
+        return;
+    }
+
     // vertical pass + table + store, one output row at a time (row parameters are wave-uniform)
     for (int y = oy0; y < oy1; ++y) {
         const int ymin = (h == oh) ? y : by[2 * y];
