@@ -306,14 +306,15 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
             } else if (SMALLK) {
                 // taps beyond cnt carry a zero coefficient; clamp their address to stay inside the staged row
                 const int c1 = e_cnt[j] > 1 ? 3 : 0, c2 = e_cnt[j] > 2 ? 6 : 0;
-                const int ss = (1 << (PRECISION_BITS - 1)) + (int)sp[0] * e_k[j][0] + (int)sp[c1] * e_k[j][1] +
-                               (int)sp[c2] * e_k[j][2];
+                // 24-bit multiplies (a byte x a weight <= 2^22): full-rate v_mad_u32_u24 instead of quarter-rate 32-bit multiplies
+                const int ss = (1 << (PRECISION_BITS - 1)) + __mul24((int)sp[0], e_k[j][0]) + __mul24((int)sp[c1], e_k[j][1]) +
+                               __mul24((int)sp[c2], e_k[j][2]);
                 tr[e] = clip8(ss);
             } else {
                 const int ox = e / 3;
                 const int* k = kx + ox * ksx;
                 int ss = 1 << (PRECISION_BITS - 1);
-                for (int x = 0; x < e_cnt[j]; ++x) ss += (int)sp[x * 3] * k[x];
+                for (int x = 0; x < e_cnt[j]; ++x) ss += __mul24((int)sp[x * 3], k[x]);
                 tr[e] = clip8(ss);
             }
         }
@@ -339,8 +340,8 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
                 unsigned outw = 0;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const int ss = (1 << (PRECISION_BITS - 1)) + (int)((t0 >> (8 * b)) & 255u) * k0 + (int)((t1 >> (8 * b)) & 255u) * k1 +
-                                   (int)((t2 >> (8 * b)) & 255u) * k2;
+                    const int ss = (1 << (PRECISION_BITS - 1)) + __mul24((int)((t0 >> (8 * b)) & 255u), k0) +
+                                   __mul24((int)((t1 >> (8 * b)) & 255u), k1) + __mul24((int)((t2 >> (8 * b)) & 255u), k2);
                     outw |= (unsigned)clip8(ss) << (8 * b);
                 }
                 if (4 * dw + 3 < rowlen) {
@@ -375,11 +376,11 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
             if (h == oh) {
                 v = tp[0];
             } else if (cnt <= 3) {
-                const int ss = (1 << (PRECISION_BITS - 1)) + (int)tp[0] * k0 + (int)tp[p1] * k1 + (int)tp[p2] * k2;
+                const int ss = (1 << (PRECISION_BITS - 1)) + __mul24((int)tp[0], k0) + __mul24((int)tp[p1], k1) + __mul24((int)tp[p2], k2);
                 v = clip8(ss);
             } else {
                 int ss = 1 << (PRECISION_BITS - 1);
-                for (int yy = 0; yy < cnt; ++yy) ss += (int)tp[(size_t)yy * tmp_pitch] * k[yy];
+                for (int yy = 0; yy < cnt; ++yy) ss += __mul24((int)tp[(size_t)yy * tmp_pitch], k[yy]);
                 v = clip8(ss);
             }
             if (dst) {                                      // dst == nullptr: uint8 result only (the stem conv applies the table)
