@@ -287,8 +287,8 @@ int tise_gather_rows_f16(const void* x_dev, const int64_t* index_dev, int64_t n,
  *        the pixel operand is loaded (torchvision's MaxPool2d(3, 2) before Conv2d_3b_1x1 and before Mixed_5b,
  *        image_realism/FID/inception.py:61-71); bit-identical to tise_maxpool3s2_split_nhwc followed by variant 128.
  *   (Round 1's variants 0 / 32 and the other pipe configurations tied with 128 and were removed.)
- * Bits 8..11 of args->nseg are measurement switches (tools/conv_ablate.py, tools/conv_stamps.py) and must be
- * zero in product calls.
+ * Bits 8..13 of args->nseg are measurement switches (tools/conv_ablate.py, tools/conv_stamps.py; 0x2000: the epilogue
+ * converts and stages but does not store) and must be zero in product calls.
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int c0, c1;             /* output-channel range [c0, c1) of this segment (c0 % 8 == 0)             */

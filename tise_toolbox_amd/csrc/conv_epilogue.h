@@ -27,6 +27,18 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 // first): v[ci][pi] = couts 16 ci .. +15 x pixels 16 pi .. +15; a lane holds pixel 16 pi + (lane & 15) and the four
 // CONSECUTIVE couts 16 ci + 4 (lane >> 4) + k, i.e. half ((lane >> 4) & 1) of the tile's 8-cout chunk 2 ci + (lane >> 5).
 // (float16_t = the 32 x 32 block of v_mfma_f32_32x32x16_f16: pixel (lane & 31), couts 8 g + 4 (lane >> 5) + k.)
+// destination pointers come out of LDS descriptors as plain integers: tell the compiler they are GLOBAL memory, or it emits
+// flat_store (address-space check per lane, counted on both vmcnt and lgkmcnt) instead of global_store (+0.3 % images/s).
+// The stores are non-temporal (`nt`): an activation tensor is written once and read by a LATER kernel, by which time a
+// 500-image batch has pushed it out of the 32 MB of L2 anyway -- without the hint the lines it allocates evict the weights
+// and tap-shifted inputs the running kernel re-reads (+0.5 % images/s).  tools/conv_ablate.py (switch 0x2000): the stores,
+// not the conversion, are the larger part of what the epilogue costs a launch (17x17x768->704: 0.58 ms with, 0.48 without
+// the stores, 0.44 without any epilogue).
+typedef __attribute__((address_space(1))) u32x4_t* global_u32x4_ptr;
+__device__ __forceinline__ global_u32x4_ptr global_ptr(unsigned char* p) {
+    return (global_u32x4_ptr)(unsigned long long)p;
+}
+
 struct Acc16 {
     float4_t v[2][2];
 };
@@ -263,7 +275,7 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, ACC (&
 #pragma unroll
             for (int r4 = 0; r4 < NPASS; ++r4) {
                 if (r4 * rows_per_pass >= 32) continue;
-                if (cd.valid && row0 + r4 * rows_per_pass < rows_ok) *reinterpret_cast<u32x4_t*>(d) = vals[r4];
+                if (cd.valid && row0 + r4 * rows_per_pass < rows_ok && !(p.nseg & 0x2000)) __builtin_nontemporal_store(vals[r4], global_ptr(d));
                 d += step;
             }
         } else {
@@ -294,7 +306,7 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, ACC (&
             for (int r4 = 0; r4 < NPASS; ++r4) {
                 if (r4 * rows_per_pass >= 32) continue;
                 const bool ok = cd.valid && row0 + r4 * rows_per_pass < rows_ok && y < (unsigned)p.OH && x < (unsigned)p.OW;
-                if (ok) *reinterpret_cast<u32x4_t*>(d) = vals[r4];
+                if (ok) __builtin_nontemporal_store(vals[r4], global_ptr(d));
                 x += rows_per_pass;                               // next pass: rows_per_pass grid pixels further (W >= 8)
                 int adv = sx;
                 if (x >= (unsigned)p.W) {

@@ -24,7 +24,7 @@ for name, H, Cin, Cout, kh, kw, st, pad in LAYERS:
     out = torch.zeros((N, oh, ow, 2 * Cout), dtype=torch.float16, device=dev)
     line = f"{name:7s} {VARIANT} tn={conv.tn} cfg={conv.pipe_cfg} K={conv.k:5d}"
     for label, flags in (("full", 0), ("noDMA", 0x100), ("noMMA", 0x200), ("noEPI", 0x400), ("noDMA+noEPI", 0x500),
-                         ("noMMA+noEPI", 0x600), ("onlyEPI", 0x300), ("nothing", 0x700)):
+                         ("noMMA+noEPI", 0x600), ("onlyEPI", 0x300), ("nothing", 0x700), ("noSTORE", 0x2000), ("onlyEPInoSTORE", 0x2300)):
         conv.debug_flags = flags
         for _ in range(3):
             conv(x, [(0, Cout, out, 0, 0)])
