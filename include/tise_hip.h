@@ -310,7 +310,7 @@ typedef struct {
     long long M;            /* N*OH*OW                                                                 */
     int nseg;
     tise_conv_seg seg[4];
-    /* Round 3, variants 512|33 and 512|34 only (0 everywhere else): write the (OH, OW) result INTO a larger
+    /* Variant 512|34 only (the one configuration tise_conv_pipe_launch accepts; 0 everywhere else): write the (OH, OW) result INTO a larger
      * destination image of out_hp x out_wp pixels per image at offset (out_y0, out_x0) -- Conv2d_2a writes into the
      * interior of a zero-bordered 149 x 149 buffer so that the padded Conv2d_2b runs as a valid convolution with no
      * per-lane tap masks.  out_hp = 0: the destination is the plain (OH, OW) image. */

@@ -4,17 +4,13 @@ TOPOLOGY PINNED, WEIGHTS UNPINNED.  Round 3: the graph this module executes is c
 kernel / stride / padding / channels / sizes, BatchNorm eps, pools, concat order, 5 711 168 096 MAC) with the listing
 of the same network that the reference repository ships, executed by path under a stub tensorflow
 (``image_realism/IS/bird/inception/slim/inception_model.py:48-299`` -> ``tests/golden/inception_v3_topology.json``,
-``tests/test_topology.py``).  What stays unpinned is the NUMBERS of a pretrained forward: the arithmetic behind ``image_realism/FID/inception.py:57``
-(``torchvision.models.inception_v3(pretrained=True)``, torchvision==0.9.1 per
-``requirements.txt:126``) is third-party and absent from /root/reference, and the
-build container has neither torchvision nor the pretrained file.  This module
-restates torchvision's published Inception3 graph functionally from a
-torchvision-format ``state_dict`` -- unfolded conv -> batch_norm(eps=1e-3) -> relu,
-NCHW, fp32, on the CPU -- and is anchored only by the reference's call sites
-(``inception.py:59-95`` block cuts, ``:117-124`` input handling), the parameter
-count of the published model (27 161 264) and the 5.7112 GMAC/img the survey
-counted from the in-repo TF-slim listing of the same topology
-(``image_realism/IS/bird/inception/slim/inception_model.py:73-299``).
+``tests/test_topology.py``).  What stays unpinned is the NUMBERS of a pretrained forward: the arithmetic behind
+``image_realism/FID/inception.py:57`` (``torchvision.models.inception_v3(pretrained=True)``, torchvision==0.9.1 per
+``requirements.txt:126``) is third-party and absent from /root/reference, and the build container has neither
+torchvision nor the pretrained file.  This module restates torchvision's published Inception3 graph functionally from a
+torchvision-format ``state_dict`` -- unfolded conv -> batch_norm(eps=1e-3) -> relu, NCHW, fp32, on the CPU.  Beside the
+topology listing above, the reference's call sites (``inception.py:59-95`` block cuts, ``:117-124`` input handling) and
+the parameter count of the published model (27 161 264) are checked by the same tests.
 
 It deliberately shares no code with ``tise_toolbox_amd/inception.py`` (module
 tree, BN folded, channels-last, GPU) so the two can be compared.

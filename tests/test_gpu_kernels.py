@@ -508,6 +508,19 @@ def test_split_trunk_matches_module_graph(dev, dims, monkeypatch):
     err = (got - want).abs().max().item()
     assert err <= 2e-4 * want.abs().max().item(), err
     assert torch.equal(got, got_sep)
+    # ... and against the CPU ORACLE (not only the GPU module graph): the same block output of oracle/inception_oracle.py
+    # (unfolded BatchNorm, CPU fp32, no code shared with the product module), averaged as fid_score.py:110-111 does
+    from oracle import inception_oracle
+    from tise_toolbox_amd.inception import build_inception3
+    sd = {k: v.float() for k, v in build_inception3(seed=0).state_dict().items()}    # the same seeded parameters, torchvision keys
+    blk = InceptionV3.BLOCK_INDEX_BY_DIM[dims]
+    o = inception_oracle.inception_forward(sd, x.cpu().contiguous(), last_block=blk, resize_input=False,
+                                           normalize_input=False)[blk]          # x is already the network input
+    o = o.mean(dim=(2, 3), keepdim=True) if o.shape[2] != 1 else o
+    assert o.shape == got.shape
+    err_o = (got.cpu() - o).abs().max().item()
+    print(f"--dims {dims}: HIP trunk vs CPU oracle max err {err_o:.3e} of scale {o.abs().max().item():.3e}")
+    assert err_o <= 2e-4 * o.abs().max().item(), err_o
     eng = RealismEngine(dims=dims, seed=0)
     assert isinstance(eng.fused, SplitTrunk)
     u8 = torch.randint(0, 256, (5, 64, 48, 3), dtype=torch.uint8, device=dev)
@@ -1003,3 +1016,14 @@ def test_split_trunk_with_uncalibrated_checkpoint_matches_fp32_trunk(dev, tmp_pa
     print("perturbed checkpoint: feature scale", scale, "max err", err)
     assert np.isfinite(scale) and scale > 0 and err <= 1e-4 * scale
     assert (la - lb).abs().max().item() <= 1e-3 * max(1.0, lb.abs().max().item())
+    # the same checkpoint through the CPU ORACLE on 8 of the images (PIL-exact resize, unfolded BatchNorm, CPU fp32)
+    from oracle import inception_oracle, resize_oracle
+    sd_cpu = {k: v.float() for k, v in torch.load(path).items()}
+    xin = torch.from_numpy(np.stack([resize_oracle.to_tensor(resize_oracle.resize_bilinear_u8(im, 299, 299))
+                                     for im in imgs[:8].cpu().numpy()]))
+    o = inception_oracle.inception_forward(sd_cpu, xin)[3].flatten(1)
+    err_o = (fa[:8].cpu() - o).abs().max().item()
+    print("perturbed checkpoint: HIP trunk vs CPU oracle max err", err_o, "of scale", o.abs().max().item())
+    assert err_o <= 2e-4 * o.abs().max().item()
+    lo = inception_oracle.logits_from_pool3(sd_cpu, inception_oracle.inception_forward(sd_cpu, xin)[3])
+    assert (la[:8].cpu() - lo).abs().max().item() <= 1e-3 * max(1.0, lo.abs().max().item())

@@ -381,6 +381,21 @@ def test_ragged_crops_one_trunk_pass_and_per_class_fid(setup, tmp_path):
         m2, s2 = fid_score._compute_statistics_of_path(str(tmp_path / f"gen_{c}"), model, n2, 2048, True, 0)
         want = fid_score.calculate_frechet_distance(m1, s1, m2, s2)
         assert abs(per[c] - want) <= 1e-6 * max(1.0, abs(want)), (c, per[c], want)
+    # the per-class solves are SHARDED over the ranks (class i of the sorted union -> rank i mod W: reduce to the owner,
+    # solve there, all-reduce of the scalars): 2 and 3 ranks on this GPU reproduce the one-process result per class
+    for world in (2, 3):
+        outw = tmp_path / f"pc_{world}.txt"
+        res = _run_ranks(world, ["--batch-size", "4", "--path1", str(tmp_path / "ref"), "--path2", str(tmp_path / "gen"),
+                                 "--label", "O-FID", "--num-classes", "80", "--per-class", "--num-workers", "0",
+                                 "--synthetic-weights", "--saved_file", str(outw)], tmp_path)
+        assert all(rc == 0 for rc, _ in res), res
+        lines = outw.read_text().splitlines()
+        got = {ln[len("O-FID["):ln.index("]")]: float(ln.split("]: ")[1].split()[0]) for ln in lines if ln.startswith("O-FID[")}
+        assert list(got) == list(per)
+        for c in per:
+            # N << d: the shards change the fp64 summation order of S (as test_two_ranks_with_an_empty_shard)
+            assert abs(got[c] - per[c]) <= 1e-9 * max(1.0, abs(per[c])) + 1e-5, (world, c, got[c], per[c])
+        assert "cup" in lines[-1]
     # ... and the CPU ORACLE on the same crops (object_fidelity/O-FID/fid_score.py:188-205 applied to
     # one class's files): PIL-exact resize of every crop, CPU fp32 InceptionV3 with the same 80-class stand-in
     # weights, np.cov, scipy sqrtm.  |dFID| <= 1e-3.
@@ -449,6 +464,98 @@ def test_baseline_config0_1k_vs_1k_random_pngs(cuda_device, tmp_path, monkeypatc
     assert 2.0 <= want <= 200.0, want                      # the published range the absolute budget is meant for
     assert abs(got - want) <= 1e-3, (got, want)
     assert abs(got32 - want) <= 1e-3, (got32, want)
+
+
+def test_config0_style_point_near_the_top_of_the_published_range(cuda_device, tmp_path):
+    """test_baseline_config0... samples the published FID range (2 .. 200, README.md:487-497) at its bottom
+    (3.5).  Second point near the TOP: 300 generated white-noise PNGs (default_rng(0)) against 300 reference PNGs of
+    white noise at 0.47 of the contrast (default_rng(1): byte * 0.47 + 68), batch 50, through the drop-in CLI, against the
+    CPU oracle on the same files.  The oracle lands at FID ~180; the same ABSOLUTE bound |dFID| <= 1e-3."""
+    from PIL import Image
+    from tise_toolbox_amd import fid_score, img_data
+    from tise_toolbox_amd.inception import build_inception3
+    n = 300
+    for name, seed in (("gen", 0), ("ref", 1)):
+        rng = np.random.default_rng(seed)
+        os.makedirs(tmp_path / name)
+        for i in range(n):
+            im = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+            if name == "ref":
+                im = (im.astype(np.float32) * 0.47 + 68).astype(np.uint8)
+            Image.fromarray(im).save(tmp_path / name / f"{i:05d}.png", compress_level=1)
+    got = fid_score.main(["--batch-size", "50", "--path1", str(tmp_path / "ref"), "--path2", str(tmp_path / "gen"),
+                          "--num-workers", "8", "--synthetic-weights"])
+    sd = {k: v.float() for k, v in build_inception3(seed=0).state_dict().items()}
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+
+    def oracle_stats(root):
+        files = img_data.get_filenames(str(root))
+        files = files[:fid_oracle.n_used_images(len(files), 50)]
+        feats = []
+        for i in range(0, len(files), 50):
+            x = np.stack([resize_oracle.to_tensor(resize_oracle.resize_bilinear_u8(
+                np.asarray(Image.open(f).convert("RGB")), 299, 299)) for f in files[i:i + 50]])
+            feats.append(inception_oracle.inception_forward(sd, torch.from_numpy(x))[3].flatten(1).numpy())
+        return fid_oracle.calculate_activation_statistics(np.concatenate(feats).astype(np.float64))
+    want = fid_oracle.calculate_frechet_distance(*oracle_stats(tmp_path / "ref"), *oracle_stats(tmp_path / "gen"))
+    print("config0-style top-of-range point: device", got, "oracle", want, "|d|", abs(got - want))
+    assert 150.0 <= want <= 200.0, want
+    assert abs(got - want) <= 1e-3, (got, want)
+
+
+def test_device_batch_is_decoupled_from_batch_size(setup, tmp_path, monkeypatch):
+    """--batch-size defines the drop-last rule and the shard borders (fid_score.py:90-96,215-217), NOT
+    the size of a trunk pass: the loader's batches are gathered into device batches of up to TISE_DEVICE_BATCH images
+    (engine.device_batch_images / coalesce_u8; img_data.U8CacheLoader(group=K)).  Features are bit-identical whatever the
+    grouping; the FID moves only by the fp64 summation order of S."""
+    from PIL import Image
+    from tise_toolbox_amd import engine, fid_score
+    from tise_toolbox_amd.inception import InceptionV3
+    assert engine.device_batch_images(50) == 1000 and engine.device_batch_images(64) == 960
+    assert engine.device_batch_images(3000) == 3000 and engine.device_batch_images(50, 4096 * 4096 * 3) == 50
+    dev = setup["dev"]
+    model = InceptionV3([3], seed=0).cuda()
+    batches = [torch.from_numpy(setup["gen"][i:i + 4]) for i in range(0, 44, 4)]          # 11 host batches of 4
+    passes = []
+    orig = engine.RealismEngine.features_from_u8
+
+    def spy(self, b):
+        passes.append(int(b.shape[0]))
+        return orig(self, b)
+    monkeypatch.setattr(engine.RealismEngine, "features_from_u8", spy)
+    acts = {}
+    for limit in ("4", "12", "1000"):
+        monkeypatch.setenv("TISE_DEVICE_BATCH", limit)
+        passes.clear()
+        acts[limit] = fid_score.get_activations(batches, model, batch_size=4, dims=2048, cuda=True, verbose=False)
+        assert passes == {"4": [4] * 11, "12": [12, 12, 12, 8], "1000": [44]}[limit], (limit, passes)
+    assert acts["4"].shape == (44, 2048) and np.array_equal(acts["4"], acts["12"]) and np.array_equal(acts["4"], acts["1000"])
+    # a device batch in the middle of the list keeps its place; ragged lists pass through in order
+    mixed = [batches[0], batches[1].to(dev), [torch.from_numpy(setup["gen"][8][:100, :90].copy()), torch.from_numpy(setup["gen"][9])], batches[3]]
+    got = list(engine.coalesce_batches(iter(mixed), dev, 1000))
+    assert [len(g) for g in got] == [8, 2, 4] and isinstance(got[1], list)
+    assert torch.equal(got[0].cpu(), torch.cat([batches[0], batches[1]])) and torch.equal(got[2].cpu(), batches[3])
+    # the CLI, PNG and --u8-cache feeds: 23 generated / 17 reference images at batch 4 -> 20 / 16 used
+    gdir, rdir = tmp_path / "gen", tmp_path / "ref"
+    gdir.mkdir(); rdir.mkdir()
+    for i in range(23):
+        Image.fromarray(setup["gen"][i]).save(gdir / f"{i:05d}.png")
+    for i in range(17):
+        Image.fromarray(setup["ref"][i]).save(rdir / f"{i:05d}.png")
+    argv = ["--batch-size", "4", "--path1", str(rdir), "--path2", str(gdir), "--num-workers", "2", "--synthetic-weights"]
+    fids = {}
+    for limit in ("4", "12", "1000"):
+        monkeypatch.setenv("TISE_DEVICE_BATCH", limit)
+        passes.clear()
+        fids[limit, "png"] = fid_score.main(argv)
+        assert sum(passes) == 36 and max(passes) == min(int(limit), 20), (limit, passes)
+        passes.clear()
+        fids[limit, "u8"] = fid_score.main(argv + ["--u8-cache"])
+        assert sum(passes) == 36 and max(passes) == min(int(limit), 20), (limit, passes)
+    ref_fid = fids["4", "png"]
+    print("FID by device batch / feed:", fids)
+    for k, v in fids.items():
+        assert abs(v - ref_fid) <= 1e-6, (k, v, ref_fid)        # N << d: only the summation order of S differs
 
 
 def test_split_trunk_vs_exact_fp32_convs_3000_images(cuda_device, monkeypatch):

@@ -107,39 +107,52 @@ def test_rp_cli_end_to_end_with_stand_in_towers(cuda_device, tmp_path):
     Checked against the oracle applied to the SAME embeddings (the towers themselves: parity unpinned)."""
     from PIL import Image
     from tise_toolbox_amd import RP_coco, clip_model
-    rng = np.random.default_rng(0)
+    from tise_toolbox_amd.weights import SYNTHETIC_TAG
     words = ["a", "red", "bus", "dog", "on", "the", "grass", "two", "people", "near", "table"]
-    items = []
-    img_dir = tmp_path / "images"
-    img_dir.mkdir()
-    pool = [" ".join(rng.choice(words, 5)) + f" x{k}" for k in range(30)]          # mismatched captions repeat
-    for i in range(23):
-        items.append({"caption_id": 100 + i, "caption": " ".join(rng.choice(words, 5)) + f" {i}",
-                      "mismatched_captions": [pool[(i * 3 + 5 * j) % 30] for j in range(6)]})
-        Image.fromarray(rng.integers(0, 256, (64, 80, 3), dtype=np.uint8)).save(img_dir / f"{100 + i}.png")
+    model, scale = RP_coco.build_towers(None, cuda_device)
+
+    def make_case(data_seed, root):
+        rng = np.random.default_rng(data_seed)
+        items = []
+        img_dir = root / f"images{data_seed}"
+        img_dir.mkdir()
+        pool = [" ".join(rng.choice(words, 5)) + f" x{k}" for k in range(30)]          # mismatched captions repeat
+        for i in range(23):
+            items.append({"caption_id": 100 + i, "caption": " ".join(rng.choice(words, 5)) + f" {i}",
+                          "mismatched_captions": [pool[(i * 3 + 5 * j) % 30] for j in range(6)]})
+            Image.fromarray(rng.integers(0, 256, (64, 80, 3), dtype=np.uint8)).save(img_dir / f"{100 + i}.png")
+        # oracle on the embeddings of the towers the CLI builds (csrc/clip_ops.hip by default)
+        caps, index = RP_coco.caption_table(items)
+        assert len(caps) < 23 * 7                                         # captions are de-duplicated
+        txt = RP_coco.embed_texts(model, clip_model.HashTokenizer(), caps, cuda_device, 8).float().cpu().numpy().astype(np.float64)
+        img = RP_coco.embed_images(model, str(img_dir), [it["caption_id"] for it in items], cuda_device, 8, workers=0)
+        img = img.float().cpu().numpy().astype(np.float64)
+        success, margins = [], []
+        for i in range(len(items)):
+            lg = rp_oracle.clip_logits(img[i], txt[index[i]], scale, normalize=False)
+            success.append(int(np.argmax(lg) == 0))
+            margins.append(np.sort(lg)[-1] - np.sort(lg)[-2])
+        return items, img_dir, success, min(margins)
+
+    # the fp64 oracle is only an oracle where no item is a near-tie (the kernel rounds what CLIP.forward rounds: the test
+    # below covers that side): take the first data seed whose smallest top-1 margin is clear, and REQUIRE that one exists
+    case = None
+    for data_seed in range(8):
+        items, img_dir, success, margin = make_case(data_seed, tmp_path)
+        if margin > 1e-3:
+            case = (items, img_dir, success)
+            break
+    assert case is not None, "no data seed in 0..7 without a near-tie"
+    items, img_dir, success = case
     pkl = tmp_path / "rp.pkl"
     pickle.dump(items, open(pkl, "wb"))
     out = tmp_path / "rp.txt"
     mean, std = RP_coco.main(["--image_dir", str(img_dir), "--rp_input_file", str(pkl), "--saved_file_path", str(out),
                               "--gpu_id", str(cuda_device.index or 0), "--seed", "4", "--batch-size", "8",
                               "--num-workers", "0", "--synthetic-weights"])
-    from tise_toolbox_amd.weights import SYNTHETIC_TAG
     assert open(out).read() == f"R-precision: {mean} +- {std}" + SYNTHETIC_TAG
-    # oracle on the same embeddings (the same towers the CLI built: csrc/clip_ops.hip by default)
-    model, scale = RP_coco.build_towers(None, cuda_device)
-    caps, index = RP_coco.caption_table(items)
-    assert len(caps) < 23 * 7                                         # captions are de-duplicated
-    txt = RP_coco.embed_texts(model, clip_model.HashTokenizer(), caps, cuda_device, 8).float().cpu().numpy().astype(np.float64)
-    img = RP_coco.embed_images(model, str(img_dir), [it["caption_id"] for it in items], cuda_device, 8, workers=0)
-    img = img.float().cpu().numpy().astype(np.float64)
-    success, margins = [], []
-    for i in range(len(items)):
-        lg = rp_oracle.clip_logits(img[i], txt[index[i]], scale, normalize=False)
-        success.append(int(np.argmax(lg) == 0))
-        margins.append(np.sort(lg)[-1] - np.sort(lg)[-2])
-    if min(margins) > 1e-3:
-        m2, s2, _ = rp_oracle.rp_score(success, RP_coco.shuffled_ids(len(items), 4))
-        assert (m2, s2) == (mean, std)
+    m2, s2, _ = rp_oracle.rp_score(success, RP_coco.shuffled_ids(len(items), 4))
+    assert (m2, s2) == (mean, std)
 
 
 def test_fp16_near_ties_resolve_like_clip_forward(cuda_device):

@@ -128,6 +128,14 @@ def rowwin_fits(ow, kw):
 PIPE_BN = {34: 64}
 
 
+def pipe_fits(w, cout):
+    """LDS budget of configuration 34 (conv_pipe.hip launch_regw32: input ring + epilogue area + staging <= 160 KB)."""
+    tpi = 64 // cout
+    r16 = (128 * tpi + 2 * w + 2 + 15) & ~15
+    pf = 2 if cout == 64 else 1
+    return w >= 8 and (r16 + 128 * tpi * pf) * 128 + 2048 + 8 * 32 * (128 + 16) <= 160 * 1024
+
+
 class SplitConv:
     """One (possibly channel-concatenated) convolution with folded scale/bias, packed for the kernel."""
 
@@ -158,6 +166,7 @@ class SplitConv:
         self.cout_pad = max(-(-cout // (32 * t)) * 32 * t for t in (1, 2, 3, 4, 5))
         if self.variant == "pipe":                              # resident-weights sliding-window kernel (conv_pipe.hip)
             self.pipe_cfg = 34 if pipe_cfg is None else pipe_cfg
+            self._orig = (weight.detach().float().cpu(), bias.detach().float().cpu())       # see __call__
         self.k = kh * kw * cin
         self.kpad = -(-self.k // 32) * 32
         w = weight.detach().float().cpu()
@@ -241,6 +250,11 @@ class SplitConv:
             # at KW = 3): the default kernel serves the layer from its own packing, built on first use
             if self._fallback is None:
                 self._fallback = SplitConv(self._orig[0], self._orig[1], self.stride, self.padding, x.device, tn=self.tn, variant="fast")
+            return self._fallback(x, segs)
+        if self.pipe_cfg is not None and out_pad is None and not pipe_fits(w, self.cout):
+            # image rows so long that the sliding ring does not fit the LDS (W > ~230): the default kernel, built on first use
+            if self._fallback is None:
+                self._fallback = SplitConv(self._orig[0], self._orig[1], self.stride, self.padding, x.device, variant="fast")
             return self._fallback(x, segs)
         a = ConvArgs()
         a.x = x.data_ptr()

@@ -305,7 +305,7 @@ __device__ __forceinline__ void store_tiles_desc(const tise_conv_args& p, ACC (&
 #pragma unroll
             for (int r4 = 0; r4 < NPASS; ++r4) {
                 if (r4 * rows_per_pass >= 32) continue;
-                const bool ok = cd.valid && row0 + r4 * rows_per_pass < rows_ok && y < (unsigned)p.OH && x < (unsigned)p.OW;
+                const bool ok = cd.valid && row0 + r4 * rows_per_pass < rows_ok && y < (unsigned)p.OH && x < (unsigned)p.OW && !(p.nseg & 0x2000);
                 if (ok) __builtin_nontemporal_store(vals[r4], global_ptr(d));
                 x += rows_per_pass;                               // next pass: rows_per_pass grid pixels further (W >= 8)
                 int adv = sx;

@@ -66,6 +66,22 @@ def all_reduce_sum_(t):
     return t
 
 
+def reduce_sum_(t, dst):
+    """In-place SUM reduce of ``t`` to rank ``dst`` (other ranks' copies are left undefined); identity for one process.
+    RCCL: a real reduce (a ring moves the buffer once instead of twice).  gloo has no reduce for device tensors
+    (tests on a single-GPU box, TISE_DIST_BACKEND=gloo): an all-reduce gives the owner the same sum."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl" or not t.is_cuda:
+            dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
 def broadcast_module_(module, src=0):
     """Overwrite every parameter and buffer of `module` with rank `src`'s values (identity for 1 process)."""
     if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):

@@ -248,6 +248,101 @@ class RealismEngine:
         return mean, std
 
 
+# ---- device batch: decoupled from the loader's --batch-size ------------------------------------------------
+def device_batch_images(batch_size, image_bytes=256 * 256 * 3):
+    """Images per trunk pass for a loader that delivers ``batch_size`` images at a time: whole loader batches up to
+    TISE_DEVICE_BATCH images (default 1000: the trunk's launches -- 85 per pass -- and tile tails are amortised over
+    1000 images instead of the README recipe's 50, README.md:214-219) and at most 1 GiB of uint8 pixels.  The
+    reference's ``--batch-size`` keeps its one semantic role, the drop-last rule (fid_score.py:90-96,215-217);
+    features do not depend on how images are batched (tests/test_gpu_kernels.py: batch invariance, bit for bit)."""
+    target = int(os.environ.get("TISE_DEVICE_BATCH", "1000"))
+    cap = max(1, (1 << 30) // max(1, int(image_bytes)))
+    target = max(1, min(target, cap))
+    return max(1, target // max(1, int(batch_size))) * int(batch_size)
+
+
+def coalesce_u8(batches, dev, limit):
+    """Generator: consecutive equal-shaped uint8 (B, H, W, 3) batches of ``batches`` (host -- pinned or not -- or device
+    tensors) gathered into device batches of up to ``limit`` images, in order; anything else (ragged crop lists, float
+    tensors, a batch of another image size) passes through unchanged after what was gathered before it.
+    Two staging buffers: the copies of the NEXT device batch run on a side stream while the trunk works on the current
+    one; a buffer is refilled only after the consumer's stream has passed the point where it handed it back."""
+    dev = torch.device(dev)
+    side = torch.cuda.Stream(device=dev)
+    bufs, freed, keep = [None, None], [None, None], []
+    cur, fill = 0, 0
+
+    def flush():
+        nonlocal cur, fill
+        done = torch.cuda.Event()
+        done.record(side)
+        torch.cuda.current_stream(dev).wait_event(done)
+        out = bufs[cur][:fill]
+        return out
+
+    def handed_back():
+        nonlocal cur, fill
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        freed[cur] = ev
+        cur ^= 1
+        fill = 0
+        keep.clear()                                          # (the side stream finished with the host batches: `done` was waited on)
+
+    for b in batches:
+        dense = isinstance(b, torch.Tensor) and b.dtype == torch.uint8 and b.dim() == 4 and b.shape[3] == 3
+        if not dense or b.shape[0] >= limit:
+            if fill:
+                yield flush()
+                handed_back()
+            yield b
+            continue
+        if fill and (tuple(bufs[cur].shape[1:]) != tuple(b.shape[1:]) or fill + b.shape[0] > limit):
+            yield flush()
+            handed_back()
+        if bufs[cur] is None or tuple(bufs[cur].shape[1:]) != tuple(b.shape[1:]):
+            bufs[cur] = torch.empty((limit,) + tuple(b.shape[1:]), dtype=torch.uint8, device=dev)
+        if fill == 0 and freed[cur] is not None:
+            side.wait_event(freed[cur])
+        if b.is_cuda:                                          # produced on the consumer's stream
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            side.wait_event(ev)
+        with torch.cuda.stream(side):
+            bufs[cur][fill:fill + b.shape[0]].copy_(b, non_blocking=True)
+        keep.append(b)                                         # a pinned host batch must outlive its asynchronous copy
+        fill += b.shape[0]
+    if fill:
+        yield flush()
+        handed_back()
+    side.synchronize()
+
+
+def coalesce_batches(loader, dev, limit):
+    """Device batches for crop directories: equal-sized uint8 batches are gathered by coalesce_u8; ragged batches
+    (lists of crops of different sizes, img_data.collate_u8) are concatenated up to ``limit`` crops, so that the trunk
+    runs once per ~1000 crops whatever --batch-size is (order preserved)."""
+    pending = []
+
+    def ragged(it):
+        nonlocal pending
+        for b in it:
+            if isinstance(b, (list, tuple)):
+                if pending and len(pending) + len(b) > limit:
+                    yield pending
+                    pending = []
+                pending = pending + list(b)
+            else:
+                if pending:
+                    yield pending
+                    pending = []
+                yield b
+        if pending:
+            yield pending
+            pending = []
+    return coalesce_u8(ragged(loader), dev, limit)
+
+
 _SOLVERS = {}
 
 

@@ -124,18 +124,23 @@ class U8CacheLoader:
     a buffer is reused once the consumer's stream has passed the point where it was handed back.  Same contract as the
     DataLoader it replaces: ``len()`` = number of batches, drop_last=True semantics (fid_score.py:215-217).  ``rows`` =
     (lo, hi) restricts it to a shard of the cache (data-parallel runs).  ``h2d_seconds``: time the feeder spent reading
-    and enqueueing (not waiting for buffers)."""
+    and enqueueing (not waiting for buffers).
+    ``group`` = K > 1: the DEVICE batch is decoupled from ``batch_size`` -- an item is K consecutive batches (the last
+    item whatever whole batches remain), read, copied and handed over as one tensor; ``len()`` still counts batches of
+    ``batch_size`` (the drop-last bookkeeping of fid_score.py:90-96), ``pregrouped`` tells the consumer."""
 
     NBUF = 3
     READERS = 4
 
-    def __init__(self, cache_path, batch_size, device, rows=None):
+    def __init__(self, cache_path, batch_size, device, rows=None, group=1):
         self.path = cache_path
         self.arr = np.load(cache_path, mmap_mode="r")
         if self.arr.ndim != 4 or self.arr.shape[3] != 3 or self.arr.dtype != np.uint8:
             raise ValueError(f"{cache_path}: expected a (N, H, W, 3) uint8 array")
         self.lo, self.hi = rows if rows is not None else (0, self.arr.shape[0])
         self.bs = int(batch_size)
+        self.group = max(1, int(group))
+        self.pregrouped = self.group > 1
         self.device = torch.device(device)
         self.h2d_seconds = 0.0
 
@@ -147,12 +152,13 @@ class U8CacheLoader:
         import threading
         import time
         from concurrent.futures import ThreadPoolExecutor
-        nb = len(self)
-        if nb == 0:
+        n_rows = len(self) * self.bs                                    # whole batches only
+        if n_rows == 0:
             return
-        shape = (self.bs,) + tuple(self.arr.shape[1:])
+        item_rows = self.bs * self.group
+        nb = -(-n_rows // item_rows)                                     # items; the last one may be shorter
+        shape = (min(item_rows, n_rows),) + tuple(self.arr.shape[1:])
         row_bytes = int(np.prod(shape[1:]))
-        batch_bytes = self.bs * row_bytes
         data_offset = int(self.arr.offset)
         nbuf = min(self.NBUF, nb)
         pinned = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
@@ -185,14 +191,16 @@ class U8CacheLoader:
                             return
                         consumed[k].synchronize()                        # ... and its stream is past that point
                         t0 = time.perf_counter()
-                        off = data_offset + (self.lo + b * self.bs) * row_bytes
+                        rows = min(item_rows, n_rows - b * item_rows)
+                        batch_bytes = rows * row_bytes
+                        off = data_offset + (self.lo + b * item_rows) * row_bytes
                         step = -(-batch_bytes // self.READERS)
                         list(pool.map(lambda i: read_chunk(k, off, i * step, min(batch_bytes, (i + 1) * step)), range(self.READERS)))
                         with torch.cuda.stream(side):
-                            dev[k].copy_(pinned[k], non_blocking=True)
+                            dev[k][:rows].copy_(pinned[k][:rows], non_blocking=True)
                             ready[k].record(side)
                         self.h2d_seconds += time.perf_counter() - t0
-                        out.put(k)
+                        out.put((k, rows))
             except BaseException as e:                                   # noqa: BLE001 -- re-raised in the consumer
                 out.put(e)
 
@@ -203,9 +211,10 @@ class U8CacheLoader:
                 k = out.get()
                 if isinstance(k, BaseException):
                     raise k
+                k, rows = k
                 cur = torch.cuda.current_stream(self.device)
                 cur.wait_event(ready[k])
-                yield dev[k]
+                yield dev[k][:rows]
                 consumed[k].record(torch.cuda.current_stream(self.device))
                 handed[k].release()
         finally:

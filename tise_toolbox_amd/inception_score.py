@@ -104,7 +104,10 @@ def get_inception_score(images, splits=10):
     eng.begin(n_total=n, temperature=_CONFIG["temperature"], splits=splits, rule=_CONFIG["rule"],
               drop_first_class=_CONFIG["drop_first_class"])
     base = lo
-    for batch in loader:
+    # --batch-size is the loader's batch; a trunk pass takes up to engine.device_batch_images of them (split membership
+    # is by global index, so batching changes nothing: tests/test_gpu_kernels.py batch invariance)
+    from .engine import coalesce_batches, device_batch_images
+    for batch in coalesce_batches(loader, eng.device, device_batch_images(bs)):
         if isinstance(batch, (list, tuple)):              # images of different sizes: one trunk pass for the batch
             eng.step_u8_list(batch, base)
             base += len(batch)

@@ -78,7 +78,10 @@ def inception_score(imgs, cuda=True, batch_size=32, resize=False, splits=1, weig
                                          collate_fn=img_data.collate_u8 if isinstance(imgs, IgnoreLabelDataset) else None)
     eng.begin(n_total=N, temperature=temperature, splits=splits, rule="ois")
     base = lo
-    for batch in loader:
+    # batch_size (32 in the reference's call, :122) is the loader's batch; a trunk pass takes up to
+    # engine.device_batch_images of them
+    from .engine import coalesce_batches, device_batch_images
+    for batch in coalesce_batches(loader, eng.device, device_batch_images(batch_size)):
         if isinstance(batch, (list, tuple)):              # crops of different sizes: resized into ONE batch
             feats, logits = eng.features_from_u8_list(batch)
         elif batch.dtype == torch.uint8:

@@ -308,7 +308,9 @@ class SplitTrunk(FusedTrunk):
         self.sblocks = [(kind, {k: sc(v) for k, v in P.items()}) for kind, P in self.blocks]
         # the two stem max-pools are taken inside the operand load of the 1x1 convolutions that consume them
         # (Conv2d_3b; Mixed_5b's fused 1x1): conv_poolin_kernel, bit-identical to pooling first.  TISE_POOL_FUSE=0: separate kernels
-        self.fuse_pool = os.environ.get("TISE_POOL_FUSE", "1") != "0"
+        # (only with the default packing of the consuming convolutions: a TISE_CONV_VARIANT=glds / rowwin A/B run pools first)
+        consumers = ([self.s3b] if self.last_block >= 1 else []) + ([self.sblocks[0][1]["f"]] if self.last_block >= 2 else [])
+        self.fuse_pool = os.environ.get("TISE_POOL_FUSE", "1") != "0" and all(c.variant == "fast" for c in consumers)
 
     # ---- helpers on split tensors (N, H, W, 2C) fp16 --------------------------------------------------
     @staticmethod
@@ -439,7 +441,9 @@ class SplitTrunk(FusedTrunk):
         n, h, w, _ = u8_nhwc.shape
         oh, ow = (h - 3) // 2 + 1, (w - 3) // 2 + 1
         a = self._new(n, oh, ow, 32, u8_nhwc.device)
-        if self.stem_mfma and w >= 5:
+        # the matrix-core stem reads aligned 16-byte windows: a 4-byte-aligned tensor of at least 32 bytes (a slice u8[i:j] of
+        # 299 x 299 x 3 images starts on an odd address: the fp32-FMA kernel serves it, same results to the last layer's 1e-6)
+        if self.stem_mfma and w >= 5 and u8_nhwc.data_ptr() % 4 == 0 and u8_nhwc.numel() >= 32:
             _lib.call("tise_stem_conv3x3s2_split_u8_mfma", _p(u8_nhwc), _p(lut_dev), n, h, w, _p(self.stem_wsplit), _p(self.stem_scale),
                       _p(self.c1a.b), _p(a), _stream())
         else:
@@ -449,20 +453,27 @@ class SplitTrunk(FusedTrunk):
 
     def _zero_bordered(self, n, hp, wp, c, dev):
         """Persistent split tensor (n, hp, wp, 2c) whose border stays zero: allocated and zeroed once per shape (the two
-        most recent shapes are kept), only its interior is ever written."""
+        most recent shapes are kept), only its interior is ever written.  With hipGraph replay (TISE_GRAPH=1) nothing is
+        evicted: a captured graph holds the raw address of the buffer of its batch shape."""
         key = (n, hp, wp, c, str(dev))
         buf = self._padbufs.pop(key, None)
         if buf is None:
             buf = torch.zeros((n, hp, wp, 2 * c), dtype=torch.float16, device=dev)
-            while len(self._padbufs) >= 2:
+            while len(self._padbufs) >= 2 and os.environ.get("TISE_GRAPH", "0") != "1":
                 self._padbufs.pop(next(iter(self._padbufs)))
         self._padbufs[key] = buf                                        # most recently used last
         return buf
 
     def _after_stem(self, a):
-        if self.pad2b:
-            n, h, w, _ = a.shape
-            oh, ow = self.s2a.out_hw(h, w)
+        from .conv_split import SplitConv, pipe_fits
+        n, h, w, _ = a.shape
+        oh, ow = self.s2a.out_hw(h, w)
+        if self.pad2b and not (pipe_fits(w, self.s2a.cout) and pipe_fits(ow + 2, self.s2b.cout)):
+            # inputs wider than the sliding-window kernels' LDS ring (never the 299 x 299 network input): default kernels
+            if getattr(self, "_s2b_wide", None) is None:
+                self._s2b_wide = SplitConv(self.c2b.w, self.c2b.b, self.c2b.stride, self.c2b.padding, self.device, variant="fast")
+            a = self._sconv(self._s2b_wide, self._sconv(self.s2a, a))
+        elif self.pad2b:
             buf = self._zero_bordered(n, oh + 2, ow + 2, self.s2a.cout, a.device)
             self.s2a(a, [(0, self.s2a.cout, buf, 0, 0)], out_pad=(oh + 2, ow + 2, 1, 1))
             a = self._sconv(self.s2b, buf)

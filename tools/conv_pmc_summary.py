@@ -102,7 +102,7 @@ if have:
           "the conv launches of ONE trunk forward at batch 500 (the last of three), summed per kernel instance.", "",
           "* `MFMA util` = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): share of ALL SIMD cycles of the launch in",
           "  which the SIMD's matrix core was executing (rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs and the SQ counters over all",
-          "  SIMDs; cross-check: SQ_VALU_MFMA_BUSY_CYCLES = 32 x SQ_INSTS_MFMA, the 8 passes x 4 cycles of a 32x32x16 MFMA)",
+          "  SIMDs; cross-check: SQ_VALU_MFMA_BUSY_CYCLES = 16 x SQ_INSTS_MFMA, the 4 passes x 4 cycles of a 16x16x32 MFMA)",
           "* `vs clock-free peak`: the same figure is fp16-MFMA rate / (1024 SIMDs x 1024 flop/clk x the clock the chip actually ran)",
           "* `VALU:MFMA` = SQ_INSTS_VALU / SQ_INSTS_MFMA (SQ_INSTS_VALU counts the MFMAs as well)",
           "* `issue-stall` = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, `parked` = SQ_WAIT_ANY / SQ_WAVE_CYCLES", "",
