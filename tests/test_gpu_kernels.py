@@ -705,6 +705,48 @@ def test_conv_pooled_input_is_bit_identical_to_pool_then_conv(dev):
         assert (got - want).abs().max().item() <= 4e-6 * max(1.0, want.abs().max().item()), (H, W, Cin, Cout)
 
 
+def test_conv_pooled_output_is_bit_identical_to_conv_then_pool(dev):
+    """Round 4 (inception.py:63-65: Conv2d_2b -> MaxPool2d(3, 2)): the register-weights kernel with the
+    max-pool in its EPILOGUE (conv_pipe.hip, POOL instance: per-column running maxima in LDS while the workgroup walks the
+    conv rows, horizontal pass per tile) against the two-kernel path it replaces -- the same kernel writing the full
+    result, then tise_maxpool3s2_split_nhwc: the pooled (hi, lo) pairs must be equal bit for bit; and against an fp64
+    convolution + max-pool.  Shapes: the trunk's (149^2 zero-bordered -> 147^2 -> 73^2) at batch sizes that cut the
+    workgroups' runs of pool rows inside and between images, the narrowest and widest grids the kernel takes, odd / even
+    output sizes, one image, constant regions (exact ties between taps), a channel slice of a wider destination."""
+    import torch.nn.functional as F
+    from tise_toolbox_amd.conv_split import SplitConv, merge, new_split, pool_output_fits, split
+    from tise_toolbox_amd.trunk import SplitTrunk
+    g = torch.Generator(device="cpu").manual_seed(41)
+    w = (torch.randn((64, 32, 3, 3), generator=g) * (2.0 / 288) ** 0.5).to(dev)
+    b = (torch.randn(64, generator=g) * 0.2).to(dev)
+    conv = SplitConv(w, b, (1, 1), (0, 0), dev, variant="pipe", pipe_cfg=34)
+    for (n, H, W) in [(3, 149, 149), (1, 149, 149), (37, 149, 149), (2, 7, 128), (5, 12, 131), (3, 10, 152), (4, 5, 140), (9, 149, 150)]:
+        assert pool_output_fits(W, W - 2)
+        x = torch.rand((n, H, W, 32), generator=g) * 2.0
+        x[:, : H // 2, : W // 3] = 0.75                                # constant windows: ties between taps and between rows
+        x[:, :, 0] = 0; x[:, :, -1] = 0; x[:, 0] = 0; x[:, -1] = 0    # (the trunk's input has a zero border; any input is legal)
+        xs = split(x.to(dev))
+        oh, ow = H - 2, W - 2
+        ph, pw = (oh - 3) // 2 + 1, (ow - 3) // 2 + 1
+        full = new_split(n, oh, ow, 64, dev)
+        conv(xs, [(0, 64, full, 0, 0)])
+        want = SplitTrunk._maxpool_split(full)
+        got = torch.full((n, ph, pw, 128), 9.0, dtype=torch.float16, device=dev)
+        assert conv(xs, [(0, 64, got, 0, 0)], pool_output=True) == (ph, pw)
+        assert torch.equal(got, want), (n, H, W)
+        again = torch.zeros_like(got)
+        conv(xs, [(0, 64, again, 0, 0)], pool_output=True)
+        assert torch.equal(again, got)                                  # run-to-run (a race in V / HV would show here)
+        # into channels 32..95 of a 128-channel tensor: the rest untouched
+        wide = torch.full((n, ph, pw, 256), 3.0, dtype=torch.float16, device=dev)
+        conv(xs, [(0, 64, wide, 32, 0)], pool_output=True)
+        mw = merge(wide)
+        assert torch.equal(mw[..., 32:96], merge(want)) and bool((mw[..., :32] == 3.0 + 3.0 / 2048).all()) and bool((mw[..., 96:] == 3.0 + 3.0 / 2048).all())
+        ref = F.max_pool2d(torch.relu(F.conv2d(merge(xs).double().permute(0, 3, 1, 2), w.double(), b.double())), 3, 2).permute(0, 2, 3, 1)
+        err = (merge(got).double() - ref).abs().max().item()
+        assert err <= 4e-6 * ref.abs().max().item(), (n, H, W, err)
+
+
 def test_split_trunk_fused_pools_do_not_change_a_bit(dev, monkeypatch):
     """The whole trunk with the stem max-pools fused into their consumers == the trunk with separate pool kernels."""
     from tise_toolbox_amd.inception import InceptionV3

@@ -136,6 +136,13 @@ def pipe_fits(w, cout):
     return w >= 8 and (r16 + 128 * tpi * pf) * 128 + 2048 + 8 * 32 * (128 + 16) <= 160 * 1024
 
 
+def pool_output_fits(w, ow):
+    """Configuration 34 with the max-pool in its epilogue (conv_pipe.hip launch_regw32_pool): a 128-pixel tile spans at most
+    two grid rows, the horizontal buffer keeps 130 columns, ring + column state within 160 KB of LDS."""
+    r16 = (128 + 2 * w + 2 + 15) & ~15
+    return 128 <= w <= 260 and ow >= 3 and (r16 + 256) * 128 + 2048 + ow * 256 + 130 * 256 <= 160 * 1024
+
+
 class SplitConv:
     """One (possibly channel-concatenated) convolution with folded scale/bias, packed for the kernel."""
 
@@ -229,13 +236,16 @@ class SplitConv:
         """Output grid of ``__call__(..., pooled_input=True)``: max_pool2d(3, stride 2) of the input, then this 1x1 conv."""
         return (h - 3) // 2 + 1, (w - 3) // 2 + 1
 
-    def __call__(self, x, segs, pooled_input=False, out_pad=None):
+    def __call__(self, x, segs, pooled_input=False, out_pad=None, pool_output=False):
         """x: split tensor (N, H, W, 2*Cin) fp16.  segs: list of (c0, c1, dst_tensor, dst_off, mode):
         mode 0 -> dst is a split tensor (N, OH, OW, 2*C), mode 1 -> dst is a (N, OH, OW, C) fp32 tensor.
         ``pooled_input``: the convolution (1x1, Cin % 32 == 0, default packing) reads max_pool2d(x, 3, stride 2) -- the
         pool is taken while loading the operand (conv_poolin_kernel), bit-identical to pooling first.
         ``out_pad`` = (hp, wp, y0, x0) (sliding-window kernels only): the destination tensors are (N, hp, wp, ...) images
-        and the (OH, OW) result is written at offset (y0, x0) inside them (the rest is left untouched)."""
+        and the (OH, OW) result is written at offset (y0, x0) inside them (the rest is left untouched).
+        ``pool_output`` (configuration 34, 64 couts, unpadded: Conv2d_2b on its zero-bordered input): the destinations are split
+        tensors of max_pool2d(result, 3, stride 2) -- the pool is taken in the kernel's epilogue, bit-identical to
+        pooling the stored result; returns the pooled (OH', OW')."""
         assert x.dtype == torch.float16 and x.dim() == 4 and x.shape[3] == 2 * self.cin and x.is_contiguous()
         n, h, w, _ = x.shape
         oh, ow = self.out_hw(h, w)
@@ -268,6 +278,10 @@ class SplitConv:
         a.M = n * oh * ow
         a.nseg = len(segs) | getattr(self, "debug_flags", 0)
         dshape = (n, oh, ow)
+        if pool_output:
+            assert self.pipe_cfg == 34 and self.cout == 64 and self.padding == (0, 0) and out_pad is None and not pooled_input
+            assert pool_output_fits(w, ow) and oh >= 3 and all(sg[4] == 0 for sg in segs)
+            dshape = (n, (oh - 3) // 2 + 1, (ow - 3) // 2 + 1)
         if out_pad is not None:
             hp, wp, y0, x0 = out_pad
             assert self.pipe_cfg is not None and not pooled_input and y0 + oh <= hp and x0 + ow <= wp and min(y0, x0) >= 0
@@ -294,11 +308,11 @@ class SplitConv:
         if pooled_input:
             code = min(max(tn, 2), 4) | 256
         elif self.pipe_cfg is not None:
-            code = 512 | self.pipe_cfg
+            code = 512 | self.pipe_cfg | (1024 if pool_output else 0)
         else:
             code = tn | {"glds": 16, "fast": 128, "rowwin": 64}[self.variant]
         _lib.call("tise_conv_split_f16", ctypes.byref(a), code, stream)
         if timer is not None:
             e1.record()
             timer.append((e0, e1, 2.0 * a.M * self.cout * self.k))
-        return oh, ow
+        return (dshape[1], dshape[2]) if pool_output else (oh, ow)

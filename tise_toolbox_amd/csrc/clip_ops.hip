@@ -336,6 +336,171 @@ __global__ __launch_bounds__(512, 1) void gemm_f16_big_kernel(const GemmArgs p) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: both GEMM kernels on v_mfma_f32_16x16x32_f16 (gemm16_f16_kernel<BIG>).  Same tiles, LDS images, DMA and
+// epilogue staging as the two kernels above; inside a wave a fragment is 16 rows x 32 K (lane -> row lane & 15, 16-byte
+// chunk lane >> 4 of the K-step's first or second 64 bytes) and the accumulator four-register blocks of 16 x 16.  The
+// convolution kernels made the same move in round 3 (same flop, same LDS bytes, but the K = 32 shape reads and
+// writes half the accumulator registers per flop and the chip holds 1.79 instead of 1.52 GHz under its power limit).
+// The chunk swizzle is the convolution kernels' tise_lds_swz (conflict-free for 16-row fragments).
+// BIG = false: 128 x 128 x 64 tiles, 4 waves of 64 x 64, two workgroups per CU;  BIG = true: 256 x 256 x 64, 8 waves of
+// 128 x 64, one per CU.  TISE_GEMM_SHAPE=32 selects the 32x32x16 kernels above (A/B of tools/clip_gemm_probe.py).
+typedef float float4_t __attribute__((ext_vector_type(4)));
+
+template <bool BIG>
+__global__ __launch_bounds__(BIG ? 512 : 256, BIG ? 1 : 2) void gemm16_f16_kernel(const GemmArgs p) {
+    constexpr int BM = BIG ? 256 : 128, BN = BM;
+    constexpr int NW = BIG ? 8 : 4;
+    constexpr int WM = BIG ? 128 : 64;                          // rows of A per wave; 64 columns (rows of W) per wave
+    constexpr int MI = WM / 16, NI = 4;                         // 16-row fragments per wave along m and n
+    constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = BIG ? (wave >> 2) : (wave >> 1), wn = BIG ? (wave & 3) : (wave & 1);
+    const unsigned tiles_n = (unsigned)(p.N + BN - 1) / BN;
+    const unsigned nwg = gridDim.x;
+    unsigned bid = blockIdx.x;
+    {
+        const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (int)(bid / tiles_n) * BM;
+    const int n0 = (int)(bid % tiles_n) * BN;
+    // DMA pieces (8 rows x 128 B): this wave fetches rows 32 wave .. +31 of both operands.  Source = one scalar base per
+    // operand (advanced by 128 bytes per K-step on the scalar unit) + a constant 32-bit byte offset per lane and piece (the
+    // `saddr` form of the instruction: no per-step vector arithmetic, 8 address registers instead of 24).  Rows beyond M
+    // (N) are CLAMPED to the last valid row instead of redirected to a zero page: a row of the product depends on its own
+    // operand row only, and rows / columns beyond M / N are never stored.
+    const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.a + (long long)m0 * p.lda);
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w + (long long)n0 * p.ldw);
+    unsigned offa[4], offw[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int r = (4 * wave + g) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ tise_lds_swz(r);
+        const int ra = m0 + r < p.M ? r : p.M - 1 - m0, rw = n0 + r < p.N ? r : p.N - 1 - n0;
+        offa[g] = (unsigned)ra * (unsigned)p.lda * 2u + c * 16;
+        offw[g] = (unsigned)rw * (unsigned)p.ldw * 2u + c * 16;
+    }
+#define G16_ISSUE(SOFF)                                                                                   \
+    {                                                                                                     \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
+            const unsigned char* s_ = abase + offa[g];                                                     \
+            __builtin_amdgcn_global_load_lds(s_, (lds_ptr_t)(lds + (SOFF) + (4 * wave + g) * 1024), 16, 0, 0);            \
+        }                                                                                                  \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                    \
+            const unsigned char* s_ = wbase + offw[g];                                                     \
+            __builtin_amdgcn_global_load_lds(s_, (lds_ptr_t)(lds + (SOFF) + A_BYTES + (4 * wave + g) * 1024), 16, 0, 0);  \
+        }                                                                                                  \
+        abase += 128; wbase += 128;                                                                        \
+    }
+    float4_t acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) acc[i][j] = float4_t{0.f, 0.f, 0.f, 0.f};
+    // fragment: row (lane & 15) of a 16-row block, chunk (lane >> 4) of K-slice 0 (slice 1: chunk + 4 = address ^ 64)
+    const int f16o = (lane & 15) * 128 + (((lane >> 4) ^ tise_lds_swz(lane & 15)) << 4);
+    const unsigned char* fa = lds + (wm * WM) * 128;
+    const unsigned char* fb = lds + A_BYTES + (wn * 64) * 128;
+    half8_t a_[MI], b_[2][NI];
+// K-slice 0 of the stage: all fragments
+#define G16_READS(SOFF)                                                                                   \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                     \
+            a_[i] = *reinterpret_cast<const half8_t*>(fa + (SOFF) + i * 2048 + f16o);                      \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                     \
+            b_[0][j] = *reinterpret_cast<const half8_t*>(fb + (SOFF) + j * 2048 + f16o);                   \
+    }
+// slice 0's MFMAs row block by row block; a row block's slice-1 fragment is requested into the registers its slice-0
+// fragment has just left (the LDS latency passes under the following blocks' MFMAs; 64 + 32 fragment registers live
+// instead of 96 + 48: the 256 x 256 instance would spill otherwise), then slice 1's MFMAs
+#define G16_COMPUTE(SOFF)                                                                                 \
+    {                                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                     \
+            b_[1][j] = *reinterpret_cast<const half8_t*>(fb + (SOFF) + j * 2048 + (f16o ^ 64));            \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                   \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b_[0][j], a_[i], acc[i][j], 0, 0, 0);   \
+            a_[i] = *reinterpret_cast<const half8_t*>(fa + (SOFF) + i * 2048 + (f16o ^ 64));               \
+            __builtin_amdgcn_sched_barrier(0);                                                             \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                     \
+            _Pragma("unroll") for (int j = 0; j < NI; ++j)                                                 \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b_[1][j], a_[i], acc[i][j], 0, 0, 0);   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+    const int nsteps = p.K / GM_BK;
+    G16_ISSUE(0)
+    int step = 0;
+    for (; step + 1 < nsteps; step += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        G16_READS(0)
+        __builtin_amdgcn_sched_barrier(0);
+        G16_ISSUE(STAGE)
+        G16_COMPUTE(0)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        G16_READS(STAGE)
+        __builtin_amdgcn_sched_barrier(0);
+        if (step + 2 < nsteps) G16_ISSUE(0)
+        G16_COMPUTE(STAGE)
+    }
+    if (step < nsteps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        G16_READS(0)
+        G16_COMPUTE(0)
+    }
+    __syncthreads();
+#undef G16_ISSUE
+#undef G16_READS
+#undef G16_COMPUTE
+    // epilogue: 32 rows x 64 columns at a time through the wave's staging rows (as the kernels above); the accumulator
+    // block (i, j) holds row m = 16 i + (lane & 15) and the four columns n = 16 j + 4 (lane >> 4) + k of this lane
+    constexpr int PITCH = 144;
+    unsigned char* st = lds + wave * (32 * PITCH);
+    const int ncol0 = n0 + wn * 64;
+#pragma unroll
+    for (int i2 = 0; i2 < MI / 2; ++i2) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int cl = 16 * j + 4 * (lane >> 4);
+            const int n = ncol0 + cl;
+            half4_t bq = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            if (p.bias && n < p.N) bq = *reinterpret_cast<const half4_t*>(p.bias + n);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                half4_t h;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float v = acc[2 * i2 + h2][j][k] + (float)bq[k];
+                    if (p.act == 1) v = v / (1.0f + __expf(-1.702f * v));
+                    h[k] = (_Float16)v;
+                }
+                *reinterpret_cast<half4_t*>(st + (16 * h2 + (lane & 15)) * PITCH + cl * 2) = h;
+            }
+        }
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int r = pass * 8 + (lane >> 3), ch = lane & 7;
+            const int m = m0 + wm * WM + i2 * 32 + r, n = ncol0 + ch * 8;
+            half8_t v = *reinterpret_cast<const half8_t*>(st + r * PITCH + ch * 16);
+            if (m < p.M && n < p.N) {
+                if (p.res) {
+                    const half8_t rr = *reinterpret_cast<const half8_t*>(p.res + (long long)m * p.ldr + n);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = (_Float16)((float)v[k] + (float)rr[k]);
+                }
+                *reinterpret_cast<half8_t*>(p.out + (long long)m * p.ldo + n) = v;
+            }
+        }
+    }
+}
+
 // one wave per row: y = (x - mean) / sqrt(var + eps) * gamma + beta, statistics in fp32 (two passes over registers).
 // 16-byte loads and stores: lane l holds columns 8l .. 8l+7 and 512 + 8l .. (C <= 1024, C % 8 == 0) -- the first
 // version moved 2 bytes per lane and instruction and ran at 2 TB/s.
@@ -597,7 +762,28 @@ int tise_gemm_f16(const void* a_dev, int64_t lda, const void* w_dev, int64_t ldw
     // TISE_GEMM_BIG: 0 never, 1 (default) by the rule below, 2 always -- the A/B switch of tools/clip_gemm_probe.py
     static const int big_mode = [] { const char* e = getenv("TISE_GEMM_BIG"); return e ? atoi(e) : 1; }();
     const long long tiles_big = (long long)((m + 255) / 256) * ((n + 255) / 256);
-    if (big_mode == 2 || (big_mode == 1 && tiles_big >= 768)) {
+    // TISE_GEMM_SHAPE: 16 = the v_mfma_f32_16x16x32_f16 kernels for every launch, 32 = round 2's 32x32x16 kernels for every
+    // launch, unset = by measurement (tools/clip_gemm_probe.py, profiles/r04b_clip_gemm_shapes.txt): the 128 x 128 kernel
+    // is 12-14 % faster on the K = 32 shape (660 -> 754, 889 -> 1001, 877 -> 984 TFLOP/s), the 256 x 256 kernel 8-14 %
+    // SLOWER (its 128 x 64 wave tile needs the slice-1 fragments re-loaded row block by row block to stay inside 256
+    // registers, which serialises its issue stream), so it stays on 32x32x16
+    static const int shape = [] { const char* e = getenv("TISE_GEMM_SHAPE"); return e ? atoi(e) : 0; }();
+    const bool big = big_mode == 2 || (big_mode == 1 && tiles_big >= 768);
+    if (shape == 16 || (shape == 0 && !big)) {
+        constexpr int lds_big = 2 * (256 * 128 + 256 * 128), lds_small = 2 * (128 * 128 + 128 * 128);
+        static std::atomic<unsigned long long> attr16{0};
+        if (tise_first_use_on_this_device(attr16)) {
+            TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16_f16_kernel<true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_big));
+            TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm16_f16_kernel<false>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_small));
+        }
+        if (big) hipLaunchKernelGGL(gemm16_f16_kernel<true>, dim3((unsigned)tiles_big), dim3(512), lds_big, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(gemm16_f16_kernel<false>, dim3((unsigned)tiles), dim3(256), lds_small, (hipStream_t)stream, p);
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
+    if (big) {
         constexpr int lds_big = 2 * (256 * 128 + 256 * 128);
         static std::atomic<unsigned long long> attr_set{0};
         if (tise_first_use_on_this_device(attr_set))

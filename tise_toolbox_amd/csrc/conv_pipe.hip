@@ -56,8 +56,29 @@ __device__ __forceinline__ bool wrap_guard(long long tile, long long ntiles) { r
 // lane's pixels advanced incrementally (no division in the loop), four fragment addresses per tap from one.
 // DBG instance only (tools/conv_ablate.py; never launched by the product path): bits 8..10 of args->nseg switch the DMA,
 // the taps and the epilogue off.
-template <int COUT, bool PADDED, bool DBG = false>
+//
+// POOL = true (round 4; Conv2d_2b -> MaxPool2d(3, 2), inception.py:63-65): the max-pool is taken in THIS kernel's epilogue and
+// only the pooled split tensor is written (a quarter of the bytes; the pooled-input kernel that used to read the 147^2 x 64
+// result back disappears).  The sliding walk already visits the conv rows of an image in order, so pooling needs no halo:
+//   * a workgroup owns a contiguous run of POOL ROWS (n, oy) and walks the conv rows 2 oy .. 2 oy + 2 they need, from the
+//     start of a grid row (one conv row per workgroup boundary is computed twice: 256 x 149 pixels of 22 million);
+//   * vertical first, per lane, no communication: V[x][cout] (fp32, LDS, one 256-byte slot per image column) holds the
+//     running maximum of the open window's rows in column x; the lane that converts conv pixel (y, x) does
+//       y even, a window ends here:  HV[x] = max(V[x], f), V[x] = f;     y odd: V[x] = max(V[x], f);     first row: V[x] = f
+//     (a column is touched by one lane per conv row, and consecutive rows are >= one iteration = one barrier apart);
+//   * horizontal after a barrier: thread (ox, 8-cout chunk) takes max(HV[2 ox], HV[2 ox + 1], HV[2 ox + 2]) for the windows
+//     whose LAST column arrived in this iteration, re-splits and stores one 16-byte hi and one 16-byte lo chunk.  HV keeps 130
+//     columns (slot = x mod 130): the 128 of a tile and the two seam columns of the tile before.
+//   f = hi + lo * 2^-11 of the re-split conv result, exactly the value maxpool3s2_split_kernel reads back from the split
+//   tensor, and max is monotone: every pooled (hi, lo) pair is BIT-IDENTICAL to pool-after-conv (tests).
+//   Slots are swizzled (16-byte chunk ^ pool_swz(slot)) so that the per-lane accesses of the epilogue (4 pixels x 64 bytes
+//   per 16 lanes) and the reads of the horizontal pass (2 columns x 8 chunks per 16 lanes) are both conflict-free.
+__device__ __forceinline__ int pool_swz(int slot) { return ((slot & 3) << 2) ^ ((slot >> 1) & 1); }
+constexpr int POOL_HV_SLOTS = 130;
+
+template <int COUT, bool PADDED, bool DBG = false, bool POOL = false>
 __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, const int R16, const long long ntiles) {
+    static_assert(!POOL || (COUT == 64 && !PADDED && !DBG), "pooled output: Conv2d_2b's instance only");
     constexpr int KHC = 3, KWC = 3, ntaps = 9;
     constexpr int TPI = 64 / COUT;                        // tiles per iteration
     constexpr int PF = COUT == 64 ? 2 : 1;                // the ring holds the new rows of PF iterations ahead (LDS: 160 KB)
@@ -71,7 +92,9 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
     const int ring = R16 + STEP * PF;                     // rows (a multiple of 16)
     unsigned char* wbuf = lds;
     unsigned char* epi_area = wbuf + ring * 128;
-    unsigned char* stage = epi_area + 2048 + wave * STG;
+    unsigned char* stage = epi_area + 2048 + wave * STG;      // (POOL: no staging; V and HV live here)
+    unsigned char* vbuf = epi_area + 2048;                    // POOL: V[OW][64] fp32
+    unsigned char* hvbuf = vbuf + p.OW * 256;                 // POOL: HV[130][64] fp32
 
     const long long G = (long long)gridDim.x;
     const long long mgrid = (long long)p.N * p.H * p.W;
@@ -82,10 +105,23 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
     const long long niter_all = (ntiles + TPI - 1) / TPI;
     const long long per = (niter_all + G - 1) / G;
     const long long i_begin = (long long)blockIdx.x * per, i_end = (i_begin + per < niter_all) ? i_begin + per : niter_all;
-    if (i_begin >= niter_all) return;
+    if (!POOL && i_begin >= niter_all) return;
+    // POOL: this workgroup's pool rows [u0, u1) of the N * OHP -> the grid rows of conv rows 2 oy0 (image n0) .. 2 oy1 + 2 (n1)
+    const int ohp = (p.OH - 3) / 2 + 1, owp = (p.OW - 3) / 2 + 1;
+    long long g_start = 0;
+    unsigned glen = 0;                                    // grid pixels this workgroup walks (POOL)
+    if (POOL) {
+        const long long units = (long long)p.N * ohp;
+        const long long u0 = units * blockIdx.x / G, u1 = units * (blockIdx.x + 1) / G;
+        if (u0 >= u1) return;
+        const long long n0 = u0 / ohp, n1 = (u1 - 1) / ohp;
+        const int oy0 = (int)(u0 - n0 * ohp), oy1 = (int)(u1 - 1 - n1 * ohp);
+        g_start = (n0 * p.H + 2 * oy0) * p.W;
+        glen = (unsigned)((n1 * p.H + 2 * oy1 + 3) * p.W - g_start);
+    }
     const long long t_begin = i_begin * TPI;
-    const long long g_base = t_begin * 128 + minoff;      // grid pixel of relative row 0
-    const int nit = (int)(i_end - i_begin);
+    const long long g_base = (POOL ? g_start : t_begin * 128) + minoff;      // grid pixel of relative row 0
+    const int nit = POOL ? (int)((glen + 127u) / 128u) : (int)(i_end - i_begin);
 
     // ---- this wave's weights -> registers -------------------------------------------------------------------
     half8_t bw[ntaps][2][2];                              // [tap][16-cout half][hi / lo]: 16 couts x the tap's 32 channels
@@ -147,12 +183,12 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
     unsigned en, ey, ex, cy[2] = {0, 0}, cx[2] = {0, 0};
     {
         const unsigned hw = H_ * W_;
-        const unsigned g0 = (unsigned)(t_begin * 128) + (TPI == 2 ? grp * 128 : 0) + ms * 32;     // grid pixels < 2^31 (launcher)
+        const unsigned g0 = (unsigned)(POOL ? g_start : t_begin * 128) + (TPI == 2 ? grp * 128 : 0) + ms * 32;     // grid pixels < 2^31 (launcher)
         const unsigned ge = g0 + (lane >> 3);
         en = ge / hw;
         const unsigned rem = ge - en * hw;
         ey = rem / W_; ex = rem - ey * W_;
-        if (PADDED) {
+        if (PADDED || POOL) {
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi) {
                 const unsigned gc = g0 + pi * 16 + (lane & 15);
@@ -160,6 +196,13 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
                 cy[pi] = remc / W_; cx[pi] = remc - cy[pi] * W_;
             }
         }
+    }
+    // POOL: (n, y, x) of the tile's first grid pixel (wave-uniform), advanced with the tiles
+    unsigned tn_ = 0, ty_ = 0, tx_ = 0;
+    if (POOL) {
+        const unsigned hw = H_ * W_;
+        tn_ = (unsigned)g_start / hw;
+        ty_ = ((unsigned)g_start - tn_ * hw) / W_;         // the walk starts at the beginning of a grid row: tx_ = 0
     }
     // tap offsets in ring rows (scalars) and this lane's window row at ring position 0
     int toff[ntaps];
@@ -272,12 +315,118 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
             if (ex >= W_) { ex -= W_; ++ey; }                                                              \
             if (ey >= H_) { ey -= H_; ++en; }                                                              \
         }
-        if (live) RW32_TAPS()
+        if (POOL || live) RW32_TAPS()
         // the rows of the next iteration have landed.  PF = 2: they were issued one iteration ago and only this
         // iteration's DMA is younger;  PF = 1: they are this iteration's DMA (issued before the taps above)
         if (PF == 2 && ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (live) RW32_EPI(tile, en, ey, ex)
+        if constexpr (POOL) {
+            // ---- vertical running maximum, per lane (see the kernel header) --------------------------------------
+            __syncthreads();                               // every wave has finished the horizontal pass of the previous iteration (HV is free)
+            const unsigned grel0 = (unsigned)it * 128u + ms * 32 + (lane & 15);
+            float4_t vold[2][2];
+            unsigned va[2][2];
+            bool valid[2], first[2];
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi) {
+                const unsigned grel = grel0 + pi * 16;
+                valid[pi] = cx[pi] < (unsigned)p.OW && cy[pi] < (unsigned)p.OH && grel < glen;
+                first[pi] = grel < W_ || cy[pi] == 0;      // the workgroup's first conv row / an image's first: no window ends or continues here
+                const int xs_ = valid[pi] ? (int)cx[pi] : 0;
+#pragma unroll
+                for (int ci = 0; ci < 2; ++ci) {
+                    const int chunk = grp * 8 + ci * 4 + l4;
+                    va[ci][pi] = (unsigned)(xs_ * 256 + ((chunk ^ pool_swz(xs_)) << 4));
+                    vold[ci][pi] = *reinterpret_cast<const float4_t*>(vbuf + va[ci][pi]);
+                }
+            }
+            float vmax = 0.f;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const int ch = grp * 32 + ci * 16 + l4 * 4;
+                const float4_t sc = *reinterpret_cast<const float4_t*>(epi_area + conv_epi::EpiArea<COUT>::SCALE + ch * 4);
+                const float4_t bs = *reinterpret_cast<const float4_t*>(epi_area + conv_epi::EpiArea<COUT>::BIAS + ch * 4);
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi) {
+                    float4_t f, m;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float v = (acc_main[0][0].v[ci][pi][k] + acc_corr[0][0].v[ci][pi][k] * (1.0f / 2048.0f)) * sc[k];
+                        const float r = fmaxf(v + bs[k], 0.f);
+                        vmax = fmaxf(vmax, r);
+                        const _Float16 hi = (_Float16)r;
+                        const _Float16 lo = (_Float16)((r - (float)hi) * 2048.0f);
+                        f[k] = (float)hi + (float)lo * (1.0f / 2048.0f);        // what the split tensor would hold
+                        m[k] = fmaxf(vold[ci][pi][k], f[k]);
+                    }
+                    const bool even = !(cy[pi] & 1u);
+                    if (valid[pi]) {
+                        float4_t nv;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) nv[k] = (first[pi] || even) ? f[k] : m[k];
+                        *reinterpret_cast<float4_t*>(vbuf + va[ci][pi]) = nv;
+                        if (even && !first[pi]) {
+                            const int xx = (int)cx[pi];
+                            const int slot = xx >= POOL_HV_SLOTS ? xx - POOL_HV_SLOTS : xx;
+                            const int chunk = grp * 8 + ci * 4 + l4;
+                            *reinterpret_cast<float4_t*>(hvbuf + slot * 256 + ((chunk ^ pool_swz(slot)) << 4)) = m;
+                        }
+                    }
+                }
+            }
+            tise_flag_split_overflow(vmax);
+            __syncthreads();                               // HV of this iteration complete
+            // ---- horizontal pass: the windows whose last column (2 ox + 2) lies in this tile's even-row segment ----
+            {
+                const unsigned len1 = (W_ - tx_) < 128u ? (W_ - tx_) : 128u;            // pixels of the tile in grid row ty_
+                const bool ev1 = !(ty_ & 1u);
+                const unsigned ye = ev1 ? ty_ : ty_ + 1u;                               // the even one of the tile's (at most two) rows
+                const int xs = ev1 ? (int)tx_ : 0;
+                int xe = ev1 ? (int)(tx_ + len1) - 1 : 127 - (int)len1;                 // (odd first row filling the tile: xe = -1)
+                const unsigned row_rel = (unsigned)it * 128u + (ev1 ? 0u : len1) - (unsigned)xs;   // of the row's first pixel, relative to the walk
+                xe = xe < p.OW - 1 ? xe : p.OW - 1;
+                const bool row_ok = ye >= 2u && ye < (unsigned)p.OH && row_rel != 0u && row_rel < glen && xe >= 2;
+                if (row_ok) {
+                    const int ox_lo = xs <= 2 ? 0 : (xs - 1) >> 1, ox_hi = (xe - 2) >> 1;
+                    const int ox = ox_lo + (tid >> 3), c8 = tid & 7;
+                    if (ox <= ox_hi) {
+                        float mx[8];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const int xx = 2 * ox + j;
+                            const int slot = xx >= POOL_HV_SLOTS ? xx - POOL_HV_SLOTS : xx;
+                            const unsigned a = (unsigned)(slot * 256 + (((2 * c8) ^ pool_swz(slot)) << 4));
+                            const float4_t q0 = *reinterpret_cast<const float4_t*>(hvbuf + a);
+                            const float4_t q1 = *reinterpret_cast<const float4_t*>(hvbuf + (a ^ 16u));
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                mx[k] = j == 0 ? q0[k] : fmaxf(mx[k], q0[k]);
+                                mx[4 + k] = j == 0 ? q1[k] : fmaxf(mx[4 + k], q1[k]);
+                            }
+                        }
+                        half8_t ph, pl;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            ph[k] = (_Float16)mx[k];
+                            pl[k] = (_Float16)((mx[k] - (float)ph[k]) * 2048.0f);
+                        }
+                        const conv_epi::ChunkDesc cd = *reinterpret_cast<const conv_epi::ChunkDesc*>(epi_area + conv_epi::EpiArea<COUT>::DESC + c8 * 32);
+                        // the walk crossed into the next image when the even row is row 0 of it: ye >= 2 excludes that case
+                        const unsigned long long pix = ((unsigned long long)tn_ * (unsigned)ohp + ((ye - 2u) >> 1)) * (unsigned)owp + (unsigned)ox;
+                        unsigned char* d = reinterpret_cast<unsigned char*>(cd.base) + pix * (unsigned long long)cd.row_stride;
+                        if (cd.valid) {
+                            __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, ph), conv_epi::global_ptr(d));
+                            __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, pl), conv_epi::global_ptr(d + cd.second));
+                        }
+                    }
+                }
+                tx_ += sx; ty_ += sy; tn_ += sn;
+                if (tx_ >= W_) { tx_ -= W_; ++ty_; }
+                if (ty_ >= H_) { ty_ -= H_; ++tn_; }
+            }
+        } else {
+            if (live) RW32_EPI(tile, en, ey, ex)
+        }
         RW32_ADVANCE()
         // next iteration: ring positions STEP rows further
         wstart += STEP; wstart = wstart >= ring ? wstart - ring : wstart;
@@ -288,7 +437,7 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
         }
         pnew += STEP; pnew = pnew >= ring ? pnew - ring : pnew;
         relnew += STEP;
-        if (PADDED) {
+        if (PADDED || POOL) {
 #pragma unroll
             for (int pi = 0; pi < 2; ++pi) {
                 cx[pi] += sx; cy[pi] += sy;
@@ -296,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
                 if (cy[pi] >= H_) cy[pi] -= H_;
             }
         }
-        __syncthreads();
+        if (!POOL) __syncthreads();                        // (POOL: the barrier in front of the horizontal pass is the iteration's)
     }
 #undef RW32_ADVANCE
 #undef RW32_ROWS
@@ -313,6 +462,38 @@ static int launch_regw32_inst(const ConvArgs* a, int R16, long long ntiles, long
         TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_regw32_kernel<COUT, PADDED>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     hipLaunchKernelGGL((conv_regw32_kernel<COUT, PADDED>), dim3((unsigned)grid), dim3(512), lds, st, *a, R16, ntiles);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+// Conv2d_2b with MaxPool2d(3, 2) in the epilogue (POOL instance): unpadded 3x3 on a zero-bordered input, 64 couts, split
+// destinations of the POOLED grid ((OH - 3) / 2 + 1) x ((OW - 3) / 2 + 1).
+int launch_regw32_pool(const ConvArgs* a, hipStream_t st) {
+    if (a->Cin != 32 || a->SH != 1 || a->SW != 1 || a->KH != 3 || a->KW != 3 || a->Kpad != 9 * 32 || a->Cout != 64 || (a->PH | a->PW) != 0 ||
+        a->OH < 3 || a->OW < 3 || a->W < 128 || a->W > 2 * POOL_HV_SLOTS || (long long)a->N * a->H * a->W >= 0x7fffff00LL || a->out_hp != 0)
+        return TISE_ERR_INVALID_ARG;
+    for (int i = 0; i < (a->nseg & 0xff); ++i)
+        if (a->seg[i].mode != 0) return TISE_ERR_INVALID_ARG;  // pooled raw fp32 segments: not provided
+    if (a->nseg & ~0xff) return TISE_ERR_INVALID_ARG;
+    const int R16 = (128 + 2 * a->W + 2 + 15) & ~15;
+    const size_t lds = (size_t)(R16 + 256) * 128 + 2048 + (size_t)a->OW * 256 + (size_t)POOL_HV_SLOTS * 256;
+    if (lds > 160 * 1024) return TISE_ERR_UNSUPPORTED;
+    static int ncu_cached = 0;
+    if (ncu_cached == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        TISE_HIP_CHECK(hipGetDevice(&dev));
+        TISE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        ncu_cached = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long units = (long long)a->N * ((a->OH - 3) / 2 + 1);
+    long long grid = (units + 3) / 4;                         // >= 4 pool rows per workgroup: one conv row per boundary is computed twice
+    grid = grid < 1 ? 1 : (grid > ncu_cached ? ncu_cached : grid);
+    static std::atomic<unsigned long long> attr_set{0};
+    if (tise_first_use_on_this_device(attr_set))
+        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_regw32_kernel<64, false, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL((conv_regw32_kernel<64, false, false, true>), dim3((unsigned)grid), dim3(512), lds, st, *a, R16, 0x7fffffffffffLL);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
@@ -512,7 +693,8 @@ extern "C" int tise_stem_conv3x3s2_split_u8_mfma(const uint8_t* x_dev, const flo
     return TISE_OK;
 }
 
-// cfg 34: register-resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; Cout = 32 or 64, one launch).
+// cfg 34: register-resident-weights sliding-window kernel (Cin = 32, 3x3, stride 1; Cout = 32 or 64, one launch);
+// cfg 34 | 1024: the same with max_pool2d(3, 2) of the result taken in the epilogue (64 couts, unpadded).
 int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream) {
     if (a->out_hp && (a->out_y0 < 0 || a->out_x0 < 0 || a->out_y0 + a->OH > a->out_hp || a->out_x0 + a->OW > a->out_wp))
         return TISE_ERR_INVALID_ARG;
@@ -522,6 +704,7 @@ int tise_conv_pipe_launch(const tise_conv_args* a, int cfg, void* stream) {
         for (int i = 0; i < (a->nseg & 0xff); ++i) ldmax = a->seg[i].ld > ldmax ? a->seg[i].ld : ldmax;
         if ((long long)a->N * ohp * owp >= 0xffffffffLL || (ohp + a->H) * owp * ldmax * 4 >= 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
     }
+    if (cfg == (34 | 1024)) return launch_regw32_pool(a, (hipStream_t)stream);
     if (cfg != 34) return TISE_ERR_INVALID_ARG;
     return launch_regw32(a, (hipStream_t)stream);
 }

@@ -917,7 +917,7 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
             return TISE_ERR_INVALID_ARG;
     }
     if (args->seg[0].c0 != 0) return TISE_ERR_INVALID_ARG;
-    if (tn & 512) return tise_conv_pipe_launch(args, tn & 255, stream);   // resident-weights sliding-window kernel
+    if (tn & 512) return tise_conv_pipe_launch(args, (tn & 255) | (tn & 1024), stream);   // resident-weights sliding-window kernel (| 1024: pooled output)
     if (args->out_hp | args->out_wp | args->out_y0 | args->out_x0) return TISE_ERR_INVALID_ARG;   // offset destinations: sliding-window kernels only
     if (tn & 256) return launch_poolin(args, tn & 15, (hipStream_t)stream);       // max-pool fused into a 1x1 convolution's operand load
     if (tn & 64) return launch_rowwin_any(args, tn & 15, (hipStream_t)stream);   // row-window kernel, K order (kh, block, kw)

@@ -302,6 +302,9 @@ def coalesce_u8(batches, dev, limit):
             handed_back()
         if bufs[cur] is None or tuple(bufs[cur].shape[1:]) != tuple(b.shape[1:]):
             bufs[cur] = torch.empty((limit,) + tuple(b.shape[1:]), dtype=torch.uint8, device=dev)
+            # the caching allocator hands out blocks in the order of the CONSUMER's stream: this one may be the memory of
+            # activations that kernels already queued there still use -- the side stream must not write before them
+            side.wait_stream(torch.cuda.current_stream(dev))
         if fill == 0 and freed[cur] is not None:
             side.wait_event(freed[cur])
         if b.is_cuda:                                          # produced on the consumer's stream

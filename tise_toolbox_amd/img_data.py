@@ -165,6 +165,7 @@ class U8CacheLoader:
         dev = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(nbuf)]
         views = [memoryview(p.numpy()).cast("B") for p in pinned]
         side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))       # the device buffers may be memory that queued kernels still use
         ready = [torch.cuda.Event() for _ in range(nbuf)]
         consumed = [torch.cuda.Event() for _ in range(nbuf)]
         handed = [threading.Semaphore(1) for _ in range(nbuf)]        # released when the consumer gave slot k back

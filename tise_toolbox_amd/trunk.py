@@ -311,6 +311,10 @@ class SplitTrunk(FusedTrunk):
         # (only with the default packing of the consuming convolutions: a TISE_CONV_VARIANT=glds / rowwin A/B run pools first)
         consumers = ([self.s3b] if self.last_block >= 1 else []) + ([self.sblocks[0][1]["f"]] if self.last_block >= 2 else [])
         self.fuse_pool = os.environ.get("TISE_POOL_FUSE", "1") != "0" and all(c.variant == "fast" for c in consumers)
+        # round 4: stem max-pool 1 in the PRODUCER's epilogue -- Conv2d_2b (register-weights kernel on the zero-bordered input)
+        # writes the pooled tensor only, Conv2d_3b becomes a plain 1x1 launch (conv_pipe.hip, POOL instance; bit-identical).
+        # TISE_POOL_PRODUCER=0: pool 1 inside Conv2d_3b's operand load as in round 3
+        self.pool_in_2b = os.environ.get("TISE_POOL_PRODUCER", "1") != "0" and os.environ.get("TISE_POOL_FUSE", "1") != "0"
 
     # ---- helpers on split tensors (N, H, W, 2C) fp16 --------------------------------------------------
     @staticmethod
@@ -474,29 +478,42 @@ class SplitTrunk(FusedTrunk):
                 self._s2b_wide = SplitConv(self.c2b.w, self.c2b.b, self.c2b.stride, self.c2b.padding, self.device, variant="fast")
             a = self._sconv(self._s2b_wide, self._sconv(self.s2a, a))
         elif self.pad2b:
+            from .conv_split import pool_output_fits
             buf = self._zero_bordered(n, oh + 2, ow + 2, self.s2a.cout, a.device)
             self.s2a(a, [(0, self.s2a.cout, buf, 0, 0)], out_pad=(oh + 2, ow + 2, 1, 1))
+            if self.pool_in_2b and pool_output_fits(ow + 2, ow) and oh >= 3:
+                ph, pw = (oh - 3) // 2 + 1, (ow - 3) // 2 + 1
+                pooled = self._new(n, ph, pw, self.s2b.cout, a.device)
+                self.s2b(buf, [(0, self.s2b.cout, pooled, 0, 0)], pool_output=True)     # Conv2d_2b + max-pool 1
+                return self._after_pool1(pooled, True)
             a = self._sconv(self.s2b, buf)
         else:
             a = self._sconv(self.s2b, self._sconv(self.s2a, a))
+        if self.last_block == 0 or not self.fuse_pool:
+            return self._after_pool1(self._maxpool_split(a), True)
+        return self._after_pool1(a, False)
+
+    def _after_pool1(self, a, pooled):
+        """Everything behind stem max-pool 1.  ``pooled``: ``a`` is the pooled tensor (Conv2d_2b's epilogue or the stand-alone
+        kernel pooled it); otherwise ``a`` is Conv2d_2b's full result and Conv2d_3b takes the pool inside its operand load."""
         fn = {"A": self._sblock_a, "B": self._sblock_b, "C": self._sblock_c, "D": self._sblock_d, "E": self._sblock_e}
         if self.last_block == 0:                                        # --dims 64: block 0 ends with max-pool 1
-            return self._global_mean(self._maxpool_split(a))
-        if self.fuse_pool:
+            return self._global_mean(a)
+        if pooled:
+            t = self._sconv(self.s3b, a)                                # Conv2d_3b_1x1 on the pooled tensor
+        else:
             n, h, w, _ = a.shape
             oh, ow = self.s3b.pooled_out_hw(h, w)
             t = self._new(n, oh, ow, self.s3b.cout, a.device)
             self.s3b(a, [(0, self.s3b.cout, t, 0, 0)], pooled_input=True)          # max-pool 1 + Conv2d_3b_1x1
-            a = self._sconv(self.s4a, t)
-            if self.last_block == 1:                                    # --dims 192: block 1 ends with max-pool 2
-                return self._global_mean(self._maxpool_split(a))
+        a = self._sconv(self.s4a, t)
+        if self.last_block == 1:                                        # --dims 192: block 1 ends with max-pool 2
+            return self._global_mean(self._maxpool_split(a))
+        if self.fuse_pool:
             a = self._sblock_a(a, self.sblocks[0][1], pooled_input=True)           # max-pool 2 + Mixed_5b
             rest = self.sblocks[1:]
         else:
-            a = self._sconv(self.s3b, self._maxpool_split(a))
-            a = self._maxpool_split(self._sconv(self.s4a, a))
-            if self.last_block == 1:
-                return self._global_mean(a)
+            a = self._maxpool_split(a)
             rest = self.sblocks
         for kind, P in rest:                                            # --dims 768 stops after Mixed_6e, 2048 after Mixed_7c
             a = fn[kind](a, P)
