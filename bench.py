@@ -242,6 +242,10 @@ def main():
     ap.add_argument("--no-cross-check", action="store_true")
     ap.add_argument("--no-kernel-probe", action="store_true", help="skip the stand-alone timing of the HBM-bound kernels after the timed region")
     ap.add_argument("--channels-last", type=int, default=-1)
+    ap.add_argument("--no-host-feed", action="store_true",
+                    help="skip the host_feed leg (N = 1, after the timed region: the same job fed from pinned HOST memory in "
+                         "--feed-batch slices, as the CLI's --u8-cache path feeds it; reported next to `value`, never instead of it)")
+    ap.add_argument("--feed-batch", type=int, default=50, help="loader batch of the host_feed leg (README.md:214-219: 50)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(args.gpus))                  # before anything touches the GPU in this process
@@ -466,6 +470,10 @@ def main():
         out["parity"] = None
         out["cpu_baseline"] = None
         out["cross_check"] = None
+        out["host_feed"] = None
+        if world == 1 and not args.no_host_feed:
+            out["host_feed"] = host_feed_leg(eng, data, lo, n_total, args.feed_batch, mu_ref, sigma_ref, solver, dev,
+                                             float(res["fid"]), n_total / elapsed)
         if world == 1 and not args.no_cpu_baseline:
             # ---- CPU oracle on the first images of the timed set: the baseline AND the parity figures --------
             n_cpu = max(50, (min(args.cpu_sample, n_rank) // 50) * 50)
@@ -506,6 +514,46 @@ def main():
     tdist.barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+def host_feed_leg(eng, data, lo, n_total, feed_batch, mu_ref, sigma_ref, solver, dev, fid_resident, rate_resident):
+    """The same job with the images in page-locked HOST memory, inside the timed region: the loader hands over
+    ``feed_batch`` images at a time (the README recipe's --batch-size 50), engine.coalesce_u8 gathers them into device
+    batches on a side stream (the mechanism behind the CLIs' loaders since round 4: --batch-size only defines the
+    drop-last rule), the trunk runs once per device batch.  Whole job = image loop + reduce + finalize + Frechet + IS*,
+    exactly the timed region of `value`.  PNG decode is not part of it (profiles/r04*_cli_host_inclusive.txt)."""
+    from tise_toolbox_amd.engine import T_COCO, coalesce_u8, device_batch_images
+    n = data.shape[0]
+    host = torch.empty(tuple(data.shape), dtype=torch.uint8).pin_memory()
+    for i in range(0, n, 2000):
+        host[i:i + 2000].copy_(data[i:i + 2000])
+    torch.cuda.synchronize()
+    limit = device_batch_images(feed_batch, int(np.prod(data.shape[1:])))
+    n_used = (n // feed_batch) * feed_batch                 # drop-last rule of the loader batch (n divides: 30 000 / 50)
+
+    def run():
+        eng.begin(n_total=n_total, temperature=T_COCO, splits=10, rule="coco")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        base = lo
+        for big in coalesce_u8((host[i:i + feed_batch] for i in range(0, n_used, feed_batch)), dev, limit):
+            eng.step_u8(big, base)
+            base += big.shape[0]
+        t_loop = time.perf_counter()
+        eng.reduce()
+        mu, sigma = eng.statistics()
+        r = solver.distance(mu, sigma, mu_ref, sigma_ref)
+        eng.inception_score()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        return t1 - t0, t_loop - t0, float(r["fid"])
+    run()                                                   # staging buffers, allocator
+    wall, host_loop, fid = run()
+    return {"images_per_s": n_used / wall, "seconds": wall, "host_loop_seconds": host_loop, "feed_batch": feed_batch,
+            "device_batch": limit, "images": n_used, "pinned_host_bytes": int(host.numel()),
+            "ratio_to_resident": (n_used / wall) / rate_resident, "fid": fid, "dfid_vs_resident": abs(fid - fid_resident),
+            "note": "whole job from pinned host memory (H2D copies inside the timed region, gathered into device batches on a side "
+                    "stream); the Frechet solve here is the one-call form (no side-stream prefactor), `value` stays the device-resident rate"}
 
 
 def hbm_kernel_probe(eng, batch_u8, dev, reps=20):
@@ -560,7 +608,10 @@ def hbm_kernel_probe(eng, batch_u8, dev, reps=20):
     logits = torch.randn((n, 1000), device=dev)
     acc = device.InceptionScoreAccumulator(1000, n, 0.9091363549232483, 10, "coco", False, dev)
     ms = timed(lambda: acc.update(logits, 0))
-    add("is_row_kernel+is_col_kernel", 2 * n * 1000 * 4, ms, "both launches of tise_is_update; logits are read twice")
+    add("is_row_kernel+is_col_kernel", 2 * n * 1000 * 4, ms, "both launches of tise_is_update; logits are read twice.  LAUNCH-BOUND, not "
+        "HBM-bound: two DEPENDENT launches (the column sums need every row's log-sum-exp first) move 8 MB in ~30 us -- each is a few "
+        "microseconds of work behind a kernel boundary, so the HBM fraction of this entry is not a target (0.03 ms of a 38 ms device batch)")
+    out["is_row_kernel+is_col_kernel"]["launch_bound"] = True
     feats = torch.rand((n, 2048), device=dev)
     sacc = device.StatsAccumulator(2048, dev)
     ms = timed(lambda: sacc.update_parts(feats, cov=False, col_sum=True))

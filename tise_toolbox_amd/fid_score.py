@@ -270,7 +270,13 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
     dataloader = torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=False, drop_last=True,
                                              num_workers=num_workers, collate_fn=img_data.collate_u8,
                                              pin_memory=True)
-    return calculate_activation_statistics(dataloader, model, batch_size, dims, cuda)
+    t0 = time.perf_counter()
+    out = calculate_activation_statistics(dataloader, model, batch_size, dims, cuda)
+    wall = time.perf_counter() - t0
+    if tdist.is_main() and len(shard):
+        print(f"[tise] png feed: {len(shard)} images in {wall:.2f} s ({len(shard) / wall:.0f} images/s on this rank, {num_workers} "
+              f"decode workers, loader batch {batch_size}, device batch {device_batch_images(batch_size)})", file=sys.stderr)
+    return out
 
 
 def _build_model(dims, weights, num_classes, seed):

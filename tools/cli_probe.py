@@ -42,11 +42,13 @@ if __name__ == "__main__":
         t0 = time.perf_counter()
         r = subprocess.run(base + ["--batch-size", str(bs), "--num-workers", str(nw)], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
-        print(f"batch {bs:3d} workers {nw:2d}: {dt:6.1f} s wall for {N} images incl. start-up -> {N / dt:7.0f} images/s   {r.stdout.strip().splitlines()[-1] if r.stdout else r.stderr[-200:]}", flush=True)
-    for label in ("first run (builds the cache, 32 workers)", "second run (from the cache)", "third run (from the cache)"):
+        feed = [ln for ln in r.stderr.splitlines() if "png feed" in ln]
+        print(f"batch {bs:3d} workers {nw:2d}: {dt:6.1f} s wall for {N} images incl. start-up -> {N / dt:7.0f} images/s   {r.stdout.strip().splitlines()[-1] if r.stdout else r.stderr[-200:]}\n    {feed[-1] if feed else ''}", flush=True)
+    for bs, label in ((500, "first run (builds the cache, 32 workers)"), (500, "second run (from the cache)"), (500, "third run (from the cache)"),
+                      (50, "README batch size, from the cache"), (50, "README batch size, from the cache, again")):
         t0 = time.perf_counter()
-        r = subprocess.run(base + ["--batch-size", "500", "--num-workers", "32", "--u8-cache"], capture_output=True, text=True, env=env)
+        r = subprocess.run(base + ["--batch-size", str(bs), "--num-workers", "32", "--u8-cache"], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
         feed = [ln for ln in r.stderr.splitlines() if "u8 cache feed" in ln]
-        print(f"--u8-cache batch 500, {label}: {dt:6.1f} s wall incl. start-up -> {N / dt:7.0f} images/s   "
+        print(f"--u8-cache batch {bs}, {label}: {dt:6.1f} s wall incl. start-up -> {N / dt:7.0f} images/s   "
               f"{r.stdout.strip().splitlines()[-1] if r.stdout else r.stderr[-200:]}\n    {feed[-1] if feed else ''}", flush=True)

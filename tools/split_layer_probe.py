@@ -28,8 +28,10 @@ def wrapped(self, xs, segs, pooled_input=False, **kw):
     r = orig(self, xs, segs, pooled_input=pooled_input, **kw)
     e1.record()
     n, h, w, _ = xs.shape
-    oh, ow = r
+    oh, ow = r if pooled_input else self.out_hw(h, w)                # the convolution's own output grid (pool_output returns the pooled one)
     kind = "maxpool-in" if pooled_input else (f"pipe{self.pipe_cfg}" if self.pipe_cfg is not None else self.variant)
+    if kw.get("pool_output"):
+        kind += " maxpool-out"
     recs.append((e0, e1, f"{h}x{w}x{self.cin}->{self.cout} k{self.kh}x{self.kw} s{self.stride[0]} tn{self.tn} {kind}",
                  2.0 * n * oh * ow * self.cout * self.k))
     return r
