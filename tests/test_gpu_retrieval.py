@@ -69,6 +69,50 @@ def test_cosine_top1_matches_fp64_oracle(cuda_device, dtype, d, c, use_index, no
         assert 0.2 < float((got1 == 0).mean()) < 0.9
 
 
+def test_rp_full_size_30k_items_100_candidates(cuda_device):
+    """BASELINE configs[3] at its FULL size through the scoring path: 30 000 items x (1 true + 99 mismatched) candidates
+    drawn from 40 000 distinct caption embeddings, d = 512, fp16 (the model clip.load serves on a GPU).  Every item against
+    the oracle (rp_oracle.clip_forward_probs: what CLIP.forward + softmax round), the ten bin scores / mean / std against
+    rp_oracle.rp_score on the oracle's own success flags wherever the top-1 margin is clear, and the size-independent
+    property the 8-GPU run relies on: per-bin {successes, count} of 8 item shards add up to the one-process result."""
+    from tise_toolbox_amd import RP_coco, device
+    rng = np.random.default_rng(30)
+    n, c, d, rows = 30000, 100, 512, 40000
+    txt = rng.standard_normal((rows, d)).astype(np.float32)
+    img = rng.standard_normal((n, d)).astype(np.float32)
+    index = rng.integers(0, rows, size=(n, c)).astype(np.int32)
+    hit = rng.random(n) < 0.55                                           # ~55 % of the items retrieve their true caption
+    img[hit] = txt[index[hit, 0]] + 2.0 * rng.standard_normal((int(hit.sum()), d)).astype(np.float32)
+    ti = torch.from_numpy(img).to(cuda_device).half()
+    tt = torch.from_numpy(txt).to(cuda_device).half()
+    tidx = torch.from_numpy(index).to(cuda_device)
+    top1, _ = device.cosine_top1(ti, tt, tidx, normalize=True, logit_scale=100.0, want_p0=False)
+    got = (top1 == 0).cpu().numpy().astype(np.int64)
+    hi, ht = ti.cpu().numpy(), tt.cpu().numpy()
+    want = np.zeros(n, np.int64)
+    margin = np.zeros(n)
+    for i in range(n):
+        cand = ht[index[i]]
+        want[i] = int(np.argmax(rp_oracle.clip_forward_probs(hi[i], cand, 100.0, True, np.float16)) == 0)
+        lg = np.sort(rp_oracle.clip_logits(hi[i], cand, 100.0, True))
+        margin[i] = lg[-1] - lg[-2]
+    bad = got != want
+    assert not np.any(bad & (margin > 0.07)), (int(bad.sum()), margin[bad][:5])      # one fp16 ulp of a logit near 30
+    assert bad.sum() <= 60, int(bad.sum())
+    assert 0.4 < got.mean() < 0.7
+    perm = RP_coco.shuffled_ids(n, 11)
+    mean, std, scores = RP_coco.r_precision(ti, tt, tidx, perm)
+    m2, s2, sc2 = rp_oracle.rp_score(np.where(margin > 0.07, want, got), perm)
+    assert (mean, std) == (m2, s2) and list(scores) == list(sc2)
+    sums = np.zeros((10, 2))
+    for r in range(8):
+        lo, hi_ = r * n // 8, (r + 1) * n // 8
+        t1, _ = device.cosine_top1(ti[lo:hi_], tt, tidx[lo:hi_], normalize=True, logit_scale=100.0, want_p0=False)
+        sums += RP_coco.bin_sums((t1 == 0).cpu().numpy().astype(np.int64), lo, perm)
+    m8, s8, _ = RP_coco.r_precision_from_bin_sums(sums)
+    assert (m8, s8) == (mean, std)
+
+
 @pytest.mark.parametrize("name", ["rp_stub_57x10.npz", "rp_stub_40x100.npz"])
 def test_rp_through_the_kernel_reproduces_reference_text(cuda_device, golden_dir, name):
     """The fixture's logits (what the stub CLIP returned inside the reference script) are fed as 1-d 'embeddings'

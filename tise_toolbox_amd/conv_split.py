@@ -236,7 +236,7 @@ class SplitConv:
         """Output grid of ``__call__(..., pooled_input=True)``: max_pool2d(3, stride 2) of the input, then this 1x1 conv."""
         return (h - 3) // 2 + 1, (w - 3) // 2 + 1
 
-    def __call__(self, x, segs, pooled_input=False, out_pad=None, pool_output=False):
+    def __call__(self, x, segs, pooled_input=False, out_pad=None, pool_output=False, pool_h=False):
         """x: split tensor (N, H, W, 2*Cin) fp16.  segs: list of (c0, c1, dst_tensor, dst_off, mode):
         mode 0 -> dst is a split tensor (N, OH, OW, 2*C), mode 1 -> dst is a (N, OH, OW, C) fp32 tensor.
         ``pooled_input``: the convolution (1x1, Cin % 32 == 0, default packing) reads max_pool2d(x, 3, stride 2) -- the
@@ -245,16 +245,21 @@ class SplitConv:
         and the (OH, OW) result is written at offset (y0, x0) inside them (the rest is left untouched).
         ``pool_output`` (configuration 34, 64 couts, unpadded: Conv2d_2b on its zero-bordered input): the destinations are split
         tensors of max_pool2d(result, 3, stride 2) -- the pool is taken in the kernel's epilogue, bit-identical to
-        pooling the stored result; returns the pooled (OH', OW')."""
+        pooling the stored result; returns the pooled (OH', OW').
+        ``pool_h`` (row-window kernel, tile width 3: Conv2d_4a): the destinations are split tensors of the HORIZONTAL half of
+        max_pool2d(result, 3, stride 2) -- (N, OH, (OW - 3) // 2 + 1, ...) -- taken in the epilogue; the consumer finishes the
+        pool with ``pooled_input="v"`` (three vertical taps).  Together bit-identical to pooling the stored result."""
         assert x.dtype == torch.float16 and x.dim() == 4 and x.shape[3] == 2 * self.cin and x.is_contiguous()
         n, h, w, _ = x.shape
         oh, ow = self.out_hw(h, w)
         if pooled_input:
             assert (self.kh, self.kw, self.stride, self.padding) == (1, 1, (1, 1), (0, 0)) and self.cin % 32 == 0
-            assert self.variant == "fast" and self.w_fast is not None and h >= 3 and w >= 3
+            assert self.variant == "fast" and self.w_fast is not None and h >= 3 and (w >= 3 or pooled_input == "v")
             # the kernel's cout tiles: one of 128 couts, else tiles of 256 (weights / scale / bias are zero-padded to cout_pad rows)
             assert self.cout_pad >= (128 if self.cout <= 128 else -(-self.cout // 256) * 256)
             oh, ow = self.pooled_out_hw(h, w)
+            if pooled_input == "v":                             # the producer took the horizontal half (pool_h)
+                ow = w
         if self.variant == "rowwin" and not rowwin_fits(ow, self.kw):
             # rows so short that the window of a 128-pixel tile needs more than the kernel's six pieces per wave (OW < 7
             # at KW = 3): the default kernel serves the layer from its own packing, built on first use
@@ -278,6 +283,10 @@ class SplitConv:
         a.M = n * oh * ow
         a.nseg = len(segs) | getattr(self, "debug_flags", 0)
         dshape = (n, oh, ow)
+        if pool_h:
+            assert self.variant == "rowwin" and self.tn == 3 and rowwin_fits(ow, self.kw) and ow >= 3 and out_pad is None
+            assert not pooled_input and not pool_output and all(sg[4] == 0 for sg in segs)
+            dshape = (n, oh, (ow - 3) // 2 + 1)
         if pool_output:
             assert self.pipe_cfg == 34 and self.cout == 64 and self.padding == (0, 0) and out_pad is None and not pooled_input
             assert pool_output_fits(w, ow) and oh >= 3 and all(sg[4] == 0 for sg in segs)
@@ -306,13 +315,13 @@ class SplitConv:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if pooled_input:
-            code = min(max(tn, 2), 4) | 256
+            code = min(max(tn, 2), 4) | 256 | (2048 if pooled_input == "v" else 0)
         elif self.pipe_cfg is not None:
             code = 512 | self.pipe_cfg | (1024 if pool_output else 0)
         else:
-            code = tn | {"glds": 16, "fast": 128, "rowwin": 64}[self.variant]
+            code = tn | {"glds": 16, "fast": 128, "rowwin": 64}[self.variant] | (2048 if pool_h else 0)
         _lib.call("tise_conv_split_f16", ctypes.byref(a), code, stream)
         if timer is not None:
             e1.record()
             timer.append((e0, e1, 2.0 * a.M * self.cout * self.k))
-        return (dshape[1], dshape[2]) if pool_output else (oh, ow)
+        return (dshape[1], dshape[2]) if (pool_output or pool_h) else (oh, ow)

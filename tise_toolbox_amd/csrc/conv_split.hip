@@ -475,9 +475,19 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
 // ceil(KW / 2) steps per kh, like the default kernel's paired tails.
 // K order differs from the default kernel's (tap-major), so results differ from it in the last bits (fp32 summation
 // order); against fp64 both have the same error.
-template <int TN, int NP>
+//
+// POOLH = true (round 4; Conv2d_4a -> MaxPool2d(3, 2), inception.py:69-70): the HORIZONTAL half of the max-pool is taken in
+// this kernel's epilogue -- h(y, ox) = max(f(y, 2 ox), f(y, 2 ox + 1), f(y, 2 ox + 2)) -- and only the (OH, (OW - 3) / 2 + 1)
+// map is written (half the bytes); the consumer's pooled-input kernel then takes the three VERTICAL taps instead of nine.
+// The three columns of a window are neighbouring tile rows, so the tile is converted into a workgroup-wide fp32 image in
+// the operand LDS (f = hi + lo * 2^-11 of the re-split result: what a pool kernel would read back) and a second pass reads
+// three rows per window.  Tiles advance by 126 pixels and overlap by two, so that every window lies inside the tile that
+// holds its FIRST column (1.6 % of the MFMA work is computed twice).  max is monotone and re-splitting a value that is
+// already (hi, lo)-representable returns the same merged value: pooling in two halves gives the bits of pooling at once.
+template <int TN, int NP, bool POOLH = false>
 __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArgs p, const unsigned inv_wp) {
     constexpr int BN = 32 * TN;
+    constexpr int MSTEP = POOLH ? 126 : CS_BM;                 // pixels between the first pixels of consecutive tiles
     constexpr int A_BYTES = NP * 4 * 1024;                    // window buffer: NP pieces (8 rows x 128 B) per wave
     constexpr int B_BYTES = BN * 128;
     constexpr int B0 = 2 * A_BYTES;
@@ -495,13 +505,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
     }
     const unsigned tile_m = bid / tiles_n;
     const int tile_n = (int)(bid - tile_m * tiles_n);
-    const long long m0 = (long long)tile_m * CS_BM;
+    const long long m0 = (long long)tile_m * MSTEP;
     const int n0 = tile_n * BN;
     const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_conv_zero_page);
     const int pix_bytes = p.Cin * 4;
     const int Wp = p.OW + p.KW - 1;                           // window rows per image row = W + 2 PW
-    const unsigned row0 = (unsigned)(tile_m * CS_BM) / (unsigned)p.OW;     // global output line of the tile's first pixel
-    const int x0 = (int)(tile_m * CS_BM - row0 * (unsigned)p.OW);
+    const unsigned row0 = (unsigned)(tile_m * MSTEP) / (unsigned)p.OW;     // global output line of the tile's first pixel
+    const int x0 = (int)(tile_m * MSTEP - row0 * (unsigned)p.OW);
     const unsigned img0 = row0 / (unsigned)p.OH;
     const int oy0 = (int)(row0 - img0 * (unsigned)p.OH);
     const unsigned nrows_out = (unsigned)p.N * (unsigned)p.OH;
@@ -653,29 +663,115 @@ __global__ __launch_bounds__(256, 2) void conv_split_rowwin_kernel(const ConvArg
         if (step < nsteps) RW_STEP(B0 + B_BYTES, B0)
     }
     __syncthreads();
-    constexpr int ETW = TN > 1 ? 2 : 1;
-    constexpr int EPI0 = 4 * conv_epi::Staging<ETW>::BYTES;
-    static_assert(EPI0 + conv_epi::EpiArea<BN>::BYTES <= LDS_BYTES, "epilogue staging must fit the operand LDS");
-    conv_epi::prepare<BN>(p, lds + EPI0, n0, sc_pre, bs_pre);
-    __syncthreads();
-    conv_epi::store_tiles_desc<TN, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, lds + EPI0, m0 + wave * 32);
+    if constexpr (POOLH) {
+        // ---- horizontal max-pool epilogue (kernel header) ---------------------------------------------------------
+        constexpr int PITCH = BN * 4 + 16;                    // fp32 tile image: 128 pixel rows; 16-byte pad => conflict-free 16-lane groups
+        constexpr int EPI0 = CS_BM * PITCH;
+        static_assert(EPI0 + conv_epi::EpiArea<BN>::BYTES <= LDS_BYTES, "pooled epilogue image must fit the operand LDS");
+        conv_epi::prepare<BN>(p, lds + EPI0, n0, sc_pre, bs_pre);
+        __syncthreads();
+        const unsigned char* area = lds + EPI0;
+        float vmax = 0.f;
+        const int l4 = lane >> 4;
+        // the image holds the RAW fp32 results r = relu(acc * scale + bias).  F = merge(split(.)) is monotone, so
+        // max_i F(r_i) = F(max_i r_i): the windows take the maximum of raw values and the (1/2 as many) results are split,
+        // merged and split again -- exactly split(max_i merge(split(r_i))), what pooling the stored split tensor gives
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const int ch = 32 * t + 16 * ci + 4 * l4;
+                const float4_t sc = *reinterpret_cast<const float4_t*>(area + conv_epi::EpiArea<BN>::SCALE + ch * 4);
+                const float4_t bs = *reinterpret_cast<const float4_t*>(area + conv_epi::EpiArea<BN>::BIAS + ch * 4);
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi) {
+                    float4_t r;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float v = (acc_main[0][t].v[ci][pi][k] + acc_corr[0][t].v[ci][pi][k] * (1.0f / 2048.0f)) * sc[k];
+                        r[k] = fmaxf(v + bs[k], 0.f);
+                        vmax = fmaxf(vmax, r[k]);
+                    }
+                    *reinterpret_cast<float4_t*>(lds + (wave * 32 + pi * 16 + (lane & 15)) * PITCH + ch * 4) = r;
+                }
+            }
+        tise_flag_split_overflow(vmax);
+        __syncthreads();
+        // windows whose first column is tile pixel i in [0, 126): item = (pixel PAIR q, 8-cout chunk); of the pixels 2 q and
+        // 2 q + 1 the one with an even column can start a window (rows are OW pixels long, so the parity changes from row to
+        // row; where a pair straddles a row end -- x = OW - 1 even, then x = 0 -- the second pixel is the candidate)
+        const int owp = (p.OW - 3) / 2 + 1;
+        const unsigned inv_w = 65536u / (unsigned)p.OW + 1u;
+        const long long mleft = p.M - m0;                     // pixels of this tile that exist
+        // chunk fastest along the lanes: the BN / 8 lanes of a window write its hi and lo runs as whole 64-byte pieces of the
+        // destination lines (pixel fastest -- one 16-byte piece per line and lane -- cost the layer 20 %: partial-line
+        // streaming stores)
+        constexpr int NCH = BN / 8;
+        for (int item = tid; item < 64 * NCH; item += 256) {
+            const int q = item / NCH, c8 = item - q * NCH;
+            int i = 2 * q;
+            unsigned ji = ((unsigned)(x0 + i) * inv_w) >> 16;     // image-row ordinal of pixel i inside the tile
+            int x = x0 + i - (int)ji * p.OW;
+            if ((x & 1) || x == p.OW - 1) {
+                ++i; ++x;
+                if (x == p.OW) { x = 0; ++ji; }
+            }
+            if (!(i < MSTEP && i + 2 < mleft && !(x & 1) && x + 2 < p.OW)) continue;
+            const conv_epi::ChunkDesc cd = *reinterpret_cast<const conv_epi::ChunkDesc*>(area + conv_epi::EpiArea<BN>::DESC + c8 * 32);
+            if (!cd.valid) continue;
+            float mx[8];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const unsigned char* qq = lds + (i + j) * PITCH + c8 * 32;
+                const float4_t q0 = *reinterpret_cast<const float4_t*>(qq);
+                const float4_t q1 = *reinterpret_cast<const float4_t*>(qq + 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    mx[k] = j == 0 ? q0[k] : fmaxf(mx[k], q0[k]);
+                    mx[4 + k] = j == 0 ? q1[k] : fmaxf(mx[4 + k], q1[k]);
+                }
+            }
+            half8_t ph, pl;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const _Float16 h0 = (_Float16)mx[k];
+                const _Float16 l0 = (_Float16)((mx[k] - (float)h0) * 2048.0f);
+                const float f = (float)h0 + (float)l0 * (1.0f / 2048.0f);          // what the split tensor of the full result holds
+                ph[k] = (_Float16)f;
+                pl[k] = (_Float16)((f - (float)ph[k]) * 2048.0f);
+            }
+            const unsigned long long pix = (unsigned long long)(row0 + ji) * (unsigned)owp + (unsigned)(x >> 1);
+            unsigned char* d = reinterpret_cast<unsigned char*>(cd.base) + pix * (unsigned long long)cd.row_stride;
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, ph), conv_epi::global_ptr(d));
+            __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, pl), conv_epi::global_ptr(d + cd.second));
+        }
+    } else {
+        constexpr int ETW = TN > 1 ? 2 : 1;
+        constexpr int EPI0 = 4 * conv_epi::Staging<ETW>::BYTES;
+        static_assert(EPI0 + conv_epi::EpiArea<BN>::BYTES <= LDS_BYTES, "epilogue staging must fit the operand LDS");
+        conv_epi::prepare<BN>(p, lds + EPI0, n0, sc_pre, bs_pre);
+        __syncthreads();
+        conv_epi::store_tiles_desc<TN, ETW>(p, acc_main, acc_corr, lds + wave * conv_epi::Staging<ETW>::BYTES, lds + EPI0, m0 + wave * 32);
+    }
 }
 
-template <int TN, int NP>
+template <int TN, int NP, bool POOLH = false>
 static int launch_rowwin(const ConvArgs* args, hipStream_t st) {
     constexpr int LDS = 2 * NP * 4096 + 2 * 32 * TN * 128;
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
     static std::atomic<unsigned long long> attr_set{0};
     if (tise_first_use_on_this_device(attr_set)) {
-        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_rowwin_kernel<TN, NP>),
+        TISE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_split_rowwin_kernel<TN, NP, POOLH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
     const int bn = 32 * TN;
-    const long long tiles = ((args->M + CS_BM - 1) / CS_BM) * ((args->Cout + bn - 1) / bn);
+    // POOLH: tiles start every 126 pixels; the last one must hold the first column of the last window (pixel M - 3)
+    const long long tiles_m = POOLH ? (args->M - 3) / 126 + 1 : (args->M + CS_BM - 1) / CS_BM;
+    const long long tiles = tiles_m * ((args->Cout + bn - 1) / bn);
     if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
     const unsigned wp = (unsigned)(args->OW + args->KW - 1);
     const unsigned inv_wp = 65536u / wp + 1u;
-    hipLaunchKernelGGL((conv_split_rowwin_kernel<TN, NP>), dim3((unsigned)tiles), dim3(256), LDS, st, *args, inv_wp);
+    hipLaunchKernelGGL((conv_split_rowwin_kernel<TN, NP, POOLH>), dim3((unsigned)tiles), dim3(256), LDS, st, *args, inv_wp);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }
@@ -688,7 +784,7 @@ static int rowwin_np(const ConvArgs* a) {
     return (rows + 31) / 32;
 }
 
-static int launch_rowwin_any(const ConvArgs* a, int tn, hipStream_t st) {
+static int launch_rowwin_any(const ConvArgs* a, int tn, hipStream_t st, bool poolh = false) {
     const int steps_per_kh = (a->Cin / 32) * a->KW + ((a->Cin & 16) ? (a->KW + 1) / 2 : 0);
     if (a->SH != 1 || a->SW != 1 || a->KW < 2 || a->KW > 8 || a->OW != a->W + 2 * a->PW - a->KW + 1 || a->OW < 1 || a->Cin % 16 != 0 ||
         a->Cin < 32 || a->Kpad != a->KH * steps_per_kh * 32 || a->M >= 0x7fffff00LL || a->H >= 0x3f00 || a->PH >= 0x100)
@@ -700,6 +796,14 @@ static int launch_rowwin_any(const ConvArgs* a, int tn, hipStream_t st) {
             if (((u * iwp) >> 16) != u / wp || ((u * iw) >> 16) != u / w) return TISE_ERR_UNSUPPORTED;
     }
     const int np = rowwin_np(a);
+    if (poolh) {                                               // horizontal max-pool in the epilogue (Conv2d_4a's instance)
+        if (a->OW < 3 || a->M < 3 || (a->nseg & ~0xff)) return TISE_ERR_INVALID_ARG;
+        for (int i = 0; i < (a->nseg & 0xff); ++i)
+            if (a->seg[i].mode != 0) return TISE_ERR_INVALID_ARG;
+        if (tn == 3 && np == 5) return launch_rowwin<3, 5, true>(a, st);
+        if (tn == 3 && np == 6) return launch_rowwin<3, 6, true>(a, st);
+        return TISE_ERR_UNSUPPORTED;
+    }
     if (np == 5) {
         switch (tn) {
             case 2: return launch_rowwin<2, 5>(a, st);
@@ -740,7 +844,9 @@ static int launch_rowwin_any(const ConvArgs* a, int tn, hipStream_t st) {
 // split in two batches by register pressure and re-pooled Mixed_5b's input once per 128-cout tile: 2.4 TB/s of input
 // against the stand-alone pool kernel's 4.8, profiles/r03d_trunk_conv_layers.txt).  TNW = 2: 128 couts (Conv2d_3b's
 // 80), three workgroups per CU;  TNW = 4: 256 couts (Mixed_5b's 208 in ONE tile: pooled once), two per CU.
-template <int TNW>
+// VT = true (round 4): the input is ALREADY pooled horizontally by its producer (row-window kernel, POOLH): three vertical
+// taps at stride 2 instead of nine -- H = the producer's rows, W = OW = the pooled columns.
+template <int TNW, bool VT = false>
 __global__ __launch_bounds__(256, TNW == 2 ? 3 : 2) void conv_poolin_kernel(const ConvArgs p) {
     constexpr int PM = 64;                                    // pooled pixels per tile
     constexpr int BN = 64 * TNW;
@@ -781,7 +887,7 @@ __global__ __launch_bounds__(256, TNW == 2 ? 3 : 2) void conv_poolin_kernel(cons
         const unsigned n = pp / ohw;
         const unsigned rem = pp - n * ohw;
         const unsigned oh = rem / (unsigned)p.OW, ow = rem - oh * (unsigned)p.OW;
-        src0 = reinterpret_cast<const unsigned char*>(p.x) + (((long long)n * p.H + 2 * oh) * p.W + 2 * ow) * pix_bytes + pc * 16;
+        src0 = reinterpret_cast<const unsigned char*>(p.x) + (((long long)n * p.H + 2 * oh) * p.W + (VT ? ow : 2 * ow)) * pix_bytes + pc * 16;
         arow_off = row * 128 + ((pc ^ tise_lds_swz(row)) * 16);
     }
     // weights: 8-cout DMA pieces, 2 * TNW per wave and K-step (as in the default kernel: scalar base + 32-bit lane offset)
@@ -823,20 +929,21 @@ __global__ __launch_bounds__(256, TNW == 2 ? 3 : 2) void conv_poolin_kernel(cons
         half8_t ph, pl;
         {
             const unsigned char* s0 = src0 + step * 128;
-            half8_t vh[9], vl[9];
+            constexpr int NDW = VT ? 1 : 3, NTAP = 3 * NDW;
+            half8_t vh[NTAP], vl[NTAP];
 #pragma unroll
             for (int dh = 0; dh < 3; ++dh)
 #pragma unroll
-                for (int dw = 0; dw < 3; ++dw) {
+                for (int dw = 0; dw < NDW; ++dw) {
                     const unsigned char* q = s0 + dh * row_bytes + dw * pix_bytes;
-                    vh[dh * 3 + dw] = *reinterpret_cast<const half8_t*>(q);
-                    vl[dh * 3 + dw] = *reinterpret_cast<const half8_t*>(q + 64);
+                    vh[dh * NDW + dw] = *reinterpret_cast<const half8_t*>(q);
+                    vl[dh * NDW + dw] = *reinterpret_cast<const half8_t*>(q + 64);
                 }
             float bv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) bv[i] = -INFINITY;
 #pragma unroll
-            for (int t = 0; t < 9; ++t)
+            for (int t = 0; t < NTAP; ++t)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) bv[i] = fmaxf(bv[i], (float)vh[t][i] + (float)vl[t][i] * (1.f / 2048.f));
 #pragma unroll
@@ -883,9 +990,9 @@ __global__ __launch_bounds__(256, TNW == 2 ? 3 : 2) void conv_poolin_kernel(cons
                                                     m0 + wm * 32, wn * TNW * 4);
 }
 
-static int launch_poolin(const ConvArgs* a, int tn, hipStream_t st) {
-    if (a->KH != 1 || a->KW != 1 || a->PH != 0 || a->PW != 0 || a->Cin % 32 != 0 || a->Kpad != a->Cin || a->H < 3 || a->W < 3 ||
-        a->OH != (a->H - 3) / 2 + 1 || a->OW != (a->W - 3) / 2 + 1 || a->M != (long long)a->N * a->OH * a->OW || a->M >= 0x7fffff00LL ||
+static int launch_poolin(const ConvArgs* a, int tn, hipStream_t st, bool vt = false) {
+    if (a->KH != 1 || a->KW != 1 || a->PH != 0 || a->PW != 0 || a->Cin % 32 != 0 || a->Kpad != a->Cin || a->H < 3 || a->W < (vt ? 1 : 3) ||
+        a->OH != (a->H - 3) / 2 + 1 || a->OW != (vt ? a->W : (a->W - 3) / 2 + 1) || a->M != (long long)a->N * a->OH * a->OW || a->M >= 0x7fffff00LL ||
         (long long)a->W * a->Cin * 4 * 3 >= 0x7fffffffLL)
         return TISE_ERR_INVALID_ARG;
     (void)tn;                                                 // the tile width follows from Cout: one 128-cout tile, else 256-cout tiles
@@ -894,7 +1001,10 @@ static int launch_poolin(const ConvArgs* a, int tn, hipStream_t st) {
     const long long tiles = ((a->M + 63) / 64) * ((a->Cout + bn - 1) / bn);
     if (tiles > 0x7fffffffLL) return TISE_ERR_UNSUPPORTED;
     const dim3 grid((unsigned)tiles), block(256);
-    if (tnw == 2) hipLaunchKernelGGL(conv_poolin_kernel<2>, grid, block, 0, st, *a);
+    if (vt) {
+        if (tnw == 2) hipLaunchKernelGGL((conv_poolin_kernel<2, true>), grid, block, 0, st, *a);
+        else hipLaunchKernelGGL((conv_poolin_kernel<4, true>), grid, block, 0, st, *a);
+    } else if (tnw == 2) hipLaunchKernelGGL(conv_poolin_kernel<2>, grid, block, 0, st, *a);
     else hipLaunchKernelGGL(conv_poolin_kernel<4>, grid, block, 0, st, *a);
     TISE_LAUNCH_CHECK();
     return TISE_OK;
@@ -919,8 +1029,9 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     if (args->seg[0].c0 != 0) return TISE_ERR_INVALID_ARG;
     if (tn & 512) return tise_conv_pipe_launch(args, (tn & 255) | (tn & 1024), stream);   // resident-weights sliding-window kernel (| 1024: pooled output)
     if (args->out_hp | args->out_wp | args->out_y0 | args->out_x0) return TISE_ERR_INVALID_ARG;   // offset destinations: sliding-window kernels only
-    if (tn & 256) return launch_poolin(args, tn & 15, (hipStream_t)stream);       // max-pool fused into a 1x1 convolution's operand load
-    if (tn & 64) return launch_rowwin_any(args, tn & 15, (hipStream_t)stream);   // row-window kernel, K order (kh, block, kw)
+    // | 2048: the pool is split -- the producer (row-window kernel) takes the horizontal half, the consumer the vertical one
+    if (tn & 256) return launch_poolin(args, tn & 15, (hipStream_t)stream, (tn & 2048) != 0);   // max-pool fused into a 1x1 convolution's operand load
+    if (tn & 64) return launch_rowwin_any(args, tn & 15, (hipStream_t)stream, (tn & 2048) != 0);   // row-window kernel, K order (kh, block, kw)
     const bool glds = (tn & 16) != 0;
     // fast path: K order (tap, full 32-channel block) then paired 16-channel tails (see the kernel); Kpad says which
     const int fast_kpad = (args->KH * args->KW * (args->Cin / 32) + ((args->Cin & 16) ? (args->KH * args->KW + 1) / 2 : 0)) * 32;

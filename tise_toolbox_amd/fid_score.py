@@ -261,7 +261,12 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
         wall = time.perf_counter() - t0
         n_img = len(loader) * batch_size
         if tdist.is_main() and n_img:
-            print(f"[tise] u8 cache feed: {n_img} images in {wall:.2f} s ({n_img / wall:.0f} images/s on this rank); host side "
+            steady = ""
+            if loader.first_item_done_at is not None and n_img > loader.first_item_rows:
+                # without the first device batch (first-use costs of the process: code objects, allocator, resize plans)
+                rest = n_img - loader.first_item_rows
+                steady = f"; after the first device batch {rest / (t0 + wall - loader.first_item_done_at):.0f} images/s"
+            print(f"[tise] u8 cache feed: {n_img} images in {wall:.2f} s ({n_img / wall:.0f} images/s on this rank{steady}); host side "
                   f"(page cache -> pinned buffer -> H2D enqueue) {loader.h2d_seconds:.2f} s, the rest is the device pipeline",
                   file=sys.stderr)
         return out
@@ -426,14 +431,16 @@ def calculate_per_class_fid(paths, batch_size, cuda, dims, weights=None, num_cla
 
 def _solve_classes(pairs, dims, dev, eps=1e-6):
     """Frechet distances of [(StatsAccumulator side 1, side 2), ...] on this rank.  A solve at d = 2048 is ~4 000 short
-    dependent launches (csrc/frechet.hip: one per column of the tridiagonalisation), i.e. launch-latency bound, so two
-    host threads drive two solvers on two streams and the device interleaves them (TISE_PERCLASS_STREAMS, default 2)."""
+    dependent launches (csrc/frechet.hip: one per column of the tridiagonalisation), i.e. launch-latency bound, so several
+    host threads drive one solver and one stream each and the device interleaves them (TISE_PERCLASS_STREAMS, default 4;
+    tools/perclass_probe.py, profiles/r04f_perclass_probe.txt: 80 full-rank solves 2.10 s on one stream, 1.38 / 1.22 / 1.14 s
+    on 2 / 3 / 4; 80 rank-300 solves 0.57 -> 0.18 s)."""
     import threading
     n = len(pairs)
     out = [None] * n
     if n == 0:
         return out
-    nthr = max(1, min(int(os.environ.get("TISE_PERCLASS_STREAMS", "2")), n))
+    nthr = max(1, min(int(os.environ.get("TISE_PERCLASS_STREAMS", "4")), n))
     main_stream = torch.cuda.current_stream(dev)
     done = torch.cuda.Event()
     done.record(main_stream)

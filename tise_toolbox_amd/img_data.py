@@ -143,6 +143,7 @@ class U8CacheLoader:
         self.pregrouped = self.group > 1
         self.device = torch.device(device)
         self.h2d_seconds = 0.0
+        self.first_item_done_at, self.first_item_rows = None, 0
 
     def __len__(self):
         return (self.hi - self.lo) // self.bs
@@ -215,6 +216,9 @@ class U8CacheLoader:
                 k, rows = k
                 cur = torch.cuda.current_stream(self.device)
                 cur.wait_event(ready[k])
+                if b == 1:
+                    self.first_item_done_at = time.perf_counter()       # the consumer came back for the second item
+                    self.first_item_rows = item_rows
                 yield dev[k][:rows]
                 consumed[k].record(torch.cuda.current_stream(self.device))
                 handed[k].release()

@@ -315,6 +315,11 @@ class SplitTrunk(FusedTrunk):
         # writes the pooled tensor only, Conv2d_3b becomes a plain 1x1 launch (conv_pipe.hip, POOL instance; bit-identical).
         # TISE_POOL_PRODUCER=0: pool 1 inside Conv2d_3b's operand load as in round 3
         self.pool_in_2b = os.environ.get("TISE_POOL_PRODUCER", "1") != "0" and os.environ.get("TISE_POOL_FUSE", "1") != "0"
+        # stem max-pool 2 split between producer and consumer: Conv2d_4a (row-window kernel) takes the horizontal half in its
+        # epilogue and writes 71 x 35 instead of 71 x 71 pixels, Mixed_5b's fused 1x1 takes three vertical taps instead of
+        # nine in its operand load (conv_split.hip POOLH / VT; bit-identical).  TISE_POOL2_SPLIT=0: all nine taps in the consumer
+        self.pool2_split = (os.environ.get("TISE_POOL2_SPLIT", "1") != "0" and self.fuse_pool and self.last_block >= 2 and
+                            self.s4a.variant == "rowwin" and self.s4a.tn == 3)
 
     # ---- helpers on split tensors (N, H, W, 2C) fp16 --------------------------------------------------
     @staticmethod
@@ -352,7 +357,7 @@ class SplitTrunk(FusedTrunk):
         n, h, w, _ = x.shape
         f = P["f"]
         if pooled_input:                                                # x is the UN-pooled tensor (stem max-pool 2 fused)
-            h, w = f.pooled_out_hw(h, w)
+            h, w = (f.pooled_out_hw(h, w)[0], w) if pooled_input == "v" else f.pooled_out_hw(h, w)
         pf = f.cout - 176
         dev = x.device
         out = self._new(n, h, w, 224 + pf, dev)
@@ -506,6 +511,17 @@ class SplitTrunk(FusedTrunk):
             oh, ow = self.s3b.pooled_out_hw(h, w)
             t = self._new(n, oh, ow, self.s3b.cout, a.device)
             self.s3b(a, [(0, self.s3b.cout, t, 0, 0)], pooled_input=True)          # max-pool 1 + Conv2d_3b_1x1
+        from .conv_split import rowwin_fits
+        n, h, w, _ = t.shape
+        oh, ow = self.s4a.out_hw(h, w)
+        if self.pool2_split and rowwin_fits(ow, self.s4a.kw) and ow >= 3 and oh >= 3:
+            hp = self._new(n, oh, (ow - 3) // 2 + 1, self.s4a.cout, t.device)
+            self.s4a(t, [(0, self.s4a.cout, hp, 0, 0)], pool_h=True)               # Conv2d_4a + horizontal half of max-pool 2
+            a = self._sblock_a(hp, self.sblocks[0][1], pooled_input="v")           # vertical half + Mixed_5b
+            rest = self.sblocks[1:]
+            for kind, P in rest:
+                a = fn[kind](a, P)
+            return self._global_mean(a)
         a = self._sconv(self.s4a, t)
         if self.last_block == 1:                                        # --dims 192: block 1 ends with max-pool 2
             return self._global_mean(self._maxpool_split(a))
