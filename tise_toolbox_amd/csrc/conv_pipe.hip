@@ -69,8 +69,9 @@ __device__ __forceinline__ bool wrap_guard(long long tile, long long ntiles) { r
 //   * horizontal after a barrier: thread (ox, 8-cout chunk) takes max(HV[2 ox], HV[2 ox + 1], HV[2 ox + 2]) for the windows
 //     whose LAST column arrived in this iteration, re-splits and stores one 16-byte hi and one 16-byte lo chunk.  HV keeps 130
 //     columns (slot = x mod 130): the 128 of a tile and the two seam columns of the tile before.
-//   f = hi + lo * 2^-11 of the re-split conv result, exactly the value maxpool3s2_split_kernel reads back from the split
-//   tensor, and max is monotone: every pooled (hi, lo) pair is BIT-IDENTICAL to pool-after-conv (tests).
+//   V / HV hold the RAW fp32 results; F(r) = hi + lo * 2^-11 of the re-split result -- the value maxpool3s2_split_kernel
+//   reads back from the split tensor -- is monotone, so max_i F(r_i) = F(max_i r_i): the pooled maximum is split, merged and
+//   split again, and every pooled (hi, lo) pair is BIT-IDENTICAL to pool-after-conv (tests).
 //   Slots are swizzled (16-byte chunk ^ pool_swz(slot)) so that the per-lane accesses of the epilogue (4 pixels x 64 bytes
 //   per 16 lanes) and the reads of the horizontal pass (2 columns x 8 chunks per 16 lanes) are both conflict-free.
 __device__ __forceinline__ int pool_swz(int slot) { return ((slot & 3) << 2) ^ ((slot >> 1) & 1); }
@@ -352,11 +353,8 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float v = (acc_main[0][0].v[ci][pi][k] + acc_corr[0][0].v[ci][pi][k] * (1.0f / 2048.0f)) * sc[k];
-                        const float r = fmaxf(v + bs[k], 0.f);
-                        vmax = fmaxf(vmax, r);
-                        const _Float16 hi = (_Float16)r;
-                        const _Float16 lo = (_Float16)((r - (float)hi) * 2048.0f);
-                        f[k] = (float)hi + (float)lo * (1.0f / 2048.0f);        // what the split tensor would hold
+                        f[k] = fmaxf(v + bs[k], 0.f);                           // RAW result: see the horizontal pass
+                        vmax = fmaxf(vmax, f[k]);
                         m[k] = fmaxf(vold[ci][pi][k], f[k]);
                     }
                     const bool even = !(cy[pi] & 1u);
@@ -404,11 +402,17 @@ __global__ __launch_bounds__(512, 2) void conv_regw32_kernel(const ConvArgs p, c
                                 mx[4 + k] = j == 0 ? q1[k] : fmaxf(mx[4 + k], q1[k]);
                             }
                         }
+                        // V / HV hold RAW fp32 results r.  F = merge(split(.)) is monotone, so max_i F(r_i) = F(max_i r_i): the
+                        // maximum of the raw values is split, merged and split again -- exactly split(max_i merge(split(r_i))),
+                        // what pooling the stored split tensor gives -- on a quarter as many values as a split + merge per result
                         half8_t ph, pl;
 #pragma unroll
                         for (int k = 0; k < 8; ++k) {
-                            ph[k] = (_Float16)mx[k];
-                            pl[k] = (_Float16)((mx[k] - (float)ph[k]) * 2048.0f);
+                            const _Float16 h0 = (_Float16)mx[k];
+                            const _Float16 l0 = (_Float16)((mx[k] - (float)h0) * 2048.0f);
+                            const float fm = (float)h0 + (float)l0 * (1.0f / 2048.0f);
+                            ph[k] = (_Float16)fm;
+                            pl[k] = (_Float16)((fm - (float)ph[k]) * 2048.0f);
                         }
                         const conv_epi::ChunkDesc cd = *reinterpret_cast<const conv_epi::ChunkDesc*>(epi_area + conv_epi::EpiArea<COUT>::DESC + c8 * 32);
                         // the walk crossed into the next image when the even row is row 0 of it: ye >= 2 excludes that case
