@@ -651,6 +651,58 @@ def test_conv_kernels_random_shapes_vs_fp64(dev, variant):
     assert done == 60 and not bad, bad[:3]
 
 
+def test_conv_block_major_k_order_matches_fp64_and_every_tile_width(dev):
+    """Round 4: the default kernel with K order (32-channel block, tap) for unpadded multi-tap layers (csrc/conv_split.hip
+    CBT; the stride-2 3x3 layers of Mixed_6a / 7a, chosen by SplitConv when the variant is left to "auto"): against an fp64
+    convolution of the values the split tensor holds (the tolerance of every other kernel), within rounding of the
+    tap-major kernel, the same bits for every tile width and run after run.  Shapes: the trunk's four, stride 1, 5x5, 2x3,
+    M tails, one image, three output segments."""
+    import torch.nn.functional as F
+    from tise_toolbox_amd.conv_split import SplitConv, merge, new_split, split
+    g = torch.Generator(device="cpu").manual_seed(77)
+    for (n, H, W, Cin, Cout, kh, kw, st) in [(5, 35, 35, 288, 384, 3, 3, 2), (7, 35, 35, 96, 96, 3, 3, 2), (9, 17, 17, 192, 320, 3, 3, 2),
+                                             (3, 17, 17, 192, 192, 3, 3, 2), (2, 9, 11, 64, 80, 3, 3, 1), (1, 13, 8, 32, 64, 5, 5, 2),
+                                             (4, 6, 7, 96, 144, 2, 3, 1)]:
+        x = (torch.rand((n, H, W, Cin), generator=g) * 2.0).to(dev)
+        w = (torch.randn((Cout, Cin, kh, kw), generator=g) * (2.0 / (Cin * kh * kw)) ** 0.5).to(dev)
+        b = (torch.randn(Cout, generator=g) * 0.2).to(dev)
+        xs = split(x)
+        auto = SplitConv(w, b, (st, st), (0, 0), dev, variant="fast", korder="block")
+        assert auto.korder == "block"
+        oh, ow = auto.out_hw(H, W)
+        outs = {}
+        for tn in (2, 3, 4, 5):
+            c = SplitConv(w, b, (st, st), (0, 0), dev, tn=tn, variant="fast", korder="block")
+            o = new_split(n, oh, ow, Cout, dev)
+            c(xs, [(0, Cout, o, 0, 0)])
+            o2 = torch.zeros_like(o)
+            c(xs, [(0, Cout, o2, 0, 0)])
+            assert torch.equal(o, o2), (tn, H, W)
+            outs[tn] = o
+        assert all(torch.equal(outs[2], outs[t]) for t in (3, 4, 5)), (H, W, Cin, Cout)
+        tap = SplitConv(w, b, (st, st), (0, 0), dev, variant="fast", korder="tap")
+        ot = new_split(n, oh, ow, Cout, dev)
+        tap(xs, [(0, Cout, ot, 0, 0)])
+        ref = torch.relu(F.conv2d(merge(xs).double().permute(0, 3, 1, 2), w.double(), b.double(), st)).permute(0, 2, 3, 1)
+        scale = ref.abs().max().item()
+        err = (merge(outs[4]).double() - ref).abs().max().item()
+        err_tap = (merge(ot).double() - ref).abs().max().item()
+        assert err <= 4e-6 * scale and err_tap <= 4e-6 * scale, (H, W, Cin, Cout, err, err_tap, scale)
+        assert (merge(outs[4]) - merge(ot)).abs().max().item() <= 4e-6 * scale
+    # segments: split slice | split slice | raw fp32
+    w = (torch.randn((160, 64, 3, 3), generator=g) * 0.05).to(dev); b = torch.zeros(160, device=dev)
+    xs = split((torch.rand((2, 9, 9, 64), generator=g)).to(dev))
+    c = SplitConv(w, b, (2, 2), (0, 0), dev, variant="fast", korder="block")
+    a0, a1 = new_split(2, 4, 4, 64, dev), new_split(2, 4, 4, 64, dev)
+    raw = torch.empty((2, 4, 4, 32), dtype=torch.float32, device=dev)
+    c(xs, [(0, 64, a0, 0, 0), (64, 128, a1, 0, 0), (128, 160, raw, 0, 1)])
+    ref = F.conv2d(merge(xs).double().permute(0, 3, 1, 2), w.double(), None, 2).permute(0, 2, 3, 1)
+    got = torch.cat([merge(a0).double(), merge(a1).double(), torch.relu(raw.double())], -1)
+    assert (got - torch.relu(ref)).abs().max().item() <= 4e-6 * ref.abs().max().item()
+    with pytest.raises(ValueError):
+        SplitConv(w, b, (1, 1), (1, 1), dev, variant="fast", korder="block")            # padded: the tap-major order only
+
+
 def test_conv_default_variant_on_very_short_rows(dev):
     """The default variant picks the row-window kernel for stride-1 layers with KW > 1; on rows so short that its window
     would not fit (OW = 4 here) the layer falls back to the default kernel instead of failing."""

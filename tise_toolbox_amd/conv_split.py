@@ -149,7 +149,7 @@ class SplitConv:
     # measurement hook (bench.py): when a list, every launch appends (start_event, end_event, flop)
     timer = None
 
-    def __init__(self, weight, bias, stride, padding, device, tn=None, variant=None, pipe_cfg=None):
+    def __init__(self, weight, bias, stride, padding, device, tn=None, variant=None, pipe_cfg=None, korder=None):
         """weight: (Cout, Cin, KH, KW) fp32 (BatchNorm already folded), bias: (Cout,) fp32."""
         cout, cin, kh, kw = weight.shape
         assert cin % 16 == 0 and cin >= 32, "conv_split needs Cin % 16 == 0 and Cin >= 32"
@@ -165,8 +165,19 @@ class SplitConv:
         # "rowwin" = row-window kernel (the kw taps of a filter row share one fetch of the pixel operand); "auto" (the
         # default) = rowwin where it applies and measured faster (tools/conv_rowwin_probe.py), else fast
         self.variant = variant or os.environ.get("TISE_CONV_VARIANT", "auto")
+        was_auto = self.variant == "auto"
         if self.variant == "auto":
             self.variant = "rowwin" if rowwin_applies(cin, cout, kh, kw, self.stride, self.padding, self.tn) else "fast"
+        # K order of the default kernel: "tap" = (tap, 32-channel block), the generic kernel's order (bit-identical to it);
+        # "block" = (block, tap) for unpadded multi-tap layers with Cin % 32 == 0 -- the stride-2 3x3 layers of Mixed_6a / 7a --
+        # whose tap-shifted re-reads then hit L2 (csrc/conv_split.hip CBT; chosen when the variant is left to "auto",
+        # TISE_CONV_KORDER=tap keeps the tap-major order everywhere)
+        can_block = (self.variant == "fast" and self.padding == (0, 0) and kh * kw > 1 and cin % 32 == 0 and self.tn >= 2)
+        if korder is None:
+            korder = "block" if (was_auto and can_block and os.environ.get("TISE_CONV_KORDER", "block") == "block") else "tap"
+        if korder not in ("tap", "block") or (korder == "block" and not can_block):
+            raise ValueError(f"korder {korder!r} does not apply to this layer")
+        self.korder = korder
         if self.variant not in ("fast", "glds", "pipe", "rowwin"):
             raise ValueError(f"unknown conv variant {self.variant!r} (round 2 removed reg / glds3 / gldsb / win / spec)")
         # rows of zero weights / scale / bias up to the widest tile grid any tile width may use
@@ -194,6 +205,11 @@ class SplitConv:
             tails[:, :ntaps] = w3[:, :, nfull * 32:]
             self.w = split_planes(torch.cat([full, tails.reshape(self.cout_pad, -1)], 1)).to(device).contiguous()
             self.kpad = self.w.shape[2]
+        if self.korder == "block":
+            ntaps, nblk = kh * kw, cin // 32
+            w4 = torch.zeros((self.cout_pad, ntaps, nblk, 32), dtype=torch.float32)
+            w4[:cout] = wk.reshape(cout, ntaps, nblk, 32)
+            self.w = split_planes(w4.permute(0, 2, 1, 3).reshape(self.cout_pad, -1)).to(device).contiguous()
         # the default kernel reads the weights as ONE 128-byte line per (cout, 32-wide K block): [hi 32 | lo 32]
         # (conv_split_fast_kernel: 128-byte LDS-DMA rows); the planar (2, Cout_pad, Kpad) form serves "glds" / "pipe"
         self.w_fast = None
@@ -319,7 +335,7 @@ class SplitConv:
         elif self.pipe_cfg is not None:
             code = 512 | self.pipe_cfg | (1024 if pool_output else 0)
         else:
-            code = tn | {"glds": 16, "fast": 128, "rowwin": 64}[self.variant] | (2048 if pool_h else 0)
+            code = tn | {"glds": 16, "fast": 128, "rowwin": 64}[self.variant] | (2048 if pool_h else 0) | (4096 if self.korder == "block" else 0)
         _lib.call("tise_conv_split_f16", ctypes.byref(a), code, stream)
         if timer is not None:
             e1.record()

@@ -194,7 +194,15 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs 
 // pairs, and the row 8 further has the other K group: 16 distinct 16-byte bank groups for EVERY r0 (the window kernels
 // read at arbitrary tap offsets; round 2's (row >> 1) & 7, chosen for the 32-row fragments of 32x32x16, costs this
 // shape a 2-way conflict whenever r0 is not a multiple of 4: 19 % of all indexed-LDS cycles, profiles/r03l).
-template <int TN, bool DBG = false>
+// CBT = true (round 4): K order (32-channel block, tap) instead of (tap, block) for UNPADDED multi-tap layers with
+// Cin % 32 == 0 (the stride-2 3x3 layers of Mixed_6a / 7a).  In tap-major order a pixel's 128-byte line of one channel
+// block is wanted again by the next tap that covers the pixel nine K-steps later -- 9 x 64 workgroups x 16 KB per XCD is more
+// than its 4 MB of L2, so the line comes over the fabric again (3.3 x the algorithmic reads on 35 x 35 x 288 -> 384 s2,
+// profiles/r04h_conv_hbm_traffic_by_layer.txt); in block-major order the neighbouring taps follow one K-step apart.  No
+// tap of a valid output row can leave the image, so a tap change is ONE wave-uniform byte offset added to the four
+// always-loadable pointers (rows beyond M stay on the zero page).  Same products, another summation order: results
+// differ from the tap-major kernel in the last bits (as the row-window kernel's do).
+template <int TN, bool DBG = false, bool CBT = false>
 __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs p) {
     constexpr int BN = 32 * TN;
     constexpr int A_BYTES = CS_BM * 128, B_BYTES = BN * 128;   // a stage: 128 pixel rows + BN cout rows of 128 B
@@ -313,7 +321,15 @@ __global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs 
             pb[i] += 128;                                    /* next K-step: 128 bytes further */          \
         }                                                                                                  \
         ++istep;                                             /* the step whose pointers are prepared now */ \
-        if (istep >= nA) {                                   /* wave-uniform */                            \
+        if constexpr (CBT) {                                 /* (block, tap) order: scalar offset to the next tap's pixel */ \
+            int delta = pix_bytes - 128;                     /* next tap in the filter row (the issue above advanced 128 already) */ \
+            if (++kw == p.KW) {                                                                            \
+                kw = 0;                                                                                    \
+                delta = (p.W - p.KW + 1) * pix_bytes - 128;  /* first tap of the next filter row */        \
+                if (++kh == p.KH) { kh = 0; delta = -((p.KH - 1) * p.W + (p.KW - 1)) * pix_bytes; }   /* tap (0, 0) of the next block: + 128 */ \
+            }                                                                                              \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) pa[jj] += (long long)(pa_inc[jj] ? delta : 0); \
+        } else if (istep >= nA) {                            /* wave-uniform */                            \
             if (istep < nA + nB) CF_TAP_B(istep - nA)                                                      \
         } else if (++cblk == ncblk) {                        /* next filter tap */                         \
             cblk = 0;                                                                                      \
@@ -1038,6 +1054,7 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
     const bool fast = (tn & 128) != 0 && args->Cin % 16 == 0 && args->Kpad == fast_kpad && args->M < 0x7fffff00LL &&
                       args->H < 0x3f00 && args->W < 0x3f00 && args->PH < 0x100 && args->PW < 0x100;   // packed (ih0, iw0)
     if ((tn & 128) && !fast) return TISE_ERR_UNSUPPORTED;     // the weight packing differs: no silent fall-back
+    const bool cbt = (tn & 4096) != 0;                        // weights packed (channel block, tap): conv_split.py korder="block"
     tn &= 15;
     const int bn = 32 * tn;
     const int bm = CS_BM;
@@ -1049,6 +1066,18 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
         switch (tn) {
             case 3: hipLaunchKernelGGL((conv_split_fast_kernel<3, true>), grid, block, 0, st, *args); break;
             case 4: hipLaunchKernelGGL((conv_split_fast_kernel<4, true>), grid, block, 0, st, *args); break;
+            default: return TISE_ERR_INVALID_ARG;
+        }
+        TISE_LAUNCH_CHECK();
+        return TISE_OK;
+    }
+    if (fast && cbt) {                                         // K order (channel block, tap): unpadded multi-tap layers
+        if (args->PH != 0 || args->PW != 0 || args->Cin % 32 != 0 || args->KH * args->KW < 2) return TISE_ERR_INVALID_ARG;
+        switch (tn) {
+            case 2: hipLaunchKernelGGL((conv_split_fast_kernel<2, false, true>), grid, block, 0, st, *args); break;
+            case 3: hipLaunchKernelGGL((conv_split_fast_kernel<3, false, true>), grid, block, 0, st, *args); break;
+            case 4: hipLaunchKernelGGL((conv_split_fast_kernel<4, false, true>), grid, block, 0, st, *args); break;
+            case 5: hipLaunchKernelGGL((conv_split_fast_kernel<5, false, true>), grid, block, 0, st, *args); break;
             default: return TISE_ERR_INVALID_ARG;
         }
         TISE_LAUNCH_CHECK();
