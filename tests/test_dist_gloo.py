@@ -86,6 +86,85 @@ def test_two_rank_allreduce_matches_single_process():
     assert main["mu_err"] <= 1e-14 and main["sigma_err"] <= 1e-12 and main["is_err"] <= 1e-10
 
 
+def _worker_perclass(rank, world, port, q):
+    """The exchange of fid_score.calculate_per_class_fid on CPU tensors: item shards -> per-class sums -> reduce to the owner
+    (tise_toolbox_amd.dist.class_owners / reduce_sum_) -> the owner's scalar -> all-reduce of [value, solved, skipped]."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from oracle import fid_oracle
+    from tests import _cases
+    from tise_toolbox_amd import dist as tdist
+    tdist.init_from_env(backend="gloo")
+    d = 24
+    names = ["cup", "dog", "person", "traffic light", "zebra"]                 # "zebra": a single crop on side 2 -> skipped
+    counts = {1: [40, 33, 61, 29, 30], 2: [35, 41, 50, 31, 1]}
+    owner = tdist.class_owners(names, world)
+    assert owner == {c: i % world for i, c in enumerate(names)} and tdist.rank() == rank
+    sums = {}
+    for side in (1, 2):
+        labels = np.repeat(np.arange(5), counts[side])
+        labels = np.random.default_rng(side).permutation(labels)               # classes interleaved in the directory
+        feats = _cases.pool3_like_features(len(labels), d, seed=20 + side, shift=0.1 * side).astype(np.float64)
+        lo, hi = tdist.shard_range(len(labels), rank, world)                   # this rank's crops
+        for i, c in enumerate(names):
+            x = feats[lo:hi][labels[lo:hi] == i]
+            buf = torch.zeros(d * d + d + 1, dtype=torch.float64)
+            buf[:d * d] = torch.from_numpy((x.T @ x).reshape(-1)); buf[d * d:d * d + d] = torch.from_numpy(x.sum(0)); buf[-1] = len(x)
+            tdist.reduce_sum_(buf, dst=owner[c])
+            sums[side, c] = buf if owner[c] == rank else None
+        if rank == 0:
+            sums[side, "_all"] = (feats, labels)
+    status = torch.zeros((len(names), 3), dtype=torch.float64)
+    for i, c in enumerate(names):
+        if owner[c] != rank:
+            continue
+        b1, b2 = sums[1, c], sums[2, c]
+        if b1[-1] < 2 or b2[-1] < 2:
+            status[i, 2] = 1.0
+            continue
+        st = [fid_oracle.statistics_from_sums(float(b[-1]), b[d * d:d * d + d].numpy(), b[:d * d].numpy().reshape(d, d)) for b in (b1, b2)]
+        status[i, 0] = fid_oracle.calculate_frechet_distance(*st[0], *st[1])
+        status[i, 1] = 1.0
+    tdist.all_reduce_sum_(status)
+    out = {"status": status.numpy().tolist()}
+    if rank == 0:
+        want = {}
+        for i, c in enumerate(names):
+            xs = [sums[side, "_all"][0][sums[side, "_all"][1] == i] for side in (1, 2)]
+            if min(len(x) for x in xs) >= 2:
+                want[c] = float(fid_oracle.calculate_frechet_distance(*fid_oracle.calculate_activation_statistics(xs[0]),
+                                                                      *fid_oracle.calculate_activation_statistics(xs[1])))
+        out["want"] = want
+    q.put(out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_per_class_solves_are_sharded_over_ranks(world):
+    """class i of the sorted list -> rank i mod W (reduce to the owner, solve there, all-reduce of the
+    scalars); 2 and 3 ranks reproduce the one-process per-class distances, and every rank ends with every class."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_perclass, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [o for o in outs if "want" in o][0]["want"]
+    names = ["cup", "dog", "person", "traffic light", "zebra"]
+    assert set(want) == set(names[:4])
+    for o in outs:
+        st = np.asarray(o["status"])
+        assert st[:, 1].tolist() == [1, 1, 1, 1, 0] and st[:, 2].tolist() == [0, 0, 0, 0, 1]
+        for i, c in enumerate(names[:4]):
+            assert abs(st[i, 0] - want[c]) <= 1e-9 * max(1.0, abs(want[c])), (c, st[i, 0], want[c])
+
+
 def test_shard_files_global_drop_last():
     from tise_toolbox_amd import dist as tdist
     files = list(range(1003))

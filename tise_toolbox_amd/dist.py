@@ -78,6 +78,13 @@ def reduce_sum_(t, dst):
     return t
 
 
+def class_owners(names, world):
+    """Per-class O-FID (fid_score.calculate_per_class_fid): class i of the SORTED class list is owned by rank i mod world --
+    its statistics are reduced to that rank only, which solves it.  The same map on every rank (the list comes from
+    the file names)."""
+    return {c: i % world for i, c in enumerate(sorted(names))}
+
+
 def rank():
     return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
 

@@ -402,7 +402,7 @@ def calculate_per_class_fid(paths, batch_size, cuda, dims, weights=None, num_cla
     present = [set(class_of_crop(f) for f in img_data.get_filenames(p)) for p in paths]
     names = sorted(present[0] | present[1])
     world, me = tdist.world_size(), tdist.rank()
-    owner = {c: i % world for i, c in enumerate(names)}
+    owner = tdist.class_owners(names, world)
     a1 = _class_statistics(paths[0], model, batch_size, dims, num_workers, owner)
     a2 = _class_statistics(paths[1], model, batch_size, dims, num_workers, owner)
     dev = torch.device("cuda", torch.cuda.current_device())
