@@ -114,3 +114,40 @@ def test_towers_are_batch_invariant_and_cli_switch(cuda_device, monkeypatch):
     assert isinstance(mod, clip_model.CLIP)
     cos = torch.nn.functional.cosine_similarity(mod.encode_image(img).float(), fi.float(), dim=-1)
     assert cos.min().item() >= 0.9995
+
+
+def test_text_context_is_truncated_at_the_longest_caption_exactly(cuda_device, monkeypatch):
+    """Round 4: the text transformer is causal and CLIP.encode_text reads the feature at the end-of-text token, so the
+    padding behind it cannot reach the result: RP_coco.embed_texts sorts a chunk's captions by length and encodes every
+    batch at its longest caption instead of 77 tokens.  Row for row the arithmetic is that of the 77-token run (per-token
+    LayerNorm and GEMM rows, the same keys per query, masked keys contribute exact zeros): BIT-IDENTICAL embeddings as
+    long as both runs use the same GEMM kernel (launches of < 768 large tiles: the batches here), in order, for captions
+    of 1 .. 60 words (the tokenizer clips at 75), duplicates and the empty caption."""
+    from tise_toolbox_amd import RP_coco, clip_hip, clip_model
+    towers, _ = RP_coco.build_towers(None, cuda_device)
+    assert isinstance(towers, clip_hip.HipTowers)
+    rng = np.random.default_rng(3)
+    words = [f"w{k}" for k in range(500)]
+    caps = [" ".join(rng.choice(words, int(n))) for n in rng.integers(1, 61, size=301)] + ["", "a", "a"]
+    tok = clip_model.HashTokenizer()
+    seen = []
+    orig = towers.encode_text
+
+    def spy(t):
+        seen.append(tuple(t.shape))
+        return orig(t)
+    monkeypatch.setattr(towers, "encode_text", spy)
+    short = RP_coco.embed_texts(towers, tok, caps, cuda_device, 32)
+    assert max(s[1] for s in seen) <= 62 and min(s[1] for s in seen) <= 24 and sum(s[0] for s in seen) == len(caps)
+    seen.clear()
+    monkeypatch.setenv("TISE_CLIP_TRUNCATE", "0")
+    full = RP_coco.embed_texts(towers, tok, caps, cuda_device, 32)
+    assert all(s[1] == clip_model.CONTEXT_LENGTH for s in seen)
+    assert short.shape == full.shape == (len(caps), 512) and torch.equal(short, full)
+    assert torch.equal(short[-1], short[-2])                          # duplicates: the same embedding wherever they land
+    # a large batch (the 256 x 256 GEMM kernel on one side only): equal to fp16 rounding
+    monkeypatch.delenv("TISE_CLIP_TRUNCATE")
+    many = caps * 8
+    a = RP_coco.embed_texts(towers, tok, many, cuda_device, 2048)
+    cos = torch.nn.functional.cosine_similarity(a.float(), full.repeat(8, 1).float(), dim=-1)
+    assert cos.min().item() >= 0.99999

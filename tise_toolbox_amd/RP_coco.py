@@ -124,15 +124,39 @@ def r_precision(img_emb, txt_emb, txt_index, perm, normalize=True, logit_scale=1
 
 @torch.no_grad()
 def embed_texts(model, tokenizer, captions, dev, batch):
-    """Normalised text embeddings, in order.  Tokenising (host, one core: ~60 k captions/s) and encoding (device: ~90 k/s,
-    asynchronous) overlap batch by batch; tokenising in DataLoader worker processes was tried and lost -- forking eight
-    workers from a process that holds a GPU context took 7 s for a 0.7 s job."""
-    out = []
-    for i in range(0, len(captions), batch):
-        tok = tokenizer(captions[i:i + batch]).to(dev)
-        f = model.encode_text(tok)
-        out.append(f / f.norm(dim=-1, keepdim=True))
-    return torch.cat(out).contiguous()
+    """Normalised text embeddings, in order.  Tokenising (host, one core) and encoding (device, asynchronous) overlap
+    chunk by chunk; tokenising in DataLoader worker processes was tried and lost -- forking eight workers from a process
+    that holds a GPU context took 7 s for a 0.7 s job.
+
+    Round 4, hand-written towers only: the text transformer is CAUSAL (clip model.py build_attention_mask) and the feature
+    is taken at the end-of-text token (CLIP.encode_text: ``x[arange, text.argmax(-1)]``), so nothing behind that token can
+    reach the result -- the padding of a 77-token context is dead work.  Captions are therefore sorted by length inside a
+    chunk of 4 batches and every batch is encoded at ITS longest caption (COCO captions: ~12-20 tokens instead of 77),
+    each row's arithmetic being what it is at 77 tokens (per-token LayerNorm / GEMM rows, the same keys per query)."""
+    out = torch.empty((len(captions), 0), dtype=torch.float16, device=dev)
+    truncate = hasattr(model, "blocks_t") and os.environ.get("TISE_CLIP_TRUNCATE", "1") != "0"     # clip_hip.HipTowers
+    chunk = 4 * batch if truncate else batch
+    for c0 in range(0, len(captions), chunk):
+        # index work in numpy: torch's CPU operators fan small tensors out over every core of the host (a 256-thread
+        # OpenMP team per argsort / gather cost more than the text tower at 11 tokens)
+        tok = tokenizer(captions[c0:c0 + chunk]).numpy()
+        if truncate:
+            length = tok.argmax(-1) + 1                               # position of the end-of-text token (the largest id) + 1
+            order = np.argsort(length, kind="stable")
+        else:
+            order = np.arange(tok.shape[0])
+        for i in range(0, tok.shape[0], batch):
+            sel = order[i:i + batch]
+            t = tok[sel, :max(2, int(length[sel].max()))] if truncate else tok[sel]
+            f = model.encode_text(torch.from_numpy(np.ascontiguousarray(t)).to(dev))
+            f = f / f.norm(dim=-1, keepdim=True)
+            if out.shape[1] == 0:
+                out = torch.empty((len(captions), f.shape[1]), dtype=f.dtype, device=dev)
+            if truncate:
+                out[torch.from_numpy(c0 + sel).to(dev)] = f
+            else:
+                out[c0 + i:c0 + i + f.shape[0]] = f
+    return out.contiguous()
 
 
 class _Images(torch.utils.data.Dataset):
