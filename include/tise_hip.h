@@ -286,6 +286,17 @@ int tise_gather_rows_f16(const void* x_dev, const int64_t* index_dev, int64_t n,
  *        Cout <= 128, else x 256 couts; weights, scale and bias zero-padded to that many rows).  The pool is taken while
  *        the pixel operand is loaded (torchvision's MaxPool2d(3, 2) before Conv2d_3b_1x1 and before Mixed_5b,
  *        image_realism/FID/inception.py:61-71); bit-identical to tise_maxpool3s2_split_nhwc followed by variant 128.
+ *   Round 4 modifiers (OR-ed into `tn`):
+ *   1024 with 512 | 34 (64 couts, unpadded: Conv2d_2b on its zero-bordered input): max_pool2d(3, stride 2) of the RESULT is
+ *        taken in the epilogue (image_realism/FID/inception.py:63-65) and only the pooled split tensor
+ *        N x ((OH - 3) / 2 + 1) x ((OW - 3) / 2 + 1) is written; split segments only; 128 <= W, LDS-bounded (~W <= 152).
+ *   2048 with 64 (tile width 3): the HORIZONTAL half of that pool in the row-window kernel's epilogue -- destinations
+ *        N x OH x ((OW - 3) / 2 + 1) (Conv2d_4a, inception.py:69-70); with 256: the pooled-input kernel takes the three
+ *        VERTICAL taps of such an input (H = the producer's rows, W = OW = its pooled columns).  Both halves together are
+ *        bit-identical to tise_maxpool3s2_split_nhwc of the stored result.
+ *   4096 with 128: K order (32-channel block, tap) instead of (tap, block); unpadded layers with Cin % 32 == 0 and more
+ *        than one tap, weights packed in that order (the stride-2 3x3 layers of Mixed_6a / 7a: their tap-shifted re-reads
+ *        hit L2).  Same products, another summation order than variant 16 / 128.
  *   (Round 1's variants 0 / 32 and the other pipe configurations tied with 128 and were removed.)
  * Bits 8..13 of args->nseg are measurement switches (tools/conv_ablate.py, tools/conv_stamps.py; 0x2000: the epilogue
  * converts and stages but does not store) and must be zero in product calls.
