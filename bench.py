@@ -58,8 +58,11 @@ PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: "Peak BF16/FP16 MFMA ~2.
 # waves per SIMD; profiles/r03k_mfma_shape_probe.txt): reported next to the roofline, never used as its peak
 SUSTAINED_F16_MFMA_TFLOPS = 1585.0
 JOB_IMAGES = 30000         # BASELINE.json metric / configs[1]: 30k images (README.md:214-219 of the reference)
-DEVICE_BATCH = 1000        # images per device batch when it divides a rank's share (tools/batch_sweep.sh: 500 / 750 / 1000 / 1500
-                           # -> 20.04 / 20.07 / 20.27 / 20.22 k images/s on one box: fewer launch gaps and tile tails per image)
+DEVICE_BATCH = 3000        # largest device batch (images per trunk pass); a rank's share is cut into equal batches of at most this.
+                           # Round 2 (tools/batch_sweep.sh): 500 / 750 / 1000 / 1500 -> 20.04 / 20.07 / 20.27 / 20.22 k images/s;
+                           # round 4 (tools/batch_sweep_r04.sh, two alternating runs on one box): 1000 / 1500 / 2000 / 3000 ->
+                           # 25.39 / 25.51 / 25.60 / 25.62 k -- the pooled-epilogue kernels walk whole images per workgroup and
+                           # the tile tails of the 8 x 8 layers shrink; activations of a 3000-image batch: ~40 GB of the 288
 
 
 def synth_images_device(lo, hi, device, seed=0, shift=0.0, hw=256):
@@ -97,12 +100,13 @@ def synth_images_device(lo, hi, device, seed=0, shift=0.0, hw=256):
 
 
 def rank_batch(n_rank, preferred=DEVICE_BATCH, cap=DEVICE_BATCH):
-    """Device batch of a rank: `preferred` when it divides the rank's image count, otherwise the largest divisor
-    <= cap (7 500 / 3 750 images at 4 / 8 GPUs -> 750); a count without a usable divisor runs `preferred` with a short tail."""
+    """Device batch of a rank: the largest divisor of the rank's image count that is <= cap (30 000 / 15 000 / 7 500 / 3 750
+    images at 1 / 2 / 4 / 8 GPUs -> 3000 / 3000 / 2500 / 1875); a count without a usable divisor runs `preferred` with a
+    short tail."""
     if n_rank <= 0:
         return preferred
-    if n_rank % preferred == 0 or n_rank < preferred:
-        return min(preferred, n_rank)
+    if n_rank <= cap:
+        return n_rank
     for b in range(min(cap, n_rank), 127, -1):
         if n_rank % b == 0:
             return b
@@ -508,7 +512,8 @@ def main():
                 "max_feature_err_rel": float(np.abs(fg.cpu().numpy() - fg_c).max() / np.abs(fg_c).max()),
                 "tolerance": {"dfid": 1e-3, "dis": 1e-4}}
         if world == 1 and not args.no_cross_check and isinstance(eng.fused, SplitTrunk):
-            out["cross_check"] = cross_check_fp32(eng, data, chunks, lo, n_total, mu, sigma, mu_ref, sigma_ref,
+            cc_chunks = [(a, min(a + 1000, n_rank)) for a in range(0, n_rank, 1000)]      # MIOpen's fp32 activations: 1000 images at a time
+            out["cross_check"] = cross_check_fp32(eng, data, cc_chunks, lo, n_total, mu, sigma, mu_ref, sigma_ref,
                                                   float(res["fid"]), (is_mean, is_std), solver, dev)
         print(json.dumps(out), flush=True)
     tdist.barrier()

@@ -180,11 +180,11 @@ def test_shard_files_global_drop_last():
 
 def test_bench_strong_scaling_shards_cover_the_job_once():
     """bench.py --scaling strong (SURVEY 8(d) Config 3): ONE 30k set, contiguous 30000/N images per rank, device
-    batches that divide a rank's range (1000/1000/750/750 at 1/2/4/8 GPUs)."""
+    batches that divide a rank's range (3000/3000/2500/1875 at 1/2/4/8 GPUs: the largest divisor <= 3000)."""
     sys.path.insert(0, ROOT)
     import bench
     from tise_toolbox_amd import dist as tdist
-    want_batch = {1: 1000, 2: 1000, 4: 750, 8: 750}
+    want_batch = {1: 3000, 2: 3000, 4: 2500, 8: 1875}
     for world in (1, 2, 3, 4, 8):
         covered = []
         for r in range(world):
@@ -197,7 +197,8 @@ def test_bench_strong_scaling_shards_cover_the_job_once():
             covered += [(lo + a, lo + b) for a, b in chunks]
         assert covered[0][0] == 0 and covered[-1][1] == 30000
         assert all(x[1] == y[0] for x, y in zip(covered[:-1], covered[1:]))
-    assert bench.rank_batch(1250) == 625 and bench.rank_batch(100) == 100 and bench.rank_batch(10000) == 1000
+    assert bench.rank_batch(1250) == 1250 and bench.rank_batch(100) == 100 and bench.rank_batch(10000) == 2500
+    assert bench.rank_batch(6002) == 3000                              # 2 x 3001: no divisor in 128 .. 3000 -> 3000 with a short tail
 
 
 def test_bench_self_launch_starts_fresh_ranks(monkeypatch):

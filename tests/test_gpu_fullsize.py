@@ -127,6 +127,8 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu(cuda_device):
     assert d2["config"]["collective"] == {"world_size": 2, "backend": "gloo", "launcher": "self"}
     assert d1["config"]["step_images"] == 500 and "resident in HBM" in d1["config"]["workload"]
     assert d2["config"]["images_total"] == d1["config"]["images_total"] == 2000 and d2["config"]["images_per_gpu"] == 1000
-    assert abs(d2["scores"]["fid"] - d1["scores"]["fid"]) <= 1e-7 and abs(d2["scores"]["is_mean"] - d1["scores"]["is_mean"]) <= 1e-9
+    # 2 000 images < d = 2 048: rank-deficient covariances, where the fp64 summation order of S -- one 2 000-image device batch
+    # against two ranks' 1 000-image batches (bench.rank_batch: the largest divisor <= 3 000) -- moves the distance by ~2e-7
+    assert abs(d2["scores"]["fid"] - d1["scores"]["fid"]) <= 1e-6 and abs(d2["scores"]["is_mean"] - d1["scores"]["is_mean"]) <= 1e-9
     assert d2["roofline"]["frac"] > 0.05 and d2["allreduce_ms"] >= 0.0 and d2["cpu_baseline"] is None
     assert d2["value"] > 0 and abs(d2["ms_per_step"] * 4 / 1e3 * d2["value"] - 2000) < 1.0       # value = images / elapsed
