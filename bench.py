@@ -323,7 +323,10 @@ def main():
     _SC.timer = None
     u8_stem = getattr(eng, "_u8_stem", False)
     eng.begin(n_total=n_total, temperature=T_COCO, splits=10, rule="coco")
-    prefactor_after = min(1, nch - 1) if os.environ.get("TISE_BENCH_PREFACTOR", "1") != "0" else -1
+    # after the second device batch when there are at least three (the host blocks until the side stream has the factor:
+    # two batches are queued on the main stream by then); with one or two batches per rank (8 GPUs: 2 x 1875 images) after
+    # the first, so that the factorisation still runs under a batch instead of in the tail
+    prefactor_after = (1 if nch >= 3 else 0) if os.environ.get("TISE_BENCH_PREFACTOR", "1") != "0" else -1
     tdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
