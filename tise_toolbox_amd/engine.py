@@ -305,6 +305,7 @@ def coalesce_u8(batches, dev, limit):
             # the caching allocator hands out blocks in the order of the CONSUMER's stream: this one may be the memory of
             # activations that kernels already queued there still use -- the side stream must not write before them
             side.wait_stream(torch.cuda.current_stream(dev))
+            bufs[cur].record_stream(side)                      # ... and the allocator must not recycle it under a copy still in flight there
         if fill == 0 and freed[cur] is not None:
             side.wait_event(freed[cur])
         if b.is_cuda:                                          # produced on the consumer's stream
