@@ -416,8 +416,8 @@ def main():
             # algorithmic flop (hi*hi, hi*lo, lo*hi), so its ceiling is the dense fp16 MFMA peak / 3.
             kern["conv_split_fast_kernel"] = {
                 "instances": "all convolution launches of a device batch, as rocprofv3 lists them (conv_split_fast_kernel<TN>, "
-                             "conv_split_rowwin_kernel<TN, NP>, conv_regw32_kernel<COUT>, conv_poolin_kernel<TNW>; "
-                             "profiles/r03*_kernel_stats.md)",
+                             "conv_split_rowwin_kernel<TN, NP, POOLH>, conv_regw32_kernel<COUT, .., POOL>, conv_poolin_kernel<TNW, VT>; "
+                             "profiles/r04*_kernel_stats.md)",
                 "clock_note": "the chip is power-limited on this loop: the bare inner loop (LDS fragment reads + 3 MFMAs per product, "
                               "nothing else; tools/probes/mfma_shape_probe.hip, profiles/r03k_mfma_shape_probe.txt) sustains "
                               "1.57-1.69 PFLOP/s of fp16 MFMA with v_mfma_f32_16x16x32_f16 at 1.79 GHz (1.39-1.48 at 1.52 GHz with "
@@ -567,7 +567,8 @@ def host_feed_leg(eng, data, lo, n_total, feed_batch, mu_ref, sigma_ref, solver,
 def hbm_kernel_probe(eng, batch_u8, dev, reps=20):
     """The HBM-bound hand-written kernels of a device batch, each launched ALONE `reps` times back to back between two
     HIP events AFTER the timed region (the convolution and covariance kernels are timed inside it): the remaining
-    max-pools (Mixed_6a / 7a pool branches; the two stem pools run inside conv_poolin_kernel), the average-pool tails,
+    max-pools (Mixed_6a / 7a pool branches; stem pool 1 is taken in Conv2d_2b's epilogue, pool 2 in Conv2d_4a's epilogue and
+    conv_poolin_kernel's operand load), the average-pool tails,
     the global mean, the IS* row / column kernels, stats finalize, and the resize.  `achieved` = ALGORITHMIC bytes
     (one read of the input + one write of the output) / average launch time."""
     from tise_toolbox_amd import device
