@@ -291,3 +291,27 @@ def test_u8_cache_fingerprint_and_atomic_build(tmp_path):
     # a truncated side file / missing array is "not current", never an exception
     open(cache + ".sha256", "w").write("deadbeef")
     assert not img_data.u8_cache_is_current(cache, files, str(d))
+
+
+def test_device_batch_rule_and_class_owners(monkeypatch):
+    """Round 4 host rules that need no GPU: --batch-size keeps defining the drop-last rule (dist.n_used_images) while a
+    trunk pass takes whole loader batches up to TISE_DEVICE_BATCH images and 1 GiB of pixels (engine.device_batch_images);
+    per-class O-FID: class i of the sorted list is owned by rank i mod W (dist.class_owners)."""
+    from tise_toolbox_amd import dist as tdist
+    from tise_toolbox_amd.engine import device_batch_images
+    monkeypatch.delenv("TISE_DEVICE_BATCH", raising=False)
+    assert device_batch_images(50) == 1000 and device_batch_images(64) == 960 and device_batch_images(1) == 1000
+    assert device_batch_images(1000) == 1000 and device_batch_images(1001) == 1001 and device_batch_images(4096) == 4096
+    assert device_batch_images(50, 4096 * 4096 * 3) == 50 and device_batch_images(7, 1024 * 1024 * 3) == 336     # 1 GiB cap: 341 images
+    monkeypatch.setenv("TISE_DEVICE_BATCH", "120")
+    assert device_batch_images(50) == 100 and device_batch_images(64) == 64 and device_batch_images(500) == 500
+    # the reference's README recipe: 30 000 images at --batch-size 50 -> nothing dropped, 30 trunk passes instead of 600
+    monkeypatch.delenv("TISE_DEVICE_BATCH")
+    assert tdist.n_used_images(30000, 50) == 30000 and 30000 // device_batch_images(50) == 30
+    assert tdist.n_used_images(30003, 64) == 29952                      # fid_score.py:215-217 drop_last
+    names = ["zebra", "cup", "traffic light", "dog", "person"]
+    own = tdist.class_owners(names, 3)
+    assert own == {"cup": 0, "dog": 1, "person": 2, "traffic light": 0, "zebra": 1}
+    assert tdist.class_owners(names, 1) == {c: 0 for c in names} and tdist.class_owners([], 4) == {}
+    counts = [sum(1 for c in range(80) if c % 8 == r) for r in range(8)]
+    assert counts == [10] * 8                                           # BASELINE configs[4]: 80 classes on 8 GPUs
