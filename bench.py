@@ -10,13 +10,13 @@ The JOB is BASELINE.json's metric and does not depend on the flags: IS* + FID of
 256x256x3 images -- decoded pixels already resident in HBM (PNG decode and the host->device copy are NOT in the timed
 region; DESIGN.md section 6 gives the host-inclusive rates of the CLI) -- against pre-computed reference statistics.
 A STEP is 1/K of the job = the hot path over 30 000 / K images (500 at the default K = 60, 1 500 at --steps 20; the
-device runs them in batches of 1000, see DEVICE_BATCH; `--batch B` makes the job K*B images instead):
+device runs them in batches of up to 3000, engine.DEVICE_BATCH_DEFAULT -- the CLIs' default too; `--batch B` makes the job K*B images instead):
     resize 256->299 (PIL-exact, csrc/resize.hip) -> InceptionV3 trunk (hand-written split-fp16 MFMA convolutions,
     csrc/conv_split.hip / conv_pipe.hip / trunk_ops.hip) + fc -> fp64 covariance/mean accumulation (csrc/stats.hip)
     -> IS* split sums (csrc/is_score.hip).
 With N GPUs the SAME job is sharded (STRONG scaling, SURVEY.md section 8(d) "Config 3"): rank r takes the
 contiguous index range dist.shard_range(30 000, r, N) (3 750 images at N = 8) and runs it in device batches that
-divide its range (1000 / 1000 / 750 / 750 images at N = 1 / 2 / 4 / 8; a step stays 1/K of the job).  After the loop the timed region contains, once: the
+divide its range (3000 / 3000 / 2500 / 1875 images at N = 1 / 2 / 4 / 8; a step stays 1/K of the job).  After the loop the timed region contains, once: the
 all-reduce of the sufficient statistics over RCCL, the finalisation of (mu, sigma), the Frechet distance
 (csrc/frechet.hip, solved redundantly on every rank) and the IS* finalisation.  value = 30 000 / max-over-ranks
 seconds; `allreduce_ms` and `finalize_ms` are reported separately.  `--scaling weak` gives every rank its own
@@ -58,11 +58,8 @@ PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: "Peak BF16/FP16 MFMA ~2.
 # waves per SIMD; profiles/r03k_mfma_shape_probe.txt): reported next to the roofline, never used as its peak
 SUSTAINED_F16_MFMA_TFLOPS = 1585.0
 JOB_IMAGES = 30000         # BASELINE.json metric / configs[1]: 30k images (README.md:214-219 of the reference)
-DEVICE_BATCH = 3000        # largest device batch (images per trunk pass); a rank's share is cut into equal batches of at most this.
-                           # Round 2 (tools/batch_sweep.sh): 500 / 750 / 1000 / 1500 -> 20.04 / 20.07 / 20.27 / 20.22 k images/s;
-                           # round 4 (tools/batch_sweep_r04.sh, two alternating runs on one box): 1000 / 1500 / 2000 / 3000 ->
-                           # 25.39 / 25.51 / 25.60 / 25.62 k -- the pooled-epilogue kernels walk whole images per workgroup and
-                           # the tile tails of the 8 x 8 layers shrink; activations of a 3000-image batch: ~40 GB of the 288
+from tise_toolbox_amd.engine import DEVICE_BATCH_DEFAULT as DEVICE_BATCH   # 3000: ONE device-batch default for the CLIs and this bench
+                                                                            # (a rank's share is cut into equal batches of at most this)
 
 
 def synth_images_device(lo, hi, device, seed=0, shift=0.0, hw=256):
@@ -192,7 +189,7 @@ def cpu_reference_pass(gen_u8, ref_u8, n_job, dims=2048, workers=8):
         for i in range(0, x.shape[0], bs):
             o = inception_oracle.inception_forward(sd, torch.from_numpy(x[i:i + bs]))[3]
             feats.append(o.flatten(1).numpy())
-            logits.append(inception_oracle.logits_from_pool3(sd, o).numpy())
+            logits.append(inception_oracle.logits_from_pool3(sd, o, bias=False).numpy())   # IS* coco head: pool3 x W, no bias (:104-105)
         out[key] = (np.concatenate(feats), np.concatenate(logits))
 
     inception_oracle.inception_forward(sd, torch.from_numpy(x_gen[:bs]))          # warm-up: oneDNN primitive creation
@@ -240,7 +237,12 @@ def main():
                     help="explicit images per step: the job becomes steps x batch images (0: the job is --images, a step = images / steps)")
     ap.add_argument("--device-batch", type=int, default=0, help="images per device batch (0: chosen by rank_batch)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
-    ap.add_argument("--ref-images", type=int, default=3000)
+    ap.add_argument("--ref-images", type=int, default=JOB_IMAGES,
+                    help="images of the reference side (SURVEY 8(d) Config 3: 30k vs 30k); sharded over the ranks and all-reduced "
+                         "like the generated side, before the timed region (the README recipe passes this side as an .npz)")
+    ap.add_argument("--collective", choices=["auto", "off"], default="auto",
+                    help="N = 1: auto brings up a ONE-rank RCCL group (backend nccl) so that the job's all-reduces really execute "
+                         "on the single GPU (config.collective records backend and times); off: no process group at N = 1")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip cpu_baseline AND parity (both need the CPU oracle)")
     ap.add_argument("--cpu-sample", type=int, default=250, help="images of the timed set the CPU oracle processes")
     ap.add_argument("--no-cross-check", action="store_true")
@@ -253,13 +255,31 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(args.gpus))                  # before anything touches the GPU in this process
+    # The contract is ONE JSON line on stdout.  librccl prints a version banner ("RCCL version : ...", five lines) to the C
+    # stdout when its first communicator comes up (seen on the GPU boxes, flushed at exit): file descriptor 1 is pointed at
+    # stderr for the life of the process and the JSON line is written to a duplicate of the original descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     from tise_toolbox_amd import _lib, device, dist as tdist, fid_score
     from tise_toolbox_amd.engine import RealismEngine, T_COCO, frechet_solver
-    rank, world, local_rank = tdist.init_from_env()
+    coll_note = None
+    t_init0 = time.perf_counter()
+    if "WORLD_SIZE" not in os.environ and args.gpus == 1 and args.collective == "auto" and torch.cuda.device_count() > 0:
+        # one GPU: the collective leg of the job still executes -- a one-rank "nccl" (= RCCL) group through the product's
+        # own init path; a box whose RCCL cannot come up falls back to no group and says so in config.collective
+        try:
+            rank, world, local_rank = tdist.init_from_env(force=True)
+        except Exception as e:                                           # noqa: BLE001
+            coll_note = f"one-rank RCCL group failed to initialise: {type(e).__name__}: {e}"[:300]
+            rank, world, local_rank = 0, 1, 0
+    else:
+        rank, world, local_rank = tdist.init_from_env()
+    t_group_init = time.perf_counter() - t_init0
     if world != args.gpus:
         raise SystemExit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    backend = torch.distributed.get_backend() if world > 1 else None
+    backend = torch.distributed.get_backend() if torch.distributed.is_initialized() else None
     if os.environ.get("TISE_FORCE_DEVICE0"):       # testing aid: several ranks on one GPU (gloo backend only)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -284,12 +304,24 @@ def main():
     for i in range(0, n_rank, 1000):
         j = min(i + 1000, n_rank)
         data[i:j] = synth_images_device(lo + i, lo + j, dev, seed=0)
-    # reference statistics (the README recipe passes them as an .npz, fid_score.py:200-203): untimed
+    # reference side (the README recipe passes it as an .npz, fid_score.py:200-203): before the timed region, but computed as
+    # SURVEY 8(d) Config 3 says -- --ref-images (30 000) images sharded over the ranks exactly like the generated side, ONE
+    # all-reduce of {n, s, S} for this side (the generated side's is inside the timed region)
+    r_lo, r_hi = tdist.shard_range(args.ref_images, rank, world)
     eng.begin(n_total=args.ref_images)
-    for i in range(0, args.ref_images, 500):
-        j = min(i + 500, args.ref_images)
+    t_ref0 = time.perf_counter()
+    for i in range(r_lo, r_hi, 1000):
+        j = min(i + 1000, r_hi)
         eng.step_u8(synth_images_device(i, j, dev, seed=1, shift=0.12), i)
+    torch.cuda.synchronize()
+    t_ref1 = time.perf_counter()
+    eng.reduce()                                    # first collective of the process: also creates the RCCL communicator
+    torch.cuda.synchronize()
+    t_ref2 = time.perf_counter()
     mu_ref, sigma_ref = eng.statistics()
+    ref_side = {"images": args.ref_images, "images_this_rank": r_hi - r_lo, "seconds_images": t_ref1 - t_ref0,
+                "allreduce_incl_communicator_creation_ms": (t_ref2 - t_ref1) * 1e3,
+                "note": "sharded over the ranks and all-reduced like the generated side; outside the timed region"}
     solver = frechet_solver(2048, dev)
     solver.set_profiling(True)
 
@@ -355,7 +387,7 @@ def main():
     ev_tail[0].record()
     t_loop_host = time.perf_counter()
     eng.reduce()                                             # RCCL all-reduce of {n, s, S} and the IS* sums
-    if world > 1:
+    if backend is not None:
         torch.cuda.current_stream().synchronize()            # so that allreduce_ms is the collective, not the queue
     ev_tail[1].record()
     t_reduce_host = time.perf_counter()
@@ -461,7 +493,14 @@ def main():
                        "step_images": B, "images_per_gpu": n_rank, "images_total": n_total, "device_batch": rb,
                        "device_batches_per_gpu": nch, "dims": 2048, "trunk": trunk_desc, "parallelism": f"dp{world}",
                        "collective": {"world_size": world, "backend": backend,
+                                      "forced_one_rank_group": bool(world == 1 and backend is not None),
+                                      "init_process_group_s": t_group_init if backend is not None else None,
+                                      "all_reduces": "one per side: [S | s | n] (33.57 MB fp64) + the IS* sums (80 KB) of the generated "
+                                                     "side inside the timed region (allreduce_ms); the reference side's before it "
+                                                     "(reference_side)", "note": coll_note,
+                                      "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                                       "launcher": os.environ.get("TISE_BENCH_LAUNCHER", "external" if world > 1 else "none")}},
+            "reference_side": ref_side,
             "roofline": roofline,
             "stage_ms_per_device_batch": {"resize": resize_ms, "trunk": trunk_ms, "cov_syrk": syrk_ms},
             "allreduce_ms": allreduce_ms,
@@ -518,10 +557,9 @@ def main():
             cc_chunks = [(a, min(a + 1000, n_rank)) for a in range(0, n_rank, 1000)]      # MIOpen's fp32 activations: 1000 images at a time
             out["cross_check"] = cross_check_fp32(eng, data, cc_chunks, lo, n_total, mu, sigma, mu_ref, sigma_ref,
                                                   float(res["fid"]), (is_mean, is_std), solver, dev)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     tdist.barrier()
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    tdist.shutdown()
 
 
 def host_feed_leg(eng, data, lo, n_total, feed_batch, mu_ref, sigma_ref, solver, dev, fid_resident, rate_resident):

@@ -137,6 +137,12 @@ def inception_forward(sd, x, last_block=3, resize_input=True, normalize_input=Tr
 
 
 @torch.no_grad()
-def logits_from_pool3(sd, pool3):
-    """torchvision Inception3 classifier head: fc(flatten(pool3)) (dropout is identity in eval)."""
-    return F.linear(pool3.flatten(1).float(), sd["fc.weight"], sd["fc.bias"])
+def logits_from_pool3(sd, pool3, bias=True):
+    """torchvision Inception3 classifier head: fc(flatten(pool3)) (dropout is identity in eval).
+
+    ``bias=False``: the head of image_realism/IS/coco/inception_score_star_coco.py:104-105, which multiplies pool3 by
+    the weight matrix of the last layer only (``w = ...("softmax/logits/MatMul").inputs[1]; logits = tf.matmul(
+    tf.squeeze(pool3, [1, 2]), w)``; the graph's BiasAdd is not applied) before tf.div(logits, T) (:107).
+    ``bias=True``: object_centric_inception_score.py:41-60 (the whole torch model) and the slim ``logits`` end point
+    of inception_score_star_bird.py:189."""
+    return F.linear(pool3.flatten(1).float(), sd["fc.weight"], sd["fc.bias"] if bias else None)

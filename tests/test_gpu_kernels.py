@@ -1221,5 +1221,5 @@ def test_split_trunk_with_uncalibrated_checkpoint_matches_fp32_trunk(dev, tmp_pa
     err_o = (fa[:8].cpu() - o).abs().max().item()
     print("perturbed checkpoint: HIP trunk vs CPU oracle max err", err_o, "of scale", o.abs().max().item())
     assert err_o <= 2e-4 * o.abs().max().item()
-    lo = inception_oracle.logits_from_pool3(sd_cpu, inception_oracle.inception_forward(sd_cpu, xin)[3])
+    lo = inception_oracle.logits_from_pool3(sd_cpu, inception_oracle.inception_forward(sd_cpu, xin)[3], bias=False)   # coco head, :104-105
     assert (la[:8].cpu() - lo).abs().max().item() <= 1e-3 * max(1.0, lo.abs().max().item())

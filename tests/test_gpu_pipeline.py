@@ -33,16 +33,18 @@ def setup(cuda_device):
 
     def oracle_feats(imgs):
         xs = np.stack([resize_oracle.to_tensor(resize_oracle.resize_bilinear_u8(im, 299, 299)) for im in imgs])
-        feats, logits = [], []
+        feats, logits, logits_b = [], [], []
         for i in range(0, len(xs), 8):
             o = inception_oracle.inception_forward(sd, torch.from_numpy(xs[i:i + 8]))[3]
             feats.append(o.flatten(1).numpy())
-            logits.append(inception_oracle.logits_from_pool3(sd, o).numpy())
-        return np.concatenate(feats), np.concatenate(logits)
+            # the IS* head of inception_score_star_coco.py:104-105: pool3 x W, the graph's bias is NOT added
+            logits.append(inception_oracle.logits_from_pool3(sd, o, bias=False).numpy())
+            logits_b.append(inception_oracle.logits_from_pool3(sd, o, bias=True).numpy())
+        return np.concatenate(feats), np.concatenate(logits), np.concatenate(logits_b)
 
-    fg, lg = oracle_feats(gen)
-    fr, _ = oracle_feats(ref)
-    return dict(eng=eng, gen=gen, ref=ref, fg=fg, lg=lg, fr=fr, dev=cuda_device)
+    fg, lg, lg_bias = oracle_feats(gen)
+    fr, _, _ = oracle_feats(ref)
+    return dict(eng=eng, gen=gen, ref=ref, fg=fg, lg=lg, lg_bias=lg_bias, fr=fr, dev=cuda_device, sd=sd)
 
 
 def test_features_match_cpu_fp32(setup):
@@ -199,6 +201,48 @@ def test_is_cli(setup, tmp_path):
     idx = [int(os.path.basename(f).split(".")[0]) for f in files]
     want = is_oracle.inception_score_from_logits(setup["lg"][idx], is_oracle.T_COCO, 10, "coco", dtype=np.float32)
     assert abs(mean - want[0]) <= 1e-4 and abs(std - want[1]) <= 1e-4
+
+
+def test_is_star_coco_head_has_no_bias(setup, tmp_path):
+    """inception_score_star_coco.py:104-105 forms the IS* logits from the last layer's WEIGHT MATRIX only
+    (``w = ...("softmax/logits/MatMul").inputs[1]; logits = tf.matmul(tf.squeeze(pool3), w)``).  The stand-in classifier
+    bias is non-zero by construction, so the two heads give clearly different scores: the device path must land on the
+    bias-free oracle for --rule coco, on the biased one with --fc-bias on / the bird and ois rules, and the test fails
+    for a product that adds the bias under the coco rule (round 4's behaviour)."""
+    from PIL import Image
+    from tise_toolbox_amd import inception_score as isc, img_data
+    from tise_toolbox_amd.inception import fc_bias_for_rule
+    assert float(setup["sd"]["fc.bias"].abs().max()) > 0.1
+    assert fc_bias_for_rule("coco") is False and fc_bias_for_rule("bird") is True and fc_bias_for_rule("ois") is True
+    assert fc_bias_for_rule("coco", "on") is True and fc_bias_for_rule("ois", "off") is False
+    d = tmp_path / "imgs"
+    d.mkdir()
+    for i in range(30):
+        Image.fromarray(setup["gen"][i]).save(d / f"{i:05d}.png")
+    files = img_data.get_filenames(str(d))
+    idx = [int(os.path.basename(f).split(".")[0]) for f in files]
+    want_nobias = is_oracle.inception_score_from_logits(setup["lg"][idx], is_oracle.T_COCO, 10, "coco", dtype=np.float32)
+    want_bias = is_oracle.inception_score_from_logits(setup["lg_bias"][idx], is_oracle.T_COCO, 10, "coco", dtype=np.float32)
+    assert abs(want_nobias[0] - want_bias[0]) > 1e-3, "the stand-in bias does not separate the two heads: the test would test nothing"
+    base = ["--image_folder", str(d), "--batch-size", "7", "--synthetic-weights"]
+    auto = isc.main(base)
+    on = isc.main(base + ["--fc-bias", "on"])
+    off = isc.main(base + ["--fc-bias", "off"])
+    print("IS* coco head: no bias", auto, "oracle", want_nobias, "| with bias", on, "oracle", want_bias)
+    assert abs(auto[0] - want_nobias[0]) <= 1e-4 and abs(auto[1] - want_nobias[1]) <= 1e-4
+    assert off == auto
+    assert abs(on[0] - want_bias[0]) <= 1e-4 and abs(on[1] - want_bias[1]) <= 1e-4
+    assert abs(auto[0] - want_bias[0]) > 1e-3
+    # the engine follows the rule of begin(): logits of the same images with and without the bias
+    eng, dev = setup["eng"], setup["dev"]
+    x = torch.as_tensor(setup["gen"][:8], device=dev)
+    eng.begin(n_total=8, rule="bird", temperature=is_oracle.T_BIRD)
+    lb = eng.features_from_u8(x)[1].cpu().numpy()
+    eng.begin(n_total=8, rule="coco")
+    ln = eng.features_from_u8(x)[1].cpu().numpy()
+    assert np.abs(lb - setup["lg_bias"][:8]).max() <= 2e-3 * max(1.0, np.abs(setup["lg_bias"]).max())
+    assert np.abs(ln - setup["lg"][:8]).max() <= 2e-3 * max(1.0, np.abs(setup["lg"]).max())
+    np.testing.assert_allclose(lb - ln, np.broadcast_to(setup["sd"]["fc.bias"].numpy(), lb.shape), atol=1e-4)
 
 
 def test_object_centric_inception_score(setup, tmp_path):
@@ -511,7 +555,7 @@ def test_device_batch_is_decoupled_from_batch_size(setup, tmp_path, monkeypatch)
     from PIL import Image
     from tise_toolbox_amd import engine, fid_score
     from tise_toolbox_amd.inception import InceptionV3
-    assert engine.device_batch_images(50) == 1000 and engine.device_batch_images(64) == 960
+    assert engine.device_batch_images(50) == 3000 and engine.device_batch_images(64) == 2944
     assert engine.device_batch_images(3000) == 3000 and engine.device_batch_images(50, 4096 * 4096 * 3) == 50
     dev = setup["dev"]
     model = InceptionV3([3], seed=0).cuda()

@@ -33,6 +33,21 @@ static inline bool tise_first_use_on_this_device(std::atomic<unsigned long long>
     return (mask.fetch_or(bit) & bit) == 0;
 }
 
+// Compute units of the CURRENT device, cached per device in atomics (launch paths are called from several host threads:
+// fid_score._solve_classes; a process may drive GPUs of different sizes).  256 when the query fails.
+static inline int tise_cu_count() {
+    static std::atomic<int> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
+    int n = cus[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        hipDeviceProp_t prop;
+        n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -482,14 +482,7 @@ int launch_regw32_pool(const ConvArgs* a, hipStream_t st) {
     const int R16 = (128 + 2 * a->W + 2 + 15) & ~15;
     const size_t lds = (size_t)(R16 + 256) * 128 + 2048 + (size_t)a->OW * 256 + (size_t)POOL_HV_SLOTS * 256;
     if (lds > 160 * 1024) return TISE_ERR_UNSUPPORTED;
-    static int ncu_cached = 0;
-    if (ncu_cached == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        TISE_HIP_CHECK(hipGetDevice(&dev));
-        TISE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        ncu_cached = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int ncu_cached = tise_cu_count();                   // per device, atomic (common.h)
     const long long units = (long long)a->N * ((a->OH - 3) / 2 + 1);
     long long grid = (units + 3) / 4;                         // >= 4 pool rows per workgroup: one conv row per boundary is computed twice
     grid = grid < 1 ? 1 : (grid > ncu_cached ? ncu_cached : grid);
@@ -514,14 +507,7 @@ int launch_regw32(const ConvArgs* a, hipStream_t st) {
     if (lds > 160 * 1024) return TISE_ERR_UNSUPPORTED;
     const long long mg = (long long)a->N * a->H * a->W;
     const long long ntiles = (mg + 127) / 128;
-    static int ncu_cached = 0;
-    if (ncu_cached == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        TISE_HIP_CHECK(hipGetDevice(&dev));
-        TISE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        ncu_cached = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int ncu_cached = tise_cu_count();                   // per device, atomic (common.h)
     const long long niter = (ntiles + tpi - 1) / tpi;
     const long long grid = niter < ncu_cached ? niter : ncu_cached;
     const bool padded = (a->PH | a->PW) != 0;

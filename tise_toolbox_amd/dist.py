@@ -20,20 +20,52 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def init_from_env(backend=None):
-    """Initialise the default process group from torchrun's environment (no-op for world size 1)."""
+_FORCED = False      # a ONE-rank group was brought up on purpose: the collectives below then really run
+
+
+def _collective():
+    """True when the reductions below have to call torch.distributed: more than one rank, or a one-rank group that was
+    forced (init_from_env(force=True) / TISE_DIST_FORCE=1: the RCCL communicator, all-reduce and reduce of the job
+    execute on a single GPU -- tests/test_gpu_rccl.py, bench.py's `collective` object)."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCED)
+
+
+def init_from_env(backend=None, force=None):
+    """Initialise the default process group from torchrun's environment (no-op for world size 1 unless ``force`` /
+    TISE_DIST_FORCE=1 asks for a one-rank group, whose collectives are then executed like any other group's).
+
+    HSA_ENABLE_IPC_MODE_LEGACY is NOT set here any more (rounds 1-4 set it to 0 blind): the image exports it, a
+    one-rank RCCL group does not need it, and what it governs -- hipIpcGetMemHandle between processes -- is probed by
+    tools/rccl_probe.py (DESIGN.md section 5 records the outcome).  A launcher that starts several ranks (bench._self_launch)
+    passes the variable on from its own environment."""
+    global _FORCED
     rank, world, local_rank = env_world()
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("TISE_DIST_FORCE", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             # TISE_DIST_BACKEND=gloo lets the multi-rank path be exercised on a single-GPU box (tests only)
             backend = os.environ.get("TISE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket                                   # a forced one-rank group has no launcher: any free port
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        _FORCED = world == 1
     return rank, world, local_rank
+
+
+def shutdown():
+    """Destroy the default group (a forced one-rank group included)."""
+    global _FORCED
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+    _FORCED = False
 
 
 def n_used_images(n_images, batch_size):
@@ -61,7 +93,7 @@ def shard_files(files, batch_size, rank, world):
 
 def all_reduce_sum_(t):
     """In-place SUM all-reduce of a tensor (fp64 sufficient statistics); identity for world size 1."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collective():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -70,7 +102,7 @@ def reduce_sum_(t, dst):
     """In-place SUM reduce of ``t`` to rank ``dst`` (other ranks' copies are left undefined); identity for one process.
     RCCL: a real reduce (a ring moves the buffer once instead of twice).  gloo has no reduce for device tensors
     (tests on a single-GPU box, TISE_DIST_BACKEND=gloo): an all-reduce gives the owner the same sum."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collective():
         if dist.get_backend() == "nccl" or not t.is_cuda:
             dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
         else:
@@ -110,7 +142,7 @@ def world_size():
 
 def any_rank(flag):
     """True on every rank when `flag` is true on at least one (also a synchronisation point); `flag` itself for one process."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not _collective():
         return bool(flag)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=dev)
@@ -119,7 +151,7 @@ def any_rank(flag):
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collective():
         dist.barrier()
 
 

@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib, device, dist as tdist
-from .inception import InceptionV3
+from .inception import InceptionV3, fc_bias_for_rule
 
 # MIOpen's find mode also times its reference "naive" direct convolution (~120 ms per call at batch
 # 500, ~40 s per process); it can never win, so keep it out of the search.
@@ -46,7 +46,7 @@ def require_gpu():
 class RealismEngine:
     def __init__(self, dims=2048, device_index=None, weights=None, num_classes=1000, seed=0,
                  channels_last=None, fold_bn=True, with_logits=False, model=None, normalize_input=True,
-                 lut=None, fused=None):
+                 lut=None, fused=None, fc_bias="auto"):
         require_gpu()
         if device_index is None:
             device_index = torch.cuda.current_device()
@@ -57,6 +57,10 @@ class RealismEngine:
         torch.backends.cudnn.benchmark = os.environ.get("TISE_MIOPEN_FIND", "1") != "0"
         self.dims = dims
         self.with_logits = with_logits
+        # classifier bias in the IS* logits: "auto" follows the rule given to begin() -- coco: NO bias, as
+        # inception_score_star_coco.py:104-105 forms its logits from the weight matrix alone; bird / ois: bias
+        self._fc_bias_mode = fc_bias
+        self.fc_bias = fc_bias_for_rule("coco", fc_bias)
         if channels_last is None:
             channels_last = os.environ.get("TISE_CHANNELS_LAST", "1") != "0"
         self.channels_last = channels_last
@@ -109,7 +113,7 @@ class RealismEngine:
     def _trunk_u8(self, u8):
         pred = self.fused.forward_u8(u8, self.lut_dev)
         feats = pred.reshape(pred.shape[0], -1)
-        logits = self.model.logits(feats) if self.with_logits else None
+        logits = self.model.logits(feats, bias=self.fc_bias) if self.with_logits else None
         return feats, logits
 
     @torch.no_grad()
@@ -185,11 +189,14 @@ class RealismEngine:
         feats = pred.reshape(pred.shape[0], -1)
         if feats.stride(1) != 1:
             feats = feats.contiguous()
-        logits = self.model.logits(feats) if self.with_logits else None
+        logits = self.model.logits(feats, bias=self.fc_bias) if self.with_logits else None
         return feats, logits
 
     # ---- accumulation ---------------------------------------------------------------------------
-    def begin(self, n_total=None, temperature=T_COCO, splits=10, rule="coco", drop_first_class=False):
+    def begin(self, n_total=None, temperature=T_COCO, splits=10, rule="coco", drop_first_class=False, fc_bias=None):
+        """New image set.  ``rule`` also decides (unless ``fc_bias`` / the constructor's ``fc_bias`` force it) whether the
+        classifier bias enters the logits of the following steps: inception.fc_bias_for_rule."""
+        self.fc_bias = fc_bias_for_rule(rule, self._fc_bias_mode if fc_bias is None else fc_bias)
         self.stats = device.StatsAccumulator(self.dims, self.device)
         self.is_acc = None
         if self.with_logits:
@@ -249,14 +256,22 @@ class RealismEngine:
 
 
 # ---- device batch: decoupled from the loader's --batch-size ------------------------------------------------
+DEVICE_BATCH_DEFAULT = 3000      # images per trunk pass: ONE number for the CLIs and bench.py (round 5; the CLIs ran 1000 until
+                                 # round 4 while the bench ran 3000).  tools/batch_sweep_r04.sh, two alternating runs on one box:
+                                 # 1000 / 1500 / 2000 / 3000 -> 25.39 / 25.51 / 25.60 / 25.62 k images/s (the pooled-epilogue
+                                 # kernels walk whole images per workgroup, the tile tails of the 8 x 8 layers shrink);
+                                 # activations of a 3000-image pass: ~40 GB of the 288 GB
+STAGING_BYTES_CAP = 1 << 30      # uint8 pixels of one staging buffer / one pending ragged batch
+
+
 def device_batch_images(batch_size, image_bytes=256 * 256 * 3):
     """Images per trunk pass for a loader that delivers ``batch_size`` images at a time: whole loader batches up to
-    TISE_DEVICE_BATCH images (default 1000: the trunk's launches -- 85 per pass -- and tile tails are amortised over
-    1000 images instead of the README recipe's 50, README.md:214-219) and at most 1 GiB of uint8 pixels.  The
+    TISE_DEVICE_BATCH images (default DEVICE_BATCH_DEFAULT = 3000: the trunk's launches -- 85 per pass -- and tile tails are
+    amortised over 3000 images instead of the README recipe's 50, README.md:214-219) and at most 1 GiB of uint8 pixels.  The
     reference's ``--batch-size`` keeps its one semantic role, the drop-last rule (fid_score.py:90-96,215-217);
     features do not depend on how images are batched (tests/test_gpu_kernels.py: batch invariance, bit for bit)."""
-    target = int(os.environ.get("TISE_DEVICE_BATCH", "1000"))
-    cap = max(1, (1 << 30) // max(1, int(image_bytes)))
+    target = int(os.environ.get("TISE_DEVICE_BATCH", str(DEVICE_BATCH_DEFAULT)))
+    cap = max(1, STAGING_BYTES_CAP // max(1, int(image_bytes)))
     target = max(1, min(target, cap))
     return max(1, target // max(1, int(batch_size))) * int(batch_size)
 
@@ -271,6 +286,7 @@ def coalesce_u8(batches, dev, limit):
     side = torch.cuda.Stream(device=dev)
     bufs, freed, keep = [None, None], [None, None], []
     cur, fill = 0, 0
+    limit0, shape0 = limit, None
 
     def flush():
         nonlocal cur, fill
@@ -291,6 +307,16 @@ def coalesce_u8(batches, dev, limit):
 
     for b in batches:
         dense = isinstance(b, torch.Tensor) and b.dtype == torch.uint8 and b.dim() == 4 and b.shape[3] == 3
+        if dense and tuple(b.shape[1:]) != shape0:
+            # the callers size ``limit`` for 256 x 256 images; the staging buffers are sized from what actually arrives: whole
+            # loader batches, at most STAGING_BYTES_CAP of pixels each (1024 x 1024 PNGs: 341 images, not 3000 x 3 MB twice)
+            if fill:
+                yield flush()
+                handed_back()
+            shape0 = tuple(b.shape[1:])
+            per = max(1, int(b[0].numel()))
+            nb = max(1, int(b.shape[0]))
+            limit = min(limit0, max(nb, STAGING_BYTES_CAP // per // nb * nb))
         if not dense or b.shape[0] >= limit:
             if fill:
                 yield flush()
@@ -326,24 +352,26 @@ def coalesce_batches(loader, dev, limit):
     """Device batches for crop directories: equal-sized uint8 batches are gathered by coalesce_u8; ragged batches
     (lists of crops of different sizes, img_data.collate_u8) are concatenated up to ``limit`` crops, so that the trunk
     runs once per ~1000 crops whatever --batch-size is (order preserved)."""
-    pending = []
+    pending, pending_bytes = [], 0
 
     def ragged(it):
-        nonlocal pending
+        nonlocal pending, pending_bytes
         for b in it:
             if isinstance(b, (list, tuple)):
-                if pending and len(pending) + len(b) > limit:
+                nbytes = sum(int(c.numel()) for c in b)
+                if pending and (len(pending) + len(b) > limit or pending_bytes + nbytes > STAGING_BYTES_CAP):
                     yield pending
-                    pending = []
+                    pending, pending_bytes = [], 0
                 pending = pending + list(b)
+                pending_bytes += nbytes
             else:
                 if pending:
                     yield pending
-                    pending = []
+                    pending, pending_bytes = [], 0
                 yield b
         if pending:
             yield pending
-            pending = []
+            pending, pending_bytes = [], 0
     return coalesce_u8(ragged(loader), dev, limit)
 
 

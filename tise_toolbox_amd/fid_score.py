@@ -262,10 +262,13 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
         n_img = len(loader) * batch_size
         if tdist.is_main() and n_img:
             steady = ""
-            if loader.first_item_done_at is not None and n_img > loader.first_item_rows:
-                # without the first device batch (first-use costs of the process: code objects, allocator, resize plans)
+            sec = loader.steady_seconds()
+            if sec and n_img > loader.first_item_rows:
+                # without the first device batch (first-use costs of the process: code objects, allocator, resize plans):
+                # device events at the end of the first and of the last device batch's work (the host time at
+                # which the consumer came back for the second item still contained most of the first batch's device time)
                 rest = n_img - loader.first_item_rows
-                steady = f"; after the first device batch {rest / (t0 + wall - loader.first_item_done_at):.0f} images/s"
+                steady = f"; after the first device batch {rest / sec:.0f} images/s"
             print(f"[tise] u8 cache feed: {n_img} images in {wall:.2f} s ({n_img / wall:.0f} images/s on this rank{steady}); host side "
                   f"(page cache -> pinned buffer -> H2D enqueue) {loader.h2d_seconds:.2f} s, the rest is the device pipeline",
                   file=sys.stderr)
@@ -378,11 +381,19 @@ def _class_statistics(path, model, batch_size, dims, num_workers, owner=None):
     # 80 classes on 8 GPUs: ten reduces and ten Frechet solves per rank instead of 80 all-reduces and 80 redundant
     # solves on every rank
     me = tdist.rank()
+    parked = []
     for c in names:                                        # same class list on every rank (same walk)
         dst = owner[c] if owner is not None else 0
         tdist.reduce_sum_(accs[c].buffer(), dst=dst)
         if owner is not None and dst != me:
-            accs[c] = None                                 # not this rank's class: free the buffer
+            # not this rank's class.  The buffer is the library's own hipMalloc memory, not the caching allocator's: it must
+            # outlive the asynchronous reduce without relying on hipFree's implicit device-wide synchronisation (which would
+            # also drain every reduce before the next is enqueued) -- so the accumulators are parked and dropped together
+            parked.append(accs[c])
+            accs[c] = None
+    if parked:
+        torch.cuda.current_stream(engine.device).synchronize()
+        parked.clear()
     return accs
 
 
@@ -429,6 +440,9 @@ def calculate_per_class_fid(paths, batch_size, cuda, dims, weights=None, num_cla
     return out, skipped
 
 
+_CLASS_SOLVERS = {}
+
+
 def _solve_classes(pairs, dims, dev, eps=1e-6):
     """Frechet distances of [(StatsAccumulator side 1, side 2), ...] on this rank.  A solve at d = 2048 is ~4 000 short
     dependent launches (csrc/frechet.hip: one per column of the tridiagonalisation), i.e. launch-latency bound, so several
@@ -449,8 +463,16 @@ def _solve_classes(pairs, dims, dev, eps=1e-6):
     def work(t):
         try:
             torch.cuda.set_device(dev)
-            stream = torch.cuda.Stream(device=dev) if nthr > 1 else main_stream
-            solver = device.FrechetSolver(dims, dev) if nthr > 1 else frechet_solver(dims, dev)
+            # one solver + stream per worker slot, kept for the life of the process like engine.frechet_solver: creating them
+            # per call cost several d x d hipMallocs each, and closing a solver (hipFree = device-wide synchronisation) while
+            # the sibling threads were still enqueueing their ~4000 launches per solve stalled the interleaving
+            if nthr > 1:
+                key = (int(dims), str(dev), t)
+                if key not in _CLASS_SOLVERS:
+                    _CLASS_SOLVERS[key] = (device.FrechetSolver(dims, dev), torch.cuda.Stream(device=dev))
+                solver, stream = _CLASS_SOLVERS[key]
+            else:
+                solver, stream = frechet_solver(dims, dev), main_stream
             with torch.cuda.stream(stream):
                 stream.wait_event(done)
                 for j in range(t, n, nthr):
@@ -462,8 +484,6 @@ def _solve_classes(pairs, dims, dev, eps=1e-6):
                         res = solver.distance(m1, s1, m2, s2, float(eps))
                     out[j] = float(res["fid"])
                 stream.synchronize()
-            if nthr > 1:
-                solver.close()
         except BaseException as e:                                                 # noqa: BLE001 -- re-raised below
             errs.append(e)
 

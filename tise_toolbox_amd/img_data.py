@@ -144,6 +144,7 @@ class U8CacheLoader:
         self.device = torch.device(device)
         self.h2d_seconds = 0.0
         self.first_item_done_at, self.first_item_rows = None, 0
+        self.first_item_event, self.last_item_event = None, None
 
     def __len__(self):
         return (self.hi - self.lo) // self.bs
@@ -167,6 +168,8 @@ class U8CacheLoader:
         views = [memoryview(p.numpy()).cast("B") for p in pinned]
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))       # the device buffers may be memory that queued kernels still use
+        for t in dev:
+            t.record_stream(side)                                       # ... and the allocator must not recycle them under a copy still in flight
         ready = [torch.cuda.Event() for _ in range(nbuf)]
         consumed = [torch.cuda.Event() for _ in range(nbuf)]
         handed = [threading.Semaphore(1) for _ in range(nbuf)]        # released when the consumer gave slot k back
@@ -215,19 +218,35 @@ class U8CacheLoader:
                     raise k
                 k, rows = k
                 cur = torch.cuda.current_stream(self.device)
-                cur.wait_event(ready[k])
                 if b == 1:
-                    self.first_item_done_at = time.perf_counter()       # the consumer came back for the second item
+                    # the consumer came back for the second item: the first device batch is ENQUEUED, not finished (the trunk is
+                    # asynchronous) -- so the steady-state rate is taken between two device events, not from this host time
+                    self.first_item_done_at = time.perf_counter()
                     self.first_item_rows = item_rows
+                    self.first_item_event = torch.cuda.Event(enable_timing=True)
+                    self.first_item_event.record(cur)
+                cur.wait_event(ready[k])
                 yield dev[k][:rows]
                 consumed[k].record(torch.cuda.current_stream(self.device))
                 handed[k].release()
+            if self.first_item_event is not None:
+                self.last_item_event = torch.cuda.Event(enable_timing=True)
+                self.last_item_event.record(torch.cuda.current_stream(self.device))
         finally:
             stop.set()
             for h in handed:
                 h.release()
             th.join()
+            side.synchronize()                                          # an early exit: no copy may outlive the buffers
             os.close(fd)
+
+    def steady_seconds(self):
+        """Device time from the end of the first device batch's work to the end of the last one's (None with fewer than two
+        items): what the feed sustains without the process's first-use costs.  Synchronises on the last event."""
+        if self.first_item_event is None or self.last_item_event is None:
+            return None
+        self.last_item_event.synchronize()
+        return self.first_item_event.elapsed_time(self.last_item_event) * 1e-3
 
 
 def collate_u8(samples):

@@ -220,6 +220,11 @@ def seeded_init_(net, seed=0, calibration="fid"):
     if key in _SEEDED_CACHE:
         net.load_state_dict(_SEEDED_CACHE[key])
         return net
+    cached = _standin_cache_load(key)
+    if cached is not None:
+        net.load_state_dict(cached)
+        _SEEDED_CACHE[key] = cached
+        return net
     g = torch.Generator(device="cpu").manual_seed(seed)
     for name, m in net.named_modules():
         if isinstance(m, nn.Conv2d):
@@ -275,7 +280,59 @@ def seeded_init_(net, seed=0, calibration="fid"):
     if was_training:
         net.train()
     _SEEDED_CACHE[key] = {k: v.clone() for k, v in net.state_dict().items()}
+    _standin_cache_store(key, _SEEDED_CACHE[key])
     return net
+
+
+# ---- disk cache of the calibrated stand-ins -------------------------------------------------------------------------
+# The two one-thread calibration passes cost ~50 s per process on the GPU boxes' hosts (a rank of a multi-process test, every
+# bench run, every CLI invocation with --synthetic-weights paid them).  The result is a pure function of (seed, classes,
+# calibration convention) and of the code above, so it is kept as a file: $TISE_STANDIN_CACHE, else a per-user 0700
+# directory under the temp dir.  The file holds exactly the state_dict the calibration produced -- loading it gives the
+# same bits -- and is written to a temporary name and renamed into place.  TISE_STANDIN_CACHE=off disables it.
+_STANDIN_VERSION = 3
+
+
+def _standin_cache_path(key):
+    import hashlib
+    import os
+    import tempfile
+    root = os.environ.get("TISE_STANDIN_CACHE")
+    if root == "off":
+        return None
+    if not root:
+        uid = os.getuid() if hasattr(os, "getuid") else 0
+        root = os.path.join(tempfile.gettempdir(), f"tise_toolbox_amd_standin_{uid}")
+    tag = hashlib.sha256(repr((_STANDIN_VERSION, key, CALIBRATION_NOISE_FRACTIONS, torch.__version__)).encode()).hexdigest()[:20]
+    return os.path.join(root, f"inception3_standin_{key[0]}_{key[1]}_{key[2]}_{tag}.pt")
+
+
+def _standin_cache_load(key):
+    import os
+    path = _standin_cache_path(key)
+    if path is None or not os.path.exists(path):
+        return None
+    try:
+        if hasattr(os, "getuid") and os.stat(path).st_uid != os.getuid():
+            return None
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+        return sd if isinstance(sd, dict) and "fc.bias" in sd else None
+    except Exception:                                                     # a torn or foreign file: calibrate again
+        return None
+
+
+def _standin_cache_store(key, sd):
+    import os
+    path = _standin_cache_path(key)
+    if path is None:
+        return
+    try:
+        os.makedirs(os.path.dirname(path), mode=0o700, exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        torch.save(sd, tmp)
+        os.replace(tmp, path)
+    except Exception:                                                     # read-only temp dir: no cache, no error
+        pass
 
 
 def build_inception3(weights=None, num_classes=1000, seed=0, calibration="fid"):
@@ -373,6 +430,26 @@ class InceptionV3(nn.Module):
             x[:, 2] = x[:, 2] * (0.225 / 0.5) + (0.406 - 0.5) / 0.5
         return x
 
-    def logits(self, pool3):
-        """fc head on pool3 features (B,2048[,1,1]) -> (B, num_classes)."""
-        return self.fc(pool3.flatten(1))
+    def logits(self, pool3, bias=True):
+        """fc head on pool3 features (B,2048[,1,1]) -> (B, num_classes).
+
+        ``bias=False`` is the head of the reference IS* for COCO: image_realism/IS/coco/inception_score_star_coco.py:104-105
+        takes ONLY the weight matrix of the graph's last layer (``w = ...get_operation_by_name("softmax/logits/MatMul").inputs[1];
+        logits = tf.matmul(tf.squeeze(pool3, [1, 2]), w)``) -- the graph's BiasAdd is deliberately left out.  The O-IS
+        script runs the whole torch model (object_centric_inception_score.py:41-60) and the bird script the slim
+        ``logits`` end point (inception_score_star_bird.py:189): both WITH the bias.  ``fc_bias_for_rule`` maps the rules."""
+        x = pool3.flatten(1)
+        return self.fc(x) if bias else F.linear(x, self.fc.weight)
+
+
+def fc_bias_for_rule(rule, fc_bias="auto"):
+    """Whether the classifier bias enters the IS* logits: ``fc_bias`` "on" / "off" force it, "auto" follows the
+    reference script of the rule -- coco: no bias (inception_score_star_coco.py:104-105), bird / ois: bias
+    (inception_score_star_bird.py:189, object_centric_inception_score.py:41-60)."""
+    if isinstance(fc_bias, bool):
+        return fc_bias
+    if fc_bias in ("on", "off"):
+        return fc_bias == "on"
+    if fc_bias not in (None, "auto"):
+        raise ValueError(f"fc_bias must be auto, on or off, not {fc_bias!r}")
+    return rule != "coco"

@@ -9,7 +9,10 @@ Drop-in for the reference ``image_realism/IS/coco/inception_score_star_coco.py``
 
 Model note: the reference IS* runs the 2015 TensorFlow Inception graph (1008
 classes, T calibrated for it); north_star prescribes the PyTorch InceptionV3 instead, so scores are
-comparable between paths run with the SAME weights only.  The reduction itself -- temperature,
+comparable between paths run with the SAME weights only.  What IS kept of the reference head: for
+``--rule coco`` the logits are ``pool3 @ W.T`` WITHOUT the classifier bias, as
+inception_score_star_coco.py:104-105 multiplies pool3 by the last layer's weight matrix only
+(``--fc-bias on`` adds it; the bird and ois rules use the model's biased logits like their scripts).  The reduction itself -- temperature,
 softmax, split rule, KL, exp, mean/std -- is the reference's, evaluated on device in fp64
 (csrc/is_score.hip) from fp32 logits.
 """
@@ -29,7 +32,7 @@ warnings.filterwarnings("ignore")
 
 _ENGINE = None
 _CONFIG = {"weights": None, "num_classes": 1000, "seed": 0, "temperature": T_COCO, "batch_size": 50,
-           "rule": "coco", "drop_first_class": False, "num_workers": 8}
+           "rule": "coco", "drop_first_class": False, "num_workers": 8, "fc_bias": "auto"}
 
 
 def configure(**kw):
@@ -43,7 +46,7 @@ def _engine():
     global _ENGINE
     if _ENGINE is None:
         _ENGINE = RealismEngine(dims=2048, weights=_CONFIG["weights"], num_classes=_CONFIG["num_classes"],
-                                seed=_CONFIG["seed"], with_logits=True)
+                                seed=_CONFIG["seed"], with_logits=True, fc_bias=_CONFIG["fc_bias"])
     return _ENGINE
 
 
@@ -142,6 +145,10 @@ def _build_parser():
     parser.add_argument("--num-classes", type=int, default=1000)
     parser.add_argument("--seed", type=int, default=0, help="seed of the --synthetic-weights parameters")
     parser.add_argument("--label", type=str, default="IS", choices=["IS", "O-IS", "bird"])
+    parser.add_argument("--fc-bias", type=str, default="auto", choices=["auto", "on", "off"],
+                        help="classifier bias in the logits. auto follows the reference script of --rule: coco forms its logits "
+                             "from the weight matrix alone (inception_score_star_coco.py:104-105: no bias), bird and ois use "
+                             "the model's biased logits")
     return parser
 
 
@@ -153,7 +160,7 @@ def main(argv=None):
     wpath, tag = tweights.resolve(args.weights, args.synthetic_weights,
                                   "inception80" if args.label == "O-IS" and args.num_classes == 80 else "inception")
     configure(weights=wpath, num_classes=args.num_classes, seed=args.seed, temperature=args.temperature,
-              batch_size=args.batch_size, rule=args.rule, drop_first_class=args.drop_first_class)
+              batch_size=args.batch_size, rule=args.rule, drop_first_class=args.drop_first_class, fc_bias=args.fc_bias)
     images = load_data(args.image_folder)
     print(".......")
     mean, std = get_inception_score(images, splits=args.splits)
