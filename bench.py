@@ -252,6 +252,9 @@ def main():
                     help="skip the host_feed leg (N = 1, after the timed region: the same job fed from pinned HOST memory in "
                          "--feed-batch slices, as the CLI's --u8-cache path feeds it; reported next to `value`, never instead of it)")
     ap.add_argument("--feed-batch", type=int, default=50, help="loader batch of the host_feed leg (README.md:214-219: 50)")
+    ap.add_argument("--png-images", type=int, default=12000,
+                    help="png_feed leg (N = 1, after the timed region, never `value`): this many images of the timed set are written as "
+                         "PNG files and the job is run from the FILES through the CLIs' feed (png_ring.py); 0 skips the leg")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(args.gpus))                  # before anything touches the GPU in this process
@@ -520,6 +523,9 @@ def main():
         if world == 1 and not args.no_host_feed:
             out["host_feed"] = host_feed_leg(eng, data, lo, n_total, args.feed_batch, mu_ref, sigma_ref, solver, dev,
                                              float(res["fid"]), n_total / elapsed)
+        out["png_feed"] = None
+        if world == 1 and args.png_images > 0:
+            out["png_feed"] = png_feed_leg(eng, data, lo, min(args.png_images, n_rank), args.feed_batch, mu_ref, sigma_ref, solver, dev)
         if world == 1 and not args.no_cpu_baseline:
             # ---- CPU oracle on the first images of the timed set: the baseline AND the parity figures --------
             n_cpu = max(50, (min(args.cpu_sample, n_rank) // 50) * 50)
@@ -600,6 +606,89 @@ def host_feed_leg(eng, data, lo, n_total, feed_batch, mu_ref, sigma_ref, solver,
             "ratio_to_resident": (n_used / wall) / rate_resident, "fid": fid, "dfid_vs_resident": abs(fid - fid_resident),
             "note": "whole job from pinned host memory (H2D copies inside the timed region, gathered into device batches on a side "
                     "stream); the Frechet solve here is the one-call form (no side-stream prefactor), `value` stays the device-resident rate"}
+
+
+def _write_pngs(args):
+    npy, lo, hi, d = args
+    from PIL import Image
+    arr = np.load(npy, mmap_mode="r")
+    for i in range(lo, hi):
+        Image.fromarray(np.asarray(arr[i])).save(os.path.join(d, f"{i:06d}.png"))
+    return hi - lo
+
+
+def png_feed_leg(eng, data, lo, n, feed_batch, mu_ref, sigma_ref, solver, dev):
+    """Row a2 inside the bench: the first ``n`` images of the timed set are written as PNG FILES (Pillow, its default
+    compression) and the job -- image loop + reduce + finalize + Frechet + IS* -- is run from the files through the feed of
+    the drop-in CLIs: tise_toolbox_amd.png_ring (decode processes, csrc/png_decode.c -> shared page-locked ring ->
+    side-stream H2D -> device batches).  PNG decode, the H2D copies and the start of the decode processes are INSIDE the
+    timed wall; writing the files is not.  Never `value`."""
+    import shutil
+    from concurrent.futures import ProcessPoolExecutor
+    from tise_toolbox_amd import png_ring
+    from tise_toolbox_amd.engine import T_COCO, device_batch_images
+    n = (n // feed_batch) * feed_batch
+    tmp = tempfile.mkdtemp(prefix="tise_bench_pngfeed_")
+    try:
+        npy = os.path.join(tmp, "pixels.npy")
+        np.save(npy, data[:n].cpu().numpy())
+        d = os.path.join(tmp, "png")
+        os.makedirs(d)
+        procs = max(1, png_ring.usable_cpus())
+        step = -(-n // (4 * procs))
+        t0 = time.perf_counter()
+        with ProcessPoolExecutor(procs) as ex:
+            list(ex.map(_write_pngs, [(npy, a, min(a + step, n), d) for a in range(0, n, step)]))
+        t_write = time.perf_counter() - t0
+        files = [os.path.join(d, f"{i:06d}.png") for i in range(n)]
+        png_bytes = sum(os.path.getsize(f) for f in files[:200]) / 200.0
+        limit = device_batch_images(feed_batch, int(np.prod(data.shape[1:])))
+
+        def resident():
+            eng.begin(n_total=n, temperature=T_COCO, splits=10, rule="coco")
+            for a in range(0, n, limit):
+                eng.step_u8(data[a:min(a + limit, n)], lo + a)
+            eng.reduce()
+            mu, sigma = eng.statistics()
+            r = solver.distance(mu, sigma, mu_ref, sigma_ref)
+            eng.inception_score()
+            torch.cuda.synchronize()
+            return float(r["fid"])
+
+        def from_files():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loader = png_ring.PngRingLoader(files, feed_batch, dev, group=limit // feed_batch)     # starts the decode processes
+            eng.begin(n_total=n, temperature=T_COCO, splits=10, rule="coco")
+            base = lo
+            for big in loader:
+                eng.step_u8(big, base)
+                base += big.shape[0]
+            t_loop = time.perf_counter()
+            eng.reduce()
+            mu, sigma = eng.statistics()
+            r = solver.distance(mu, sigma, mu_ref, sigma_ref)
+            eng.inception_score()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            return t1 - t0, t_loop - t0, float(r["fid"]), loader
+        fid_res = resident()
+        t0 = time.perf_counter()
+        resident()
+        t_res = time.perf_counter() - t0
+        from_files()                                                # page cache, pinned-ring registration path, allocator
+        wall, loop, fid, loader = from_files()
+        return {"images_per_s": n / wall, "seconds": wall, "image_loop_seconds": loop, "images": n, "feed_batch": feed_batch,
+                "device_batch": limit, "decode_processes": loader.workers, "host_hardware_threads": os.cpu_count(),
+                "host_usable_cpus": png_ring.usable_cpus(), "all_decoded_after_s": loader.decode_seconds,
+                "png_bytes_per_image": png_bytes, "write_seconds_untimed": t_write,
+                "resident_same_images_per_s": n / t_res, "ratio_to_resident": (n / wall) / (n / t_res),
+                "fid": fid, "dfid_vs_resident": abs(fid - fid_res),
+                "note": "whole job from PNG FILES: start of the decode processes + PNG decode (csrc/png_decode.c, Pillow for files outside "
+                        "its subset) + H2D + image loop + reduce + finalize + Frechet (one-call form) + IS*; the same images from HBM, same "
+                        "code path, alongside (resident_same_images_per_s); host_usable_cpus = affinity and cgroup CPU quota"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def hbm_kernel_probe(eng, batch_u8, dev, reps=20):

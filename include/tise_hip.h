@@ -41,6 +41,19 @@ int tise_version(void);                        /* ABI version, currently 1      
 int tise_device_info(int* cu_count, int* gcn_arch_is_gfx950, size_t* total_mem);
 
 /* ------------------------------------------------------------------------------------------
+ * (a2) Host feed.  The reference hands decoded images from 8 DataLoader worker processes to the main process through
+ * pickling queues as fp32 tensors (image_realism/FID/fid_score.py:215-217, img_data.py:19-25).  Here the decode workers
+ * write uint8 pixels into one shared-memory ring owned by the caller (tise_toolbox_amd/png_ring.py); these three calls
+ * page-lock that ring once and enqueue host->device copies straight from it.
+ *   tise_host_register    hipHostRegister of caller-owned host memory (the memory stays the caller's)
+ *   tise_host_unregister  before the caller unmaps it
+ *   tise_memcpy_h2d_async enqueue on `stream`; asynchronous when src_host is page-locked (registered)
+ * ------------------------------------------------------------------------------------------ */
+int tise_host_register(void* host_ptr, size_t bytes);
+int tise_host_unregister(void* host_ptr);
+int tise_memcpy_h2d_async(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * (a3) PIL-exact uint8 bilinear resize + ToTensor + input affine, fused.
  * Replaces transforms.Resize((299,299)) + ToTensor()   image_realism/FID/fid_score.py:208-213
  * (Pillow ImagingResample, 8bpc: 22-bit fixed-point coefficients, horizontal pass -> u8 ->

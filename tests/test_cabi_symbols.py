@@ -72,3 +72,17 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "from tests" not in text, f
+
+
+def test_png_library_exports_its_header():
+    """libtise_png.so (gcc, csrc/png_decode.c): every symbol include/tise_png.h declares, bound as _png_worker binds them."""
+    from tise_toolbox_amd import _png_worker, build
+    build.build_png(force=False, verbose=False)
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "tise_png.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(tise_png_[a-z0-9_]+)\s*\(", text)))
+    assert declared == ["tise_png_decode_rgb8", "tise_png_inflate_backend", "tise_png_probe", "tise_png_scratch_bytes"]
+    raw = ctypes.CDLL(build.PNG_LIB)
+    for name in declared:
+        getattr(raw, name)
+    lib = _png_worker.load_decoder()
+    assert lib is not None and lib.tise_png_inflate_backend() in (0, 1)

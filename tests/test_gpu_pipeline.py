@@ -657,3 +657,44 @@ def test_u8_cache_feed_is_bit_identical_to_png_decoding(setup, tmp_path):
     loader = img_data.U8CacheLoader(str(gdir / fid_score.U8_CACHE_NAME), 5, setup["dev"], rows=(5, 20))
     got = torch.cat([b.clone() for b in loader])
     assert len(loader) == 3 and torch.equal(got.cpu(), torch.from_numpy(np.load(gdir / fid_score.U8_CACHE_NAME)[5:20]))
+
+
+def test_png_ring_feed_is_bit_identical_to_the_dataloader_feed(setup, tmp_path, capfd):
+    """Row a2: --png-feed ring (decode processes -> shared page-locked ring -> side-stream H2D, png_ring.py) against
+    --png-feed dataloader (DataLoader workers + collate + pin_memory, the round 1-4 path): same files, same walk order, same
+    drop-last rule -> the SAME FID to the last bit, for several worker counts and a device batch that straddles chunks; a
+    directory with one image of another size falls back to the DataLoader path and still gives the DataLoader result."""
+    from PIL import Image
+    from tise_toolbox_amd import fid_score
+    gdir, rdir = tmp_path / "gen", tmp_path / "ref"
+    gdir.mkdir(); rdir.mkdir()
+    for i in range(47):
+        Image.fromarray(setup["gen"][i % N_GEN]).save(gdir / f"{i:05d}.png")
+    for i in range(31):
+        Image.fromarray(setup["ref"][i % N_REF]).save(rdir / f"{i:05d}.png")
+    base = ["--batch-size", "5", "--path1", str(rdir), "--path2", str(gdir), "--synthetic-weights"]
+    want = fid_score.main(base + ["--png-feed", "dataloader", "--num-workers", "2"])
+    capfd.readouterr()
+    for extra in (["--num-workers", "3"], ["--num-workers", "16"], []):
+        got = fid_score.main(base + ["--png-feed", "ring"] + extra)
+        err = capfd.readouterr().err
+        assert "shared pinned ring" in err and "falling back" not in err, err
+        assert got == want, (extra, got, want)
+    os.environ["TISE_DEVICE_BATCH"] = "15"                    # device batches of 15 images: chunks of 8 straddle them
+    try:                                                      # (another batching of the fp64 sums: compare like with like)
+        want15 = fid_score.main(base + ["--png-feed", "dataloader", "--num-workers", "2"])
+        assert fid_score.main(base + ["--png-feed", "ring", "--num-workers", "4"]) == want15
+        assert abs(want15 - want) <= 1e-5
+    finally:
+        del os.environ["TISE_DEVICE_BATCH"]
+    # statistics-only mode goes through the ring too
+    so = tmp_path / "s.npz"
+    fid_score.main(["--batch-size", "5", "--path2", str(gdir), "--save-stats", str(so), "--synthetic-weights"])
+    assert abs(fid_score.main(["--batch-size", "5", "--path1", str(so), "--path2", str(gdir), "--synthetic-weights"])) <= 1e-4
+    # ragged directory: fallback
+    Image.fromarray(setup["gen"][3][:100, :120]).save(gdir / "00046.png")
+    capfd.readouterr()
+    rag_dl = fid_score.main(base + ["--png-feed", "dataloader", "--num-workers", "2"])
+    rag_ring = fid_score.main(base + ["--png-feed", "ring", "--num-workers", "4"])
+    assert "falling back to the DataLoader path" in capfd.readouterr().err
+    assert rag_ring == rag_dl

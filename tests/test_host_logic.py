@@ -315,3 +315,156 @@ def test_device_batch_rule_and_class_owners(monkeypatch):
     assert tdist.class_owners(names, 1) == {c: 0 for c in names} and tdist.class_owners([], 4) == {}
     counts = [sum(1 for c in range(80) if c % 8 == r) for r in range(8)]
     assert counts == [10] * 8                                           # BASELINE configs[4]: 80 classes on 8 GPUs
+
+
+def test_png_ring_protocol_order_drop_last_and_ragged(tmp_path):
+    """png_ring.PngRingLoader without a GPU (iter_host): decode workers write walk-ordered chunks into the shared ring, the
+    parent sees every image exactly once and in order whatever the worker / chunk / slot counts; only whole loader batches
+    are served (fid_score.py:90-96, 215-217: drop_last); an image of another size is reported as RaggedImages; an unreadable
+    file as a RuntimeError naming it; no worker process survives."""
+    import subprocess
+    from PIL import Image
+    from tests import _cases
+    from tise_toolbox_amd import img_data, png_ring
+    imgs = _cases.smooth_images(45, 64, 48, seed=11)
+    files = []
+    for i, im in enumerate(imgs):
+        p = tmp_path / f"{i:04d}.png"
+        (Image.fromarray(im) if i % 7 else Image.fromarray(im).convert("RGBA")).save(p)      # RGBA files: convert("RGB") like img_data.py:21
+        files.append(str(p))
+    for workers, chunk, bs in ((3, 4, 6), (5, 1, 45), (1, 8, 7), (8, 50, 1)):
+        ld = png_ring.PngRingLoader(files, bs, "cpu", workers=workers, chunk=chunk)
+        assert len(ld) == 45 // bs
+        got = np.zeros((ld.n_rows, 64, 48, 3), np.uint8)
+        seen = 0
+        procs = list(ld.procs)
+        for lo, view in ld.iter_host():
+            assert lo == seen
+            got[lo:lo + len(view)] = view
+            seen += len(view)
+        assert seen == (45 // bs) * bs and np.array_equal(got, imgs[:seen])
+        assert all(p.poll() is not None for p in procs)
+    # the u8 cache is built through the same ring
+    cache = str(tmp_path / "cache.npy")
+    img_data.build_u8_cache(files, cache, num_workers=3, root=str(tmp_path))
+    assert np.array_equal(np.load(cache), imgs)
+    Image.fromarray(imgs[0][:30, :20]).save(files[20])
+    ld = png_ring.PngRingLoader(files, 5, "cpu", workers=2, chunk=4)
+    with pytest.raises(png_ring.RaggedImages, match="0020.png"):
+        for _ in ld.iter_host():
+            pass
+    with pytest.raises(ValueError, match="one size"):
+        img_data.build_u8_cache(files, cache, num_workers=2, root=str(tmp_path))
+    open(files[20], "wb").write(b"not a png")
+    ld = png_ring.PngRingLoader(files, 5, "cpu", workers=2, chunk=4)
+    with pytest.raises(RuntimeError, match="png decode worker failed"):
+        for _ in ld.iter_host():
+            pass
+    assert png_ring.auto_workers(1) >= 2 and png_ring.auto_workers(8) >= 2
+
+
+def _png_bytes(img, ft, split=1):
+    """A PNG file image of `img` (h, w, 3 | 4) whose rows all use filter type `ft` (5: a different one per row), the
+    compressed stream cut into `split` IDAT chunks, with an ancillary chunk in front."""
+    import struct
+    import zlib
+    h, w, c = img.shape
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    raw = bytearray()
+    prev = np.zeros(w * c, np.int32)
+    for y in range(h):
+        cur = img[y].reshape(-1).astype(np.int32)
+        f = ft if ft < 5 else (y * 7 + 3) % 5
+        left = np.concatenate([np.zeros(c, np.int32), cur[:-c]])
+        ul = np.concatenate([np.zeros(c, np.int32), prev[:-c]])
+        if f == 0:
+            enc = cur
+        elif f == 1:
+            enc = cur - left
+        elif f == 2:
+            enc = cur - prev
+        elif f == 3:
+            enc = cur - ((left + prev) >> 1)
+        else:
+            p = left + prev - ul
+            pa, pb, pc = abs(p - left), abs(p - prev), abs(p - ul)
+            enc = cur - np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+        raw.append(f)
+        raw += (enc & 255).astype(np.uint8).tobytes()
+        prev = cur
+    z = zlib.compress(bytes(raw), 6)
+    parts = [z[i * len(z) // split:(i + 1) * len(z) // split] for i in range(split)]
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2 if c == 3 else 6, 0, 0, 0))
+            + chunk(b"gAMA", struct.pack(">I", 45455)) + b"".join(chunk(b"IDAT", p) for p in parts) + chunk(b"IEND", b""))
+
+
+def test_native_png_decoder_equals_pillow(monkeypatch):
+    """csrc/png_decode.c against Pillow's Image.open(f).convert("RGB") (img_data.py:19-25): every row filter, RGB and RGBA,
+    one and several IDAT chunks, odd sizes, with libdeflate and with zlib; files outside the subset and broken files are
+    handed back (non-zero code), never decoded differently."""
+    import ctypes
+    import io
+    import subprocess
+    import sys
+    from PIL import Image
+    from tise_toolbox_amd import _png_worker, build
+    build.build_png(force=False, verbose=False)
+    lib = _png_worker.load_decoder()
+    assert lib is not None
+
+    def dec(lib_, b, h, w):
+        out = np.full((h, w, 3), 7, np.uint8)
+        n = lib_.tise_png_scratch_bytes(h, w, len(b))
+        sc = np.empty(n, np.uint8)
+        gw, gh = ctypes.c_int(), ctypes.c_int()
+        rc = lib_.tise_png_decode_rgb8(b, len(b), out.ctypes.data, h, w, sc.ctypes.data, n, ctypes.byref(gw), ctypes.byref(gh))
+        return rc, out, (gh.value, gw.value)
+    rng = np.random.default_rng(0)
+    cases = []
+    for c in (3, 4):
+        for ft in range(6):
+            for (h, w) in ((1, 1), (5, 7), (64, 33), (256, 256)):
+                img = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+                if ft == 4:
+                    img[:, :, 0] = np.clip(np.add.outer(np.arange(h), np.arange(w)) * 2, 0, 255)      # smooth ramps: Paeth ties
+                for split in (1, 3):
+                    cases.append((_png_bytes(img, ft, split), h, w))
+    for b, h, w in cases:
+        want = np.asarray(Image.open(io.BytesIO(b)).convert("RGB"))
+        rc, out, _ = dec(lib, b, h, w)
+        assert rc == _png_worker.PNG_OK and np.array_equal(out, want)
+    # Pillow-written files (what the toolbox is fed with), RGB and RGBA
+    from tests import _cases
+    for im in _cases.smooth_images(6, 96, 80, seed=2):
+        for mode in ("RGB", "RGBA"):
+            bio = io.BytesIO()
+            Image.fromarray(im).convert(mode).save(bio, format="PNG")
+            rc, out, _ = dec(lib, bio.getvalue(), 96, 80)
+            assert rc == _png_worker.PNG_OK and np.array_equal(out, im)
+    base = Image.fromarray(_cases.smooth_images(1, 32, 32, seed=3)[0])
+    for variant, fmt, kw in ((base.convert("L"), "PNG", {}), (base.convert("P"), "PNG", {}), (base, "JPEG", {}),
+                             (base.convert("I;16"), "PNG", {}), (base, "PNG", {"transparency": (0, 0, 0)})):
+        bio = io.BytesIO()
+        variant.save(bio, format=fmt, **kw)
+        assert dec(lib, bio.getvalue(), 32, 32)[0] == _png_worker.PNG_UNSUPPORTED
+    good = cases[-1][0]
+    assert dec(lib, good, 100, 100)[0::2] == (_png_worker.PNG_SIZE, (256, 256))
+    assert dec(lib, good[:len(good) // 2], 256, 256)[0] == _png_worker.PNG_CORRUPT
+    assert dec(lib, b"not a png at all, but long enough to be looked at......", 4, 4)[0] == _png_worker.PNG_UNSUPPORTED
+    # the zlib back end (a fresh process: the choice is made once per process)
+    code = ("import sys, ctypes, numpy as np; sys.path.insert(0, %r)\n"
+            "from tise_toolbox_amd import _png_worker\n"
+            "lib = _png_worker.load_decoder(); assert lib.tise_png_inflate_backend() == 0\n"
+            "b = open(sys.argv[1], 'rb').read(); out = np.empty((256, 256, 3), np.uint8)\n"
+            "n = lib.tise_png_scratch_bytes(256, 256, len(b)); sc = np.empty(n, np.uint8)\n"
+            "rc = lib.tise_png_decode_rgb8(b, len(b), out.ctypes.data, 256, 256, sc.ctypes.data, n, None, None)\n"
+            "sys.stdout.buffer.write(bytes([rc]) + out.tobytes())\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".png") as tf:
+        tf.write(good)
+        tf.flush()
+        r = subprocess.run([sys.executable, "-c", code, tf.name], capture_output=True, env=dict(os.environ, TISE_PNG_ZLIB="1"))
+    assert r.returncode == 0 and r.stdout[0] == 0, r.stderr[-500:]
+    assert np.array_equal(np.frombuffer(r.stdout[1:], np.uint8).reshape(256, 256, 3), np.asarray(Image.open(io.BytesIO(good)).convert("RGB")))

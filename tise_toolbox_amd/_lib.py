@@ -37,6 +37,9 @@ SIGNATURES = {
     "tise_last_hip_error": (c_int, []),
     "tise_version": (c_int, []),
     "tise_device_info": (c_int, [POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]),
+    "tise_host_register": (c_int, [c_void_p, c_size_t]),
+    "tise_host_unregister": (c_int, [c_void_p]),
+    "tise_memcpy_h2d_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "tise_resize_bilinear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                          POINTER(c_float), c_void_p, c_void_p]),
     "tise_cosine_top1": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p,

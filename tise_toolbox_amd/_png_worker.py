@@ -1,0 +1,137 @@
+"""PNG decode worker of tise_toolbox_amd.png_ring.PngRingLoader -- a stand-alone program, started by file path.
+
+It imports numpy and Pillow only (no torch, no package import: a worker is up in ~0.15 s), attaches to two anonymous
+shared-memory files inherited from the parent (memfd: the pixel ring and the control block), and decodes
+``Image.open(f).convert("RGB")`` -- the reference's ``Dataset.__getitem__`` (image_realism/FID/img_data.py:19-25) --
+straight into ring slots, a chunk of consecutive walk-ordered files at a time.  8-bit RGB / RGBA non-interlaced PNGs are
+decoded by libtise_png.so (csrc/png_decode.c: libdeflate / zlib inflate + SSE unfilter, the same bytes as Pillow, 2-3x
+faster); every other file -- and every file when the library is absent or TISE_PNG_DECODER=pillow -- by Pillow itself.
+
+Control block (int64 header, see png_ring.HDR_*):
+    next_chunk   next chunk to claim (claimed under a POSIX record lock on the control file)
+    consumed     chunks the parent has finished with, in order: chunk c may be written once c < consumed + nslots
+    stop         the parent asks everyone to leave
+    err          first error (chunk + 1); the text sits in the error area
+followed by one ``done`` byte per chunk (1 = pixels are in the slot, 2 = failed), the error text, and the file table
+(offsets + utf-8 blob).  Nothing is pickled, nothing passes through a queue.
+"""
+import fcntl
+import mmap
+import os
+import sys
+import time
+
+import numpy as np
+from PIL import Image
+
+HDR_NEXT, HDR_CONSUMED, HDR_STOP, HDR_NCHUNKS, HDR_ERR, HDR_CHUNK, HDR_NSLOTS, HDR_H, HDR_W, HDR_NFILES, HDR_FILES_OFF, \
+    HDR_DONE_OFF, HDR_ERRTXT_OFF, HDR_STARTED = range(14)
+HDR_WORDS = 16
+ERRTXT_BYTES = 1024
+
+
+def load_decoder():
+    """ctypes binding of libtise_png.so (next to this file), or None."""
+    import ctypes
+    if os.environ.get("TISE_PNG_DECODER", "native") == "pillow":
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libtise_png.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        lib.tise_png_decode_rgb8.restype = ctypes.c_int
+        lib.tise_png_decode_rgb8.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        lib.tise_png_scratch_bytes.restype = ctypes.c_size_t
+        lib.tise_png_scratch_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_size_t]
+        lib.tise_png_probe.restype = ctypes.c_int
+        lib.tise_png_probe.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                       ctypes.POINTER(ctypes.c_int)]
+        lib.tise_png_inflate_backend.restype = ctypes.c_int
+        return lib
+    except (OSError, AttributeError):
+        return None
+
+
+PNG_OK, PNG_UNSUPPORTED, PNG_CORRUPT, PNG_SIZE, PNG_SCRATCH = range(5)
+
+
+def main(argv):
+    import ctypes
+    ring_fd, ctl_fd, ring_size, ctl_size = (int(a) for a in argv[:4])
+    ctl = mmap.mmap(ctl_fd, ctl_size)
+    ring = mmap.mmap(ring_fd, ring_size)
+    hdr = np.frombuffer(ctl, dtype=np.int64, count=HDR_WORDS)
+    n_chunks, chunk, nslots = int(hdr[HDR_NCHUNKS]), int(hdr[HDR_CHUNK]), int(hdr[HDR_NSLOTS])
+    h, w, n_files = int(hdr[HDR_H]), int(hdr[HDR_W]), int(hdr[HDR_NFILES])
+    done = np.frombuffer(ctl, dtype=np.uint8, count=n_chunks, offset=int(hdr[HDR_DONE_OFF]))
+    offs = np.frombuffer(ctl, dtype=np.int64, count=n_files + 1, offset=int(hdr[HDR_FILES_OFF]))
+    blob_off = int(hdr[HDR_FILES_OFF]) + 8 * (n_files + 1)
+    slots = np.frombuffer(ring, dtype=np.uint8, count=nslots * chunk * h * w * 3).reshape(nslots, chunk, h, w, 3)
+    ring_addr = slots.ctypes.data
+    img_bytes = h * w * 3
+    lib = load_decoder()
+    scratch = np.empty(0, dtype=np.uint8)
+    gw, gh = ctypes.c_int(), ctypes.c_int()
+
+    def fail(c, text):
+        fcntl.lockf(ctl_fd, fcntl.LOCK_EX, 8, 0)
+        try:
+            if hdr[HDR_ERR] == 0:
+                raw = text.encode("utf-8", "replace")[:ERRTXT_BYTES - 1]
+                o = int(hdr[HDR_ERRTXT_OFF])
+                ctl[o:o + len(raw) + 1] = raw + b"\0"
+                hdr[HDR_ERR] = c + 1
+        finally:
+            fcntl.lockf(ctl_fd, fcntl.LOCK_UN, 8, 0)
+        done[c] = 2
+
+    fcntl.lockf(ctl_fd, fcntl.LOCK_EX, 8, 0)
+    hdr[HDR_STARTED] += 1
+    fcntl.lockf(ctl_fd, fcntl.LOCK_UN, 8, 0)
+    parent = os.getppid()
+    while not hdr[HDR_STOP] and os.getppid() == parent:
+        fcntl.lockf(ctl_fd, fcntl.LOCK_EX, 8, 0)
+        c = int(hdr[HDR_NEXT])
+        if c < n_chunks:
+            hdr[HDR_NEXT] = c + 1
+        fcntl.lockf(ctl_fd, fcntl.LOCK_UN, 8, 0)
+        if c >= n_chunks:
+            break
+        while c >= int(hdr[HDR_CONSUMED]) + nslots:               # the slot still holds a chunk the parent has not copied
+            if hdr[HDR_STOP] or os.getppid() != parent:            # asked to leave, or the parent is gone
+                return 0
+            time.sleep(0.0005)
+        dst = slots[c % nslots]
+        lo, hi = c * chunk, min((c + 1) * chunk, n_files)
+        try:
+            for i in range(lo, hi):
+                name = bytes(ctl[blob_off + int(offs[i]):blob_off + int(offs[i + 1])]).decode("utf-8", "surrogateescape")
+                if lib is not None:
+                    with open(name, "rb") as fh_:
+                        blob = fh_.read()
+                    need = lib.tise_png_scratch_bytes(h, w, len(blob))
+                    if scratch.size < need:
+                        scratch = np.empty(need + (need >> 2), dtype=np.uint8)
+                    rc = lib.tise_png_decode_rgb8(blob, len(blob), ring_addr + ((c % nslots) * chunk + (i - lo)) * img_bytes, h, w,
+                                                  scratch.ctypes.data, scratch.size, ctypes.byref(gw), ctypes.byref(gh))
+                    if rc == PNG_OK:
+                        continue
+                    if rc == PNG_SIZE:
+                        raise ValueError(f"RAGGED {name}: {gh.value}x{gw.value} where the first image is {h}x{w}")
+                    # UNSUPPORTED (palette, gray, 16-bit, interlaced, a JPEG ...) or CORRUPT: Pillow decides / raises
+                img = Image.open(name)
+                if img.size != (w, h):
+                    raise ValueError(f"RAGGED {name}: {img.size[1]}x{img.size[0]} where the first image is {h}x{w}")
+                img = img.convert("RGB")                          # img_data.py:21
+                dst[i - lo] = np.asarray(img)
+            done[c] = 1
+        except Exception as e:                                    # noqa: BLE001 -- reported to the parent through the control block
+            fail(c, f"{type(e).__name__}: {e}")
+            return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

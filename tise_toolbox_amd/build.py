@@ -29,8 +29,25 @@ def needs_build():
     return any(os.path.getmtime(p) > t for p in deps if os.path.exists(p))
 
 
+PNG_LIB = os.path.join(HERE, "libtise_png.so")
+PNG_SRC = os.path.join(CSRC, "png_decode.c")
+
+
+def build_png(force=False, verbose=True):
+    """gcc over csrc/png_decode.c -> tise_toolbox_amd/libtise_png.so: the host-side PNG decoder of the image feed's worker
+    processes (plain C, links zlib, dlopens libdeflate when present; no HIP, so a worker never loads the GPU runtime)."""
+    if not force and os.path.exists(PNG_LIB) and os.path.getmtime(PNG_LIB) >= os.path.getmtime(PNG_SRC):
+        return PNG_LIB
+    cmd = [os.environ.get("CC", "gcc"), "-O3", "-mssse3", "-msse4.1", "-fPIC", "-shared", "-o", PNG_LIB, PNG_SRC, "-lz", "-ldl"]
+    if verbose:
+        print("[tise build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return PNG_LIB
+
+
 def build(force=False, verbose=True):
-    """Compile every HIP source for gfx950 into tise_toolbox_amd/libtise_hip.so."""
+    """Compile every HIP source for gfx950 into tise_toolbox_amd/libtise_hip.so (and the host PNG decoder, build_png)."""
+    build_png(force, verbose)
     if not force and not needs_build():
         return LIB
     cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",

@@ -40,6 +40,30 @@ int tise_device_info(int* cu_count, int* gcn_arch_is_gfx950, size_t* total_mem) 
     return TISE_OK;
 }
 
+// ---- host feed: page-lock caller-owned host memory and copy from it asynchronously ------------------------------------
+// (a2) the PNG decode workers of tise_toolbox_amd/png_ring.py write decoded uint8 pixels into ONE shared-memory ring; the
+// parent page-locks that ring once and enqueues host->device copies of finished chunks straight from it (no collate, no
+// pickling, no per-batch pin_memory) -- the hand-over the reference does through DataLoader worker queues
+// (image_realism/FID/fid_score.py:215-217).
+int tise_host_register(void* host_ptr, size_t bytes) {
+    if (!host_ptr || bytes == 0) return TISE_ERR_INVALID_ARG;
+    TISE_HIP_CHECK(hipHostRegister(host_ptr, bytes, hipHostRegisterDefault));
+    return TISE_OK;
+}
+
+int tise_host_unregister(void* host_ptr) {
+    if (!host_ptr) return TISE_ERR_INVALID_ARG;
+    TISE_HIP_CHECK(hipHostUnregister(host_ptr));
+    return TISE_OK;
+}
+
+int tise_memcpy_h2d_async(void* dst_dev, const void* src_host, size_t bytes, void* stream) {
+    if ((!dst_dev || !src_host) && bytes > 0) return TISE_ERR_INVALID_ARG;
+    if (bytes == 0) return TISE_OK;
+    TISE_HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return TISE_OK;
+}
+
 // per-translation-unit range-guard words (common.h)
 int tise_internal_split_flag_conv_split(int* host_flag, void* stream);
 int tise_internal_split_flag_conv_pipe(int* host_flag, void* stream);

@@ -28,6 +28,7 @@ Deviations from the reference, all deliberate (SURVEY.md notes N3-N5):
 import os
 import sys
 import time
+_T_IMPORT0 = time.time()
 import warnings
 from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
 
@@ -40,6 +41,21 @@ from .engine import RealismEngine, coalesce_batches, coalesce_u8, device_batch_i
 from .inception import InceptionV3
 
 warnings.filterwarnings("ignore")          # fid_score.py:49
+_T_IMPORT1 = time.time()
+
+
+def _timing(label, t0=None):
+    """TISE_TIMING=1: phase times of the process on stderr (tools/cli_probe.py reads them)."""
+    if os.environ.get("TISE_TIMING") == "1" and tdist.is_main():
+        now = time.time()
+        try:
+            import psutil
+            born = psutil.Process().create_time()
+        except Exception:                                              # noqa: BLE001
+            born = _T_IMPORT0
+        extra = f" (+{now - t0:.2f} s)" if t0 is not None else ""
+        print(f"[tise timing] {label}: {now - born:.2f} s after process start{extra}", file=sys.stderr, flush=True)
+    return time.time()
 
 
 def _build_parser():
@@ -64,8 +80,13 @@ def _build_parser():
                         help="O-FID extension: one FID per object class ({stem}_{class}_{k}.png crops)")
     parser.add_argument("--save-stats", type=str, default="", help="write mu/sigma of --path2 to this .npz")
     parser.add_argument("--label", type=str, default="FID", choices=["FID", "O-FID"])
-    parser.add_argument("--num-workers", type=int, default=min(32, os.cpu_count() or 8),
-                        help="PNG-decoding DataLoader workers (the reference hard-codes 8, fid_score.py:216)")
+    parser.add_argument("--num-workers", type=int, default=0,
+                        help="PNG decode processes (the reference hard-codes 8 DataLoader workers, fid_score.py:216); 0 = auto: "
+                             "min(128, cpus / 2) shared by the ranks of the node")
+    parser.add_argument("--png-feed", type=str, default="ring", choices=["ring", "dataloader"],
+                        help="ring: decode workers write into one shared page-locked ring the parent copies from (png_ring.py); "
+                             "dataloader: torch DataLoader workers + collate + pin_memory (round 1-4 path, also the fallback "
+                             "for directories whose images differ in size)")
     return parser
 
 
@@ -223,6 +244,42 @@ def calculate_activation_statistics(images, model, batch_size=64, dims=2048, cud
 U8_CACHE_NAME = ".tise_u8_cache.npy"
 
 
+_PNG_FEED = {"mode": "ring"}        # --png-feed
+_RING_PREFETCH = {}                  # directory -> PngRingLoader whose workers are already decoding (started before the model was built)
+_RING_LOCK = __import__("threading").Lock()   # the second directory's prefetch is started from the first loader's feeder thread
+
+
+def _num_workers(num_workers, world=1):
+    from . import png_ring
+    return int(num_workers) if num_workers and int(num_workers) > 0 else png_ring.auto_workers(world)
+
+
+def _shard_of_path(path, batch_size):
+    files = img_data.get_filenames(path)                  # os.walk order (img_data.py:27-35)
+    rank, world, _ = tdist.env_world()
+    shard, _ = tdist.shard_files(files, batch_size, rank, world)       # drop_last=True (:215-217), whole batches
+    return shard, world
+
+
+def prefetch_png_ring(path, batch_size, num_workers=0):
+    """Start the decode workers of an image directory NOW (before the model is built / while the other side is still in
+    the network): _compute_statistics_of_path picks the running loader up.  No GPU call is made here."""
+    from . import png_ring
+    if _PNG_FEED["mode"] != "ring" or path.endswith(".npz") or not os.path.isdir(path):
+        return None
+    with _RING_LOCK:
+        if path in _RING_PREFETCH:
+            return _RING_PREFETCH[path]
+        shard, world = _shard_of_path(path, batch_size)
+        if not shard:
+            return None
+        group = device_batch_images(batch_size) // batch_size
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_initialized() else torch.device("cuda", tdist.env_world()[2])
+        loader = png_ring.PngRingLoader(shard, batch_size, dev, group=group, workers=_num_workers(num_workers, world), start=True)
+        _RING_PREFETCH[path] = loader
+        return loader
+
+
 def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers=8, u8_cache=False):
     """fid_score.py:199-220: an .npz holds (mu, sigma); a directory is walked and pushed through the net.
     ``u8_cache``: decode the directory ONCE into ``<path>/.tise_u8_cache.npy`` ((N,H,W,3) uint8, walk order) and feed
@@ -242,7 +299,7 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
         err = None
         if tdist.is_main() and not img_data.u8_cache_is_current(cache, files, path):
             try:
-                img_data.build_u8_cache(files, cache, num_workers, root=path)
+                img_data.build_u8_cache(files, cache, _num_workers(num_workers, world), root=path)
             except Exception as e:                         # the other ranks must not wait in a barrier for a cache that never comes
                 err = e
         failed = tdist.any_rank(err is not None)
@@ -274,16 +331,53 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
                   file=sys.stderr)
         return out
     shard, _ = tdist.shard_files(files, batch_size, rank, world)       # drop_last=True (:215-217), whole batches
+    num_workers = _num_workers(num_workers, world)
+    if _PNG_FEED["mode"] == "ring":
+        # decode workers -> shared page-locked ring -> side-stream H2D (png_ring.py).  Every rank decides alike: a directory
+        # with images of different sizes makes EVERY rank fall back (the size check below is made on the global list's first
+        # file by the workers of each rank; a rank that meets a different size raises, and the flag is agreed on collectively)
+        from . import png_ring
+        with _RING_LOCK:
+            loader = _RING_PREFETCH.pop(path, None)
+            if loader is None and shard:
+                engine = _engine_for(model, dims)
+                loader = png_ring.PngRingLoader(shard, batch_size, engine.device, group=device_batch_images(batch_size) // batch_size,
+                                                workers=num_workers, start=True)
+        if loader is not None:
+            loader.device = _engine_for(model, dims).device
+        t0 = time.perf_counter()
+        err, out = None, None
+        try:
+            out = calculate_activation_statistics(loader if loader is not None else [], model, batch_size, dims, cuda)
+        except png_ring.RaggedImages as e:
+            if world > 1:
+                raise RuntimeError(f"--png-feed ring under torchrun needs images of one size ({e}); use --png-feed dataloader") from e
+            err = e
+        finally:
+            if loader is not None:
+                loader.close()
+        if err is None:
+            wall = time.perf_counter() - t0
+            if tdist.is_main() and len(shard):
+                sec = loader.steady_seconds()
+                steady = f"; after the first device batch {(len(shard) - loader.first_item_rows) / sec:.0f} images/s" if sec else ""
+                dec = f", all decoded {loader.decode_seconds:.2f} s after the workers started" if loader.decode_seconds else ""
+                print(f"[tise] png feed: {len(shard)} images in {wall:.2f} s ({len(shard) / wall:.0f} images/s on this rank{steady}; "
+                      f"{loader.workers} decode processes -> shared pinned ring{dec}; loader batch {batch_size}, device batch "
+                      f"{device_batch_images(batch_size)})", file=sys.stderr)
+            return out
+        print(f"[tise] png feed: images of different sizes ({err}); falling back to the DataLoader path", file=sys.stderr)
+    dl_workers = min(num_workers, 32)
     dataset = img_data.Dataset(path, transform=None, file_names=shard)
     dataloader = torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=False, drop_last=True,
-                                             num_workers=num_workers, collate_fn=img_data.collate_u8,
+                                             num_workers=dl_workers, collate_fn=img_data.collate_u8,
                                              pin_memory=True)
     t0 = time.perf_counter()
     out = calculate_activation_statistics(dataloader, model, batch_size, dims, cuda)
     wall = time.perf_counter() - t0
     if tdist.is_main() and len(shard):
-        print(f"[tise] png feed: {len(shard)} images in {wall:.2f} s ({len(shard) / wall:.0f} images/s on this rank, {num_workers} "
-              f"decode workers, loader batch {batch_size}, device batch {device_batch_images(batch_size)})", file=sys.stderr)
+        print(f"[tise] png feed: {len(shard)} images in {wall:.2f} s ({len(shard) / wall:.0f} images/s on this rank, {dl_workers} "
+              f"DataLoader decode workers, loader batch {batch_size}, device batch {device_batch_images(batch_size)})", file=sys.stderr)
     return out
 
 
@@ -302,8 +396,20 @@ def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_c
         if not os.path.exists(p):
             raise RuntimeError("Invalid path: %s" % p)    # :225-227
     _check_cuda(cuda)
+    if not u8_cache:
+        # the decode workers of the first directory start now: PNG decode overlaps building the model (weights, BatchNorm
+        # folding, split packing); the second directory's start when the first one's last chunk is decoded
+        first = next((p for p in paths if os.path.isdir(p)), None)
+        rest = [p for p in paths if os.path.isdir(p) and p != first]
+        ld = prefetch_png_ring(first, batch_size, num_workers) if first else None
+        if ld is not None and rest:
+            ld.on_all_decoded = lambda: prefetch_png_ring(rest[0], batch_size, num_workers)
+    t = _timing("decode workers started, building the model")
     model = _build_model(dims, weights, num_classes, seed)
+    _engine_for(model, dims)                               # fold BatchNorm, pack the split weights, load the code objects
+    t = _timing("model + engine ready", t)
     m1, s1 = _compute_statistics_of_path(paths[0], model, batch_size, dims, cuda, num_workers, u8_cache)
+    t = _timing("first side done", t)
     # the first side's covariance is complete: factor it on a side stream while the second side's images are decoded
     # and pushed through the network (Tr sqrtm(S1 S2) is symmetric in its arguments; csrc/frechet.hip)
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -312,6 +418,7 @@ def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_c
     if use_pf:
         solver.prefactor(torch.as_tensor(np.ascontiguousarray(s1, dtype=np.float64), device=dev))
     m2, s2 = _compute_statistics_of_path(paths[1], model, batch_size, dims, cuda, num_workers, u8_cache)
+    t = _timing("second side done", t)
     if save_stats and tdist.is_main():
         np.savez(save_stats, mu=np.asarray(m2), sigma=np.asarray(s2))
     if not use_pf or np.shape(m1) != np.shape(m2) or np.shape(s1) != np.shape(s2):
@@ -336,6 +443,8 @@ def save_statistics_of_path(path, out_npz, batch_size, cuda, dims, weights=None,
     if not os.path.exists(path):
         raise RuntimeError("Invalid path: %s" % path)
     _check_cuda(cuda)
+    if not u8_cache:
+        prefetch_png_ring(path, batch_size, num_workers)   # decode overlaps building the model
     model = _build_model(dims, weights, num_classes, seed)
     mu, sigma = _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers, u8_cache)
     if tdist.is_main():
@@ -366,7 +475,8 @@ def _class_statistics(path, model, batch_size, dims, num_workers, owner=None):
     accs = {c: device.StatsAccumulator(dims, engine.device) for c in names}
     dataset = img_data.Dataset(path, transform=None, file_names=files[lo:hi])
     loader = torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=False, drop_last=False,
-                                         num_workers=num_workers, collate_fn=img_data.collate_u8, pin_memory=True)
+                                         num_workers=min(32, _num_workers(num_workers, world)), collate_fn=img_data.collate_u8,
+                                         pin_memory=True)
     base = lo
     for batch in coalesce_batches(loader, engine.device, device_batch_images(batch_size)):
         feats = _forward_batch(engine, model, batch)
@@ -503,6 +613,7 @@ def _solve_classes(pairs, dims, dev, eps=1e-6):
 def main(argv=None):
     parser = _build_parser()
     args = parser.parse_args(argv)
+    _timing(f"imports done (this module's imports {_T_IMPORT1 - _T_IMPORT0:.2f} s)")
     if args.gpu == "":
         _check_cuda(False)
     if args.path1 is None and not args.save_stats:
@@ -510,6 +621,7 @@ def main(argv=None):
     rank, world, local_rank = tdist.init_from_env()
     if world == 1:
         os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu)        # reference: CUDA_VISIBLE_DEVICES = args.gpu (:243)
+    _PNG_FEED["mode"] = args.png_feed
     kind = "inception80" if (args.label == "O-FID" and args.num_classes == 80) else "inception"
     wpath, tag = tweights.resolve(args.weights, args.synthetic_weights, kind)
     if args.path1 is None:                                             # statistics-only

@@ -1,0 +1,347 @@
+"""PNG feed of the drop-in CLIs: decode workers -> ONE shared, page-locked uint8 ring -> side-stream H2D -> device batches.
+
+Replaces (row a2 of SURVEY section 8) the hand-over of image_realism/FID/fid_score.py:215-217 --
+``DataLoader(dataset, batch_size, drop_last=True, num_workers=8)`` whose workers run ``Dataset.__getitem__``
+(img_data.py:19-25: ``Image.open(f).convert("RGB")`` + transform) and ship every batch to the main process through a
+pickling queue, where it is collated and pinned.  Round 4 measured that hand-over as THE limit of the drop-in: 3 850 images/s
+with 8 workers, 4 699 with 32, 3 565 with 64 on a 256-thread host -- falling with more workers, i.e. bound by the parent
+(queues + collate + the pin-memory thread), not by zlib (profiles/r04h_cli_host_inclusive.txt).
+
+Here the parent touches no pixel:
+  * workers are stand-alone programs (``_png_worker.py``: numpy + Pillow only, started with subprocess -- no torch import,
+    no fork of a process that holds a GPU context, no multiprocessing machinery) that decode walk-ordered chunks of
+    ``chunk`` files straight into slots of an anonymous shared-memory ring (memfd, inherited file descriptors) and set one
+    ``done`` byte per chunk; chunks are claimed under a POSIX record lock, a slot is rewritten only after the parent has
+    copied the chunk that was in it (``consumed`` counter);
+  * the parent page-locks the ring ONCE (tise_host_register) and a feeder thread enqueues ``tise_memcpy_h2d_async`` copies of
+    finished chunks, in order, on a side stream into one of three device buffers; a device batch is handed to the consumer
+    with an event its stream waits on -- the same contract as img_data.U8CacheLoader (``len()`` counts ``batch_size``
+    batches: the drop-last bookkeeping of fid_score.py:90-96; ``pregrouped``).
+Workers can be started BEFORE the model is built (``start()``), so decoding overlaps the process's start-up.
+All images must have the size of the first one; a different size raises ``RaggedImages`` and the caller falls back to the
+DataLoader path (ragged crop directories are O-FID's, which keeps that path).
+"""
+import mmap
+import os
+import queue
+import subprocess
+import sys
+import threading
+import time
+from collections import deque
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._png_worker import (ERRTXT_BYTES, HDR_CHUNK, HDR_CONSUMED, HDR_DONE_OFF, HDR_ERR, HDR_ERRTXT_OFF, HDR_FILES_OFF, HDR_H,
+                          HDR_NCHUNKS, HDR_NEXT, HDR_NFILES, HDR_NSLOTS, HDR_STARTED, HDR_STOP, HDR_W, HDR_WORDS)
+
+_WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_png_worker.py")
+
+
+class RaggedImages(ValueError):
+    """The directory holds images of different sizes: the ring (one slot shape) cannot serve it."""
+
+
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask AND the cgroup's CFS quota.  The GPU boxes show 256 hardware
+    threads and give the container ``cpu.max = 1600000 100000`` -- 16 CPUs of time per period; decode processes beyond the
+    quota are throttled in bursts and the feed gets SLOWER (12.5 k images/s with 16 workers, 8.7 k with 64, 5.9 k with 128:
+    profiles/r05b_host_decode_probe.txt; round 4's DataLoader feed fell the same way between 32 and 64 workers)."""
+    n = os.cpu_count() or 8
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):                                   # cgroup v2
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, -(-int(quota) // int(period))))
+        except (OSError, ValueError):
+            pass
+    try:                                                                       # cgroup v1
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, -(-q // per)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def auto_workers(world=1):
+    """Decode processes of one rank: the CPUs the process may really use (usable_cpus: affinity and cgroup quota; at most
+    128) shared by the ranks of the node, at least 2.  The parent needs little CPU of its own (it copies no pixel)."""
+    return max(2, min(128, usable_cpus()) // max(1, world))
+
+
+class PngRingLoader:
+    NBUF = 3
+    pregrouped = True
+
+    def __init__(self, files, batch_size, device, group=1, workers=None, chunk=8, start=True):
+        self.files = list(files)
+        self.bs = int(batch_size)
+        self.group = max(1, int(group))
+        self.device = torch.device(device)
+        self.n_rows = (len(self.files) // self.bs) * self.bs                 # whole batches only (fid_score.py:90-96)
+        self.files = self.files[:self.n_rows]
+        self.workers = int(workers) if workers else auto_workers()
+        self.chunk = max(1, int(chunk))
+        self.procs, self.ring, self.ctl = [], None, None
+        self.ring_fd = self.ctl_fd = -1
+        self.registered = False
+        self.decode_seconds = None
+        self.first_item_event = self.last_item_event = None
+        self.first_item_rows = 0
+        self.t_started = None
+        self.on_all_decoded = None                                            # hook: called once when the last chunk is in the ring
+        if self.n_rows and start:
+            self.start()
+
+    def __len__(self):
+        return self.n_rows // self.bs
+
+    # ---- shared memory + workers ------------------------------------------------------------------------------------
+    def start(self):
+        if self.procs or not self.n_rows:
+            return self
+        from PIL import Image
+        with Image.open(self.files[0]) as im:
+            w, h = im.size
+        self.h, self.w = h, w
+        img_bytes = h * w * 3
+        n_chunks = -(-self.n_rows // self.chunk)
+        self.workers = max(1, min(self.workers, n_chunks))
+        # slots: two per worker (one being written, one waiting for its copy), capped at 1 GiB of pinned pixels
+        nslots = max(2, min(2 * self.workers + 4, n_chunks, max(2, (1 << 30) // (self.chunk * img_bytes))))
+        self.nslots, self.n_chunks, self.img_bytes = nslots, n_chunks, img_bytes
+        names = [f.encode("utf-8", "surrogateescape") for f in self.files]
+        offs = np.zeros(len(names) + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in names], out=offs[1:])
+        done_off = 8 * HDR_WORDS
+        err_off = done_off + ((n_chunks + 7) & ~7)
+        files_off = err_off + ERRTXT_BYTES
+        self.ctl_size = files_off + 8 * (len(names) + 1) + int(offs[-1]) + 8
+        self.ring_size = nslots * self.chunk * img_bytes
+        self.ctl_fd = os.memfd_create("tise_png_ctl")
+        self.ring_fd = os.memfd_create("tise_png_ring")
+        os.ftruncate(self.ctl_fd, self.ctl_size)
+        os.ftruncate(self.ring_fd, self.ring_size)
+        self.ctl = mmap.mmap(self.ctl_fd, self.ctl_size)
+        self.ring = mmap.mmap(self.ring_fd, self.ring_size)
+        self.hdr = np.frombuffer(self.ctl, dtype=np.int64, count=HDR_WORDS)
+        self.hdr[:] = 0
+        self.hdr[HDR_NCHUNKS], self.hdr[HDR_CHUNK], self.hdr[HDR_NSLOTS] = n_chunks, self.chunk, nslots
+        self.hdr[HDR_H], self.hdr[HDR_W], self.hdr[HDR_NFILES] = h, w, len(names)
+        self.hdr[HDR_FILES_OFF], self.hdr[HDR_DONE_OFF], self.hdr[HDR_ERRTXT_OFF] = files_off, done_off, err_off
+        self.done = np.frombuffer(self.ctl, dtype=np.uint8, count=n_chunks, offset=done_off)
+        np.frombuffer(self.ctl, dtype=np.int64, count=len(names) + 1, offset=files_off)[:] = offs
+        blob_off = files_off + 8 * (len(names) + 1)
+        self.ctl[blob_off:blob_off + int(offs[-1])] = b"".join(names)
+        cmd = [sys.executable, "-S", _WORKER, str(self.ring_fd), str(self.ctl_fd), str(self.ring_size), str(self.ctl_size)]
+        env = dict(os.environ)
+        # site-packages must stay importable under -S (numpy, Pillow): hand the parent's path over
+        env["PYTHONPATH"] = os.pathsep.join(p for p in sys.path if p)
+        for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+            env[k] = "1"
+        self.t_started = time.perf_counter()
+        for _ in range(self.workers):
+            self.procs.append(subprocess.Popen(cmd, env=env, pass_fds=(self.ring_fd, self.ctl_fd), stdin=subprocess.DEVNULL))
+        return self
+
+    def _error(self):
+        o = int(self.hdr[HDR_ERRTXT_OFF])
+        raw = bytes(self.ctl[o:o + ERRTXT_BYTES]).split(b"\0", 1)[0].decode("utf-8", "replace")
+        if raw.startswith("ValueError: RAGGED "):
+            return RaggedImages(raw[len("ValueError: RAGGED "):])
+        return RuntimeError(f"png decode worker failed: {raw}")
+
+    def _wait_chunk(self, c, stop):
+        """Block until chunk c is decoded (done byte set); raises on a worker error or a dead worker."""
+        spins = 0
+        while not self.done[c]:
+            if stop.is_set():
+                return False
+            spins += 1
+            if spins % 2000 == 0:                                             # ~ every 0.4 s: is anybody still alive?
+                if self.hdr[HDR_ERR]:
+                    raise self._error()
+                if all(p.poll() is not None for p in self.procs) and not self.done[c]:
+                    raise RuntimeError("png decode workers exited before the ring was complete "
+                                       f"(exit codes {sorted(set(p.returncode for p in self.procs))})")
+            time.sleep(0.0002)
+        if self.done[c] == 2:
+            raise self._error()
+        return True
+
+    def iter_host(self):
+        """Host-side iteration (no GPU): yields (first row, uint8 view (rows, H, W, 3) of the ring slot) chunk by chunk in walk
+        order; the view is valid until the next item is requested (its slot is then released to the workers).  Used by
+        img_data.build_u8_cache and by the CPU tests of the worker protocol."""
+        if not self.n_rows:
+            return
+        self.start()
+        stop = threading.Event()
+        slots = np.frombuffer(self.ring, dtype=np.uint8).reshape(self.nslots, self.chunk, self.h, self.w, 3)
+        try:
+            for c in range(self.n_chunks):
+                self._wait_chunk(c, stop)
+                lo, hi = c * self.chunk, min((c + 1) * self.chunk, self.n_rows)
+                yield lo, slots[c % self.nslots][:hi - lo]
+                self.hdr[HDR_CONSUMED] = c + 1
+            self.decode_seconds = time.perf_counter() - self.t_started
+        finally:
+            del slots
+            self.close()
+
+    # ---- iteration: device batches --------------------------------------------------------------------------------------
+    def __iter__(self):
+        if not self.n_rows:
+            return
+        self.start()
+        dev = self.device
+        item_rows = self.bs * self.group
+        nb = -(-self.n_rows // item_rows)
+        nbuf = min(self.NBUF, nb)
+        shape = (min(item_rows, self.n_rows), self.h, self.w, 3)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        bufs = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        for t in bufs:
+            t.record_stream(side)
+        ring_np = np.frombuffer(self.ring, dtype=np.uint8)
+        ring_addr = ring_np.ctypes.data
+        with torch.cuda.device(dev):
+            try:
+                _lib.call("tise_host_register", ring_addr, self.ring_size)
+                self.registered = True
+            except _lib.TiseStatusError as e:                                 # not fatal: the copies become synchronous
+                print(f"[tise] png ring: hipHostRegister failed ({e}); host->device copies will be staged", file=sys.stderr)
+        ready = [torch.cuda.Event() for _ in range(nbuf)]
+        consumed = [torch.cuda.Event() for _ in range(nbuf)]
+        handed = [threading.Semaphore(1) for _ in range(nbuf)]
+        out = queue.Queue()
+        stop = threading.Event()
+        img_bytes, chunk = self.img_bytes, self.chunk
+        side_h = side.cuda_stream
+
+        def feeder():
+            try:
+                torch.cuda.set_device(dev)
+                inflight = deque()                                            # (event after the chunk's copies, chunk)
+                c = 0
+                for b in range(nb):
+                    k = b % nbuf
+                    handed[k].acquire()
+                    if stop.is_set():
+                        return
+                    consumed[k].synchronize()                                 # the consumer's stream is done with buffer k
+                    r0, r1 = b * item_rows, min((b + 1) * item_rows, self.n_rows)
+                    base = bufs[k].data_ptr()
+                    r = r0
+                    while r < r1:
+                        c = r // chunk
+                        if not self._wait_chunk(c, stop):
+                            return
+                        hi = min((c + 1) * chunk, r1, self.n_rows)
+                        src = ring_addr + ((c % self.nslots) * chunk + (r - c * chunk)) * img_bytes
+                        _lib.call("tise_memcpy_h2d_async", base + (r - r0) * img_bytes, src, (hi - r) * img_bytes, side_h)
+                        if hi == min((c + 1) * chunk, self.n_rows):           # the whole chunk is on its way: its slot frees when the copy lands
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                            inflight.append((ev, c))
+                            if c == self.n_chunks - 1:
+                                self.decode_seconds = time.perf_counter() - self.t_started
+                                if self.on_all_decoded is not None:
+                                    self.on_all_decoded()
+                        while inflight and (len(inflight) > self.nslots // 2 or inflight[0][0].query()):
+                            ev, cc = inflight.popleft()
+                            ev.synchronize()
+                            self.hdr[HDR_CONSUMED] = cc + 1
+                        r = hi
+                    ready[k].record(side)
+                    out.put((k, r1 - r0))
+                while inflight:
+                    ev, cc = inflight.popleft()
+                    ev.synchronize()
+                    self.hdr[HDR_CONSUMED] = cc + 1
+            except BaseException as e:                                        # noqa: BLE001 -- re-raised in the consumer
+                out.put(e)
+
+        th = threading.Thread(target=feeder, name="tise-png-feeder", daemon=True)
+        th.start()
+        try:
+            for b in range(nb):
+                item = out.get()
+                if isinstance(item, BaseException):
+                    raise item
+                k, rows = item
+                cur = torch.cuda.current_stream(dev)
+                if b == 1:
+                    self.first_item_rows = item_rows
+                    self.first_item_event = torch.cuda.Event(enable_timing=True)
+                    self.first_item_event.record(cur)
+                cur.wait_event(ready[k])
+                yield bufs[k][:rows]
+                consumed[k].record(torch.cuda.current_stream(dev))
+                handed[k].release()
+            if self.first_item_event is not None:
+                self.last_item_event = torch.cuda.Event(enable_timing=True)
+                self.last_item_event.record(torch.cuda.current_stream(dev))
+        finally:
+            stop.set()
+            for h in handed:
+                h.release()
+            th.join()
+            side.synchronize()
+            self.close()
+
+    def steady_seconds(self):
+        """Device time between the end of the first and of the last device batch's work (None with fewer than two)."""
+        if self.first_item_event is None or self.last_item_event is None:
+            return None
+        self.last_item_event.synchronize()
+        return self.first_item_event.elapsed_time(self.last_item_event) * 1e-3
+
+    def close(self):
+        if self.ctl is not None:
+            try:
+                self.hdr[HDR_STOP] = 1
+            except (ValueError, TypeError):
+                pass
+        for p in self.procs:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        self.procs = []
+        if self.registered:
+            try:
+                addr = np.frombuffer(self.ring, dtype=np.uint8).ctypes.data
+                with torch.cuda.device(self.device):
+                    _lib.call("tise_host_unregister", addr)
+            except Exception:                                                 # noqa: BLE001
+                pass
+            self.registered = False
+        self.hdr = self.done = None
+        for m in (self.ring, self.ctl):
+            if m is not None:
+                try:
+                    m.close()
+                except (BufferError, ValueError):                             # a numpy view still alive: the fd close below frees it with the process
+                    pass
+        self.ring = self.ctl = None
+        for fd in (self.ring_fd, self.ctl_fd):
+            if fd >= 0:
+                os.close(fd)
+        self.ring_fd = self.ctl_fd = -1
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                                     # noqa: BLE001
+            pass

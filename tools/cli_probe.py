@@ -29,7 +29,7 @@ if __name__ == "__main__":
     root = tempfile.mkdtemp(prefix="tise_cli_")
     d = os.path.join(root, "gen"); os.makedirs(d)
     t0 = time.perf_counter()
-    with ProcessPoolExecutor(32) as ex:
+    with ProcessPoolExecutor(min(96, os.cpu_count() or 8)) as ex:
         list(ex.map(write, [(d, i) for i in range(N)], chunksize=64))
     print(f"wrote {N} PNGs in {time.perf_counter() - t0:.1f} s ({sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d)) / N / 1e3:.0f} KB each)", flush=True)
     ref = os.path.join(root, "ref.npz")
@@ -37,13 +37,20 @@ if __name__ == "__main__":
     base = [sys.executable, "-m", "tise_toolbox_amd.fid_score", "--synthetic-weights", "--path1", ref, "--path2", d,
             "--saved_file", os.path.join(root, "out.txt")]
     subprocess.run([sys.executable, "-m", "tise_toolbox_amd.fid_score", "--synthetic-weights", "--path2", d, "--batch-size", "50",
-                    "--save-stats", ref, "--num-workers", "32"], check=True, capture_output=True, env=env)
-    for bs, nw in ((50, 8), (50, 32), (500, 32), (500, 64)):
+                    "--save-stats", ref], check=True, capture_output=True, env=env)
+    env["TISE_TIMING"] = "1"
+    from tise_toolbox_amd import png_ring
+    print(f"host: {os.cpu_count()} hardware threads, usable (affinity and cgroup quota) {png_ring.usable_cpus()}; auto workers {png_ring.auto_workers()}", flush=True)
+    # round 5: the shared-ring PNG feed (png_ring.py) at 32 / 64 / 128 decode processes and auto, against the DataLoader feed
+    for bs, nw, feed in ((50, 8, "ring"), (50, 12, "ring"), (50, 14, "ring"), (50, 16, "ring"), (50, 20, "ring"), (50, 32, "ring"), (50, 128, "ring"),
+                         (50, 0, "ring"), (50, 0, "ring"), (50, 16, "dataloader"), (50, 32, "dataloader")):
         t0 = time.perf_counter()
-        r = subprocess.run(base + ["--batch-size", str(bs), "--num-workers", str(nw)], capture_output=True, text=True, env=env)
+        r = subprocess.run(base + ["--batch-size", str(bs), "--num-workers", str(nw), "--png-feed", feed], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
-        feed = [ln for ln in r.stderr.splitlines() if "png feed" in ln]
-        print(f"batch {bs:3d} workers {nw:2d}: {dt:6.1f} s wall for {N} images incl. start-up -> {N / dt:7.0f} images/s   {r.stdout.strip().splitlines()[-1] if r.stdout else r.stderr[-200:]}\n    {feed[-1] if feed else ''}", flush=True)
+        feedl = [ln for ln in r.stderr.splitlines() if "png feed" in ln]
+        timing = " | ".join(ln.replace("[tise timing] ", "") for ln in r.stderr.splitlines() if "[tise timing]" in ln)
+        print(f"{feed:10s} batch {bs:3d} workers {nw:3d}: {dt:6.2f} s wall for {N} images incl. start-up -> {N / dt:7.0f} images/s   "
+              f"{r.stdout.strip().splitlines()[-1] if r.stdout else r.stderr[-300:]}\n    {feedl[-1] if feedl else ''}\n    {timing}", flush=True)
     for bs, label in ((500, "first run (builds the cache, 32 workers)"), (500, "second run (from the cache)"), (500, "third run (from the cache)"),
                       (50, "README batch size, from the cache"), (50, "README batch size, from the cache, again")):
         t0 = time.perf_counter()
