@@ -145,8 +145,9 @@ def cpu_reference_pass(gen_u8, ref_u8, n_job, dims=2048, workers=8):
     from tests import _cases
     # torch's CPU convolutions are fastest well below the host's thread count (this pool's 128-thread hosts:
     # 94 / 52 / 35 / 30 ms per image at 128 / 64 / 32 / 16 threads, batch 50): the baseline gets the better setting
+    from tise_toolbox_amd.hostinfo import usable_cpus
     all_threads = torch.get_num_threads()
-    threads = min(32, all_threads)
+    threads = min(32, all_threads, usable_cpus())            # the cgroup's CPU quota counts too (16 CPUs on the GPU boxes)
     torch.set_num_threads(threads)
     sd = {k: v.float() for k, v in build_inception3(seed=0).state_dict().items()}
     n = gen_u8.shape[0]
@@ -222,7 +223,7 @@ def cpu_reference_pass(gen_u8, ref_u8, n_job, dims=2048, workers=8):
                    f"{t_is:.3f} s; job time = N x max(decode, forward) + cov + sqrtm + IS (loader overlapped as in the reference)"),
         "stages": {"decode_resize_ms_per_img": per_img_dec * 1e3, "forward_ms_per_img": per_img_fwd * 1e3,
                    "cov_s": t_cov, "frechet_s": t_fd, "is_reduce_s": t_is, "repeats": {"decode": r_dec, "forward": r_fwd}},
-        "host_cpus": os.cpu_count(), "loader_workers": workers,
+        "host_cpus": os.cpu_count(), "host_usable_cpus": usable_cpus(), "loader_workers": workers,
     }
     return base, out
 

@@ -90,6 +90,11 @@ int tise_stats_update(tise_stats_t* h, const float* feats_dev, int64_t rows, int
  * _cov: S += X^T X (fp64 MFMA)   _sum: s += column sums, n += rows (column tiles x 8 row slices, fixed-order merge) */
 int tise_stats_update_cov(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream);
 int tise_stats_update_sum(tise_stats_t* h, const float* feats_dev, int64_t rows, int64_t ld, void* stream);
+/* GROUPED accumulation (per-class O-FID, BASELINE configs[4]): feats_dev holds rows sorted by group; group g = rows
+ * [row_offsets[g], row_offsets[g + 1]) (HOST array of n_groups + 1 offsets) is folded into handles[g] -- all groups in ONE
+ * launch (grid.y = group), so every class's S is read-modify-written once per call instead of once per class and batch. */
+int tise_stats_update_grouped(tise_stats_t* const* handles, int n_groups, const float* feats_dev, const int64_t* row_offsets,
+                              int64_t ld, void* stream);
 /* the contiguous fp64 buffer [S (d*d, upper triangle by 64x64 tile) | s (d) | n | pad] that a
  * data-parallel caller hands to RCCL / torch.distributed.all_reduce(SUM). */
 int tise_stats_buffer(tise_stats_t* h, double** buf_dev, size_t* n_doubles);
@@ -227,6 +232,9 @@ int tise_stem_conv3x3s2_split_u8_mfma(const uint8_t* x_dev, const float* lut_dev
                                       const float* scale_dev, const float* bias_dev, void* out_dev, void* stream);
 /* Global average of a split tensor (n, hw, C), C % 32 == 0 -> fp32 (n, C): AdaptiveAvgPool2d((1,1)) of the last block. */
 int tise_split_mean_nhwc(const void* x_dev, int n, int hw, int C, float* out_dev, void* stream);
+/* the same mean, also written as a split row (n, 2C) fp16 (layout above): the operand of the classifier layer, which runs
+ * as a 1x1 split-precision convolution on it (the IS* logits: pool3 x W, inception_score_star_coco.py:104-105) */
+int tise_split_mean_both_nhwc(const void* x_dev, int n, int hw, int C, float* out_dev, void* out_split_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (a11, section 8 f3) Top-1 text retrieval for R-precision and the 2-way softmax test of PA.

@@ -11,6 +11,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The GPU boxes show 256 hardware threads and grant the container 16 CPUs of cgroup quota: a 256-thread OpenMP team under
+    # that quota is throttled in bursts (the CPU oracle's forward, and every rank subprocess's start-up, ran several times
+    # slower than they need to).  Set before torch is imported, inherited by the rank subprocesses.
+    from tise_toolbox_amd.hostinfo import usable_cpus
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
 
 
 def pytest_collection_modifyitems(config, items):

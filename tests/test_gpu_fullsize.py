@@ -124,7 +124,11 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu(cuda_device):
     assert two.returncode == 0, two.stderr[-2000:]
     d2 = json.loads(two.stdout.strip().split("\n")[-1])
     assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["steps"] == 4
-    assert d2["config"]["collective"] == {"world_size": 2, "backend": "gloo", "launcher": "self"}
+    c2, c1 = d2["config"]["collective"], d1["config"]["collective"]
+    assert (c2["world_size"], c2["backend"], c2["launcher"], c2["forced_one_rank_group"]) == (2, "gloo", "self", False)
+    # the one-process run brings up a ONE-rank RCCL group so that the job's all-reduces really execute (round 5)
+    assert (c1["world_size"], c1["backend"], c1["forced_one_rank_group"]) == (1, "nccl", True), c1
+    assert d1["reference_side"]["images"] == 2200 and d2["reference_side"]["images_this_rank"] == 1100
     assert d1["config"]["step_images"] == 500 and "resident in HBM" in d1["config"]["workload"]
     assert d2["config"]["images_total"] == d1["config"]["images_total"] == 2000 and d2["config"]["images_per_gpu"] == 1000
     # 2 000 images < d = 2 048: rank-deficient covariances, where the fp64 summation order of S -- one 2 000-image device batch

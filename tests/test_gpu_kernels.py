@@ -1223,3 +1223,46 @@ def test_split_trunk_with_uncalibrated_checkpoint_matches_fp32_trunk(dev, tmp_pa
     assert err_o <= 2e-4 * o.abs().max().item()
     lo = inception_oracle.logits_from_pool3(sd_cpu, inception_oracle.inception_forward(sd_cpu, xin)[3], bias=False)   # coco head, :104-105
     assert (la[:8].cpu() - lo).abs().max().item() <= 1e-3 * max(1.0, lo.abs().max().item())
+
+
+def test_classifier_layer_runs_as_a_split_convolution(cuda_device, monkeypatch):
+    """Round 5: the IS* logits = pool3 x W (inception_score_star_coco.py:104-105) without a library GEMM: the global-mean
+    kernel also writes pool3 as a split row (tise_split_mean_both_nhwc, bit-identical fp32 output, exact split of it) and the
+    classifier layer runs as a 1x1 split-precision convolution with raw fp32 out (SplitTrunk.fc_logits).  Against an fp64
+    product of the same rows: <= 2e-6 of the logit scale (the torch / hipBLASLt fp32 GEMM it replaces: same class); the bias of
+    the bird / ois rules is added afterwards; TISE_FC=torch keeps the library GEMM and the two engines agree."""
+    import ctypes
+    from tise_toolbox_amd import _lib, conv_split as cs
+    from tise_toolbox_amd.engine import RealismEngine
+    dev = cuda_device
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = cs.split((torch.rand((37, 8, 8, 2048), generator=g) * torch.rand((1, 1, 1, 2048), generator=g) * 3).to(dev))
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    f0 = torch.empty((37, 2048), dtype=torch.float32, device=dev)
+    f1 = torch.empty_like(f0)
+    fs = torch.empty((37, 1, 1, 4096), dtype=torch.float16, device=dev)
+    _lib.call("tise_split_mean_nhwc", ctypes.c_void_p(a.data_ptr()), 37, 64, 2048, ctypes.c_void_p(f0.data_ptr()), st)
+    _lib.call("tise_split_mean_both_nhwc", ctypes.c_void_p(a.data_ptr()), 37, 64, 2048, ctypes.c_void_p(f1.data_ptr()),
+              ctypes.c_void_p(fs.data_ptr()), st)
+    assert torch.equal(f0, f1)
+    assert torch.equal(fs.view(37, 4096), cs.split(f1))                  # the split row is exactly split(fp32 mean)
+    imgs = torch.from_numpy(_cases.smooth_images(24, 256, 256, seed=12)).to(dev)
+    eng = RealismEngine(dims=2048, seed=0, with_logits=True)
+    assert eng.fused.sfc is not None
+    feats, logits = eng.features_from_u8(imgs)                           # coco rule: no bias
+    w = eng.model.fc.weight.detach().double()
+    want = feats.double() @ w.t()
+    scale = float(want.abs().max())
+    err = float((logits.double() - want).abs().max()) / scale
+    lib = torch.nn.functional.linear(feats, eng.model.fc.weight)
+    err_lib = float((lib.double() - want).abs().max()) / scale
+    print(f"classifier layer as split convolution: error {err:.2e} of the logit scale (library fp32 GEMM {err_lib:.2e})")
+    assert err <= 2e-6
+    eng.begin(n_total=24, rule="bird", temperature=0.5980541706085205)
+    lb = eng.features_from_u8(imgs)[1]
+    assert float((lb.double() - (want + eng.model.fc.bias.double())).abs().max()) / scale <= 2e-6
+    monkeypatch.setenv("TISE_FC", "torch")
+    ref = RealismEngine(dims=2048, seed=0, with_logits=True)
+    assert ref.fused.sfc is None
+    f2, l2 = ref.features_from_u8(imgs)
+    assert torch.equal(f2, feats) and float((l2 - logits).abs().max()) / scale <= 3e-6

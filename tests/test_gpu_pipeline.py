@@ -333,9 +333,11 @@ def _run_ranks(world, argv, tmp_path, module="tise_toolbox_amd.fid_score", timeo
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     procs = []
+    from tise_toolbox_amd.hostinfo import usable_cpus
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), TISE_DIST_BACKEND="gloo", PYTHONPATH=root)
+                   MASTER_PORT=str(port), TISE_DIST_BACKEND="gloo", PYTHONPATH=root,
+                   OMP_NUM_THREADS=str(max(1, usable_cpus() // world)))
         procs.append(subprocess.Popen([sys.executable, "-m", module] + argv, env=env, cwd=root,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -698,3 +700,110 @@ def test_png_ring_feed_is_bit_identical_to_the_dataloader_feed(setup, tmp_path, 
     rag_ring = fid_score.main(base + ["--png-feed", "ring", "--num-workers", "4"])
     assert "falling back to the DataLoader path" in capfd.readouterr().err
     assert rag_ring == rag_dl
+
+
+COCO80 = ("person,bicycle,car,motorcycle,airplane,bus,train,truck,boat,traffic light,fire hydrant,stop sign,parking meter,bench,bird,cat,"
+          "dog,horse,sheep,cow,elephant,bear,zebra,giraffe,backpack,umbrella,handbag,tie,suitcase,frisbee,skis,snowboard,sports ball,"
+          "kite,baseball bat,baseball glove,skateboard,surfboard,tennis racket,bottle,wine glass,cup,fork,knife,spoon,bowl,banana,apple,"
+          "sandwich,orange,broccoli,carrot,hot dog,pizza,donut,cake,chair,couch,potted plant,bed,dining table,toilet,tv,laptop,mouse,"
+          "remote,keyboard,cell phone,microwave,oven,toaster,sink,refrigerator,book,clock,vase,scissors,teddy bear,hair drier,"
+          "toothbrush").split(",")
+
+
+def test_per_class_o_fid_at_80_classes(setup, tmp_path, monkeypatch):
+    """BASELINE configs[4] AT ITS SIZE: 80 classes x 40-48 ragged crops per side through
+    ``fid_score --per-class``.  (a) every class against the plain single-class path applied to the very feature rows the CLI
+    produced (non-grouped covariance kernel, one accumulator, calculate_frechet_distance): <= 1e-9 -- the grouped launch,
+    the class sort and the sharded solves change nothing; (b) a sampled class against the plain CLI run on a directory
+    holding only that class: <= 1e-6; (c) five sampled classes against the CPU oracle (PIL-exact resize, CPU fp32
+    InceptionV3, np.cov, scipy sqrtm): <= 1e-3; (d) two ranks on this GPU reproduce the per-class values; wall times printed."""
+    import time
+    from PIL import Image
+    from tise_toolbox_amd import device, fid_score, img_data
+    from tise_toolbox_amd.inception import InceptionV3, build_inception3
+    assert len(COCO80) == 80 and "traffic light" in COCO80 and "hair drier" in COCO80
+    sampled_cli, sampled_oracle = ["traffic light"], ["person", "dog", "traffic light", "pizza", "toothbrush"]
+    k = 0
+    n_crops = {}
+    for side in ("gen", "ref"):
+        os.makedirs(tmp_path / side)
+        per_class = {c: 40 + (i * (3 if side == "gen" else 5)) % 9 for i, c in enumerate(COCO80)}
+        n_crops[side] = sum(per_class.values())
+        for c in sampled_cli + sampled_oracle:
+            os.makedirs(tmp_path / f"{side}_{c}", exist_ok=True)
+        for j in range(max(per_class.values())):                          # classes interleaved in the directory
+            for i, c in enumerate(COCO80):
+                if j >= per_class[c]:
+                    continue
+                src = setup[side][(k + 3 * i) % len(setup[side])]
+                y0, x0 = (7 * i + 3 * j) % 60, (11 * i + 5 * j) % 60
+                im = src[y0:y0 + 48 + 9 * ((k + i) % 11), x0:x0 + 40 + 13 * ((k + j) % 9)]
+                name = f"im_{k}_{c}_{k}.png"
+                Image.fromarray(im).save(tmp_path / side / name)
+                if c in sampled_cli or c in sampled_oracle:
+                    Image.fromarray(im).save(tmp_path / f"{side}_{c}" / name)
+                k += 1
+    captured = []
+    orig = device.stats_update_grouped
+
+    def spy(accs, feats_sorted, offsets):
+        captured.append((feats_sorted.clone(), [int(o) for o in offsets]))
+        return orig(accs, feats_sorted, offsets)
+    monkeypatch.setattr(device, "stats_update_grouped", spy)
+    argv = ["--batch-size", "50", "--path1", str(tmp_path / "ref"), "--path2", str(tmp_path / "gen"), "--label", "O-FID",
+            "--num-classes", "80", "--per-class", "--synthetic-weights"]
+    t0 = time.perf_counter()
+    per = fid_score.main(argv + ["--saved_file", str(tmp_path / "pc.txt")])
+    t_cli = time.perf_counter() - t0
+    monkeypatch.setattr(device, "stats_update_grouped", orig)
+    print(f"per-class O-FID, 80 classes, {n_crops['ref']} + {n_crops['gen']} ragged crops: {t_cli:.2f} s in-process (model build included)")
+    assert list(per) == sorted(COCO80) and len(captured) == 2             # ONE grouped launch per directory
+    # (a) the plain single-class path on the CLI's own feature rows
+    names = sorted(COCO80)
+    (f_ref, o_ref), (f_gen, o_gen) = captured
+    worst = 0.0
+    for i, c in enumerate(names):
+        a1, a2 = device.StatsAccumulator(2048, f_ref.device), device.StatsAccumulator(2048, f_ref.device)
+        a1.update(f_ref[o_ref[i]:o_ref[i + 1]].contiguous())
+        a2.update(f_gen[o_gen[i]:o_gen[i + 1]].contiguous())
+        want = fid_score.calculate_frechet_distance(*a1.finalize(), *a2.finalize())
+        worst = max(worst, abs(per[c] - want) / max(1.0, abs(want)))
+        a1.close(); a2.close()
+    print("80 classes, grouped launch vs single-class path on the same rows: worst relative difference", worst)
+    assert worst <= 1e-9
+    assert len(set(round(v, 6) for v in per.values())) > 70                # the classes really differ
+    # (b) the plain CLI on a directory holding only that class
+    model = InceptionV3([3], num_classes=80, seed=0).cuda()
+    for c in sampled_cli:
+        n1 = len(img_data.get_filenames(str(tmp_path / f"ref_{c}")))
+        n2 = len(img_data.get_filenames(str(tmp_path / f"gen_{c}")))
+        m1, s1 = fid_score._compute_statistics_of_path(str(tmp_path / f"ref_{c}"), model, n1, 2048, True, 0)
+        m2, s2 = fid_score._compute_statistics_of_path(str(tmp_path / f"gen_{c}"), model, n2, 2048, True, 0)
+        want = fid_score.calculate_frechet_distance(m1, s1, m2, s2)
+        assert abs(per[c] - want) <= 1e-6 * max(1.0, abs(want)), (c, per[c], want)
+    # (d) two ranks on this GPU (classes owned by rank i mod 2, reduce to the owner, solve there, all-reduce of the scalars)
+    t0 = time.perf_counter()
+    res = _run_ranks(2, argv + ["--saved_file", str(tmp_path / "pc2.txt")], tmp_path)
+    print(f"2 ranks on one GPU: {time.perf_counter() - t0:.1f} s wall incl. two process start-ups")
+    assert all(rc == 0 for rc, _ in res), res
+    got = {ln[len("O-FID["):ln.index("]")]: float(ln.split("]: ")[1].split()[0])
+           for ln in (tmp_path / "pc2.txt").read_text().splitlines() if ln.startswith("O-FID[")}
+    assert list(got) == list(per)
+    for c in per:
+        assert abs(got[c] - per[c]) <= 1e-9 * max(1.0, abs(per[c])) + 1e-5, (c, got[c], per[c])
+    # (c) the CPU oracle on five classes
+    sd80 = {k_: v.float() for k_, v in build_inception3(num_classes=80, seed=0).state_dict().items()}
+
+    def oracle_stats(root):
+        files = img_data.get_filenames(str(root))
+        x = np.stack([resize_oracle.to_tensor(resize_oracle.resize_bilinear_u8(np.asarray(Image.open(f).convert("RGB")), 299, 299))
+                      for f in files])
+        act = np.concatenate([inception_oracle.inception_forward(sd80, torch.from_numpy(x[i:i + 16]))[3].flatten(1).numpy()
+                              for i in range(0, len(x), 16)]).astype(np.float64)
+        return fid_oracle.calculate_activation_statistics(act)
+    t0 = time.perf_counter()
+    for c in sampled_oracle:
+        want = fid_oracle.calculate_frechet_distance(*oracle_stats(tmp_path / f"ref_{c}"), *oracle_stats(tmp_path / f"gen_{c}"))
+        print("per-class O-FID", c, "device", per[c], "oracle", want)
+        assert abs(per[c] - want) <= 1e-3, (c, per[c], want)
+    print(f"CPU oracle on five classes: {time.perf_counter() - t0:.1f} s")

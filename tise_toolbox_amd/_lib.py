@@ -58,6 +58,7 @@ SIGNATURES = {
     "tise_stats_update": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "tise_stats_update_cov": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "tise_stats_update_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "tise_stats_update_grouped": (c_int, [POINTER(c_void_p), c_int, c_void_p, POINTER(c_int64), c_int64, c_void_p]),
     "tise_stats_buffer": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_size_t)]),
     "tise_stats_finalize": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "tise_frechet_create": (c_int, [c_int, POINTER(c_void_p)]),
@@ -88,6 +89,7 @@ SIGNATURES = {
     "tise_stem_conv3x3s2_split_u8_mfma": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                                    c_void_p, c_void_p]),
     "tise_split_mean_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "tise_split_mean_both_nhwc": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "tise_conv_split_f16": (c_int, [c_void_p, c_int, c_void_p]),
     "tise_split_overflow_check": (c_int, [POINTER(c_int), c_void_p]),
     "tise_gemm_f64": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,

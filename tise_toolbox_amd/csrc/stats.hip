@@ -67,10 +67,9 @@ __global__ __launch_bounds__(256) void syrk_f32_upper_kernel(const float* __rest
 // per 1000 x 2048 batch = 0.11 TB/s).  Fixed order: thread (column c, phase p) adds rows p, p+4, ... of every slab.
 #define SYF_P 80
 template <bool COLSUM>
-__global__ __launch_bounds__(256, 2) void syrk_f32_upper_bk64_kernel(const float* __restrict__ X, int64_t ld, int rows,
-                                                                     int d, int tiles, double* __restrict__ S,
-                                                                     double* __restrict__ s, double* __restrict__ n) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * 64 * SYF_P];
+__device__ __forceinline__ void syrk_f32_upper_bk64_body(float* lds, const float* __restrict__ X, int64_t ld, int rows,
+                                                         int d, int tiles, double* __restrict__ S,
+                                                         double* __restrict__ s, double* __restrict__ n) {
     float* As = lds;
     float* Bs = lds + 64 * SYF_P;
     const int nwg = tiles * (tiles + 1) / 2;
@@ -139,6 +138,36 @@ __global__ __launch_bounds__(256, 2) void syrk_f32_upper_bk64_kernel(const float
         if (wave == 0) s[tm * 64 + lane] += ((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane];
         if (tm == 0 && tid == 0) *n += (double)rows;
     }
+}
+
+template <bool COLSUM>
+__global__ __launch_bounds__(256, 2) void syrk_f32_upper_bk64_kernel(const float* __restrict__ X, int64_t ld, int rows,
+                                                                     int d, int tiles, double* __restrict__ S,
+                                                                     double* __restrict__ s, double* __restrict__ n) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 64 * SYF_P];
+    syrk_f32_upper_bk64_body<COLSUM>(lds, X, ld, rows, d, tiles, S, s, n);
+}
+
+// GROUPED form (per-class O-FID, BASELINE configs[4]): the rows of X are sorted by group, group g = rows
+// [row0[g], row0[g] + rows[g]) and accumulates into ITS OWN statistics buffer; blockIdx.y = group, blockIdx.x = tile.  One
+// launch folds a whole directory's features into all 80 classes' {n, s, S} -- each S tile is read-modify-written ONCE per
+// directory (round 4: one index_select + one 528-workgroup launch per class and DEVICE BATCH, ~5.4 GB of accumulator traffic
+// per batch for 8 MB of features).  The table travels as a kernel argument (2 KB).
+#define SYRK_MAX_GROUPS 128
+struct SyrkGroups {
+    double* buf[SYRK_MAX_GROUPS];
+    int row0[SYRK_MAX_GROUPS];
+    int rows[SYRK_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256, 2) void syrk_f32_upper_bk64_grouped_kernel(const float* __restrict__ X, int64_t ld, int d,
+                                                                             int tiles, const SyrkGroups g) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 64 * SYF_P];
+    const int grp = blockIdx.y;
+    const int rows = g.rows[grp];
+    if (rows <= 0) return;                                    // workgroup-uniform
+    double* buf = g.buf[grp];
+    double* s = buf + (size_t)d * d;
+    syrk_f32_upper_bk64_body<true>(lds, X + (int64_t)g.row0[grp] * ld, ld, rows, d, tiles, buf, s, s + d);
 }
 
 // Stand-alone column sums (shapes the fused kernel does not serve, and tise_stats_update_sum).  Grid = column tiles x
@@ -296,6 +325,43 @@ int tise_stats_update(tise_stats_t* h, const float* feats_dev, int64_t rows, int
     rc = tise_stats_update_cov(h, feats_dev, rows, ld, stream);
     if (rc != TISE_OK) return rc;
     return tise_stats_update_sum(h, feats_dev, rows, ld, stream);
+}
+
+int tise_stats_update_grouped(tise_stats_t* const* handles, int n_groups, const float* feats_dev, const int64_t* row_offsets,
+                              int64_t ld, void* stream) {
+    if (!handles || n_groups < 0 || !row_offsets || (!feats_dev && n_groups > 0 && row_offsets[n_groups] > 0)) return TISE_ERR_INVALID_ARG;
+    if (n_groups == 0) return TISE_OK;
+    const int d = handles[0] ? handles[0]->d : 0;
+    for (int g = 0; g < n_groups; ++g) {
+        if (!handles[g] || handles[g]->d != d || row_offsets[g + 1] < row_offsets[g] || row_offsets[g] < 0 ||
+            row_offsets[g + 1] > ((int64_t)1 << 30))
+            return TISE_ERR_INVALID_ARG;
+    }
+    if (ld < d) return TISE_ERR_INVALID_ARG;
+    const bool fast = (d % 64 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(feats_dev) & 15) == 0);
+    if (!fast) {                                              // shapes the tiled kernel does not serve: group by group
+        for (int g = 0; g < n_groups; ++g) {
+            const int rc = tise_stats_update(handles[g], feats_dev + row_offsets[g] * ld, row_offsets[g + 1] - row_offsets[g], ld, stream);
+            if (rc != TISE_OK) return rc;
+        }
+        return TISE_OK;
+    }
+    const int tiles = handles[0]->tiles;
+    const int nwg = tiles * (tiles + 1) / 2;
+    for (int g0 = 0; g0 < n_groups; g0 += SYRK_MAX_GROUPS) {
+        const int ng = n_groups - g0 < SYRK_MAX_GROUPS ? n_groups - g0 : SYRK_MAX_GROUPS;
+        SyrkGroups tab;
+        for (int g = 0; g < SYRK_MAX_GROUPS; ++g) {
+            const bool on = g < ng;
+            tab.buf[g] = on ? handles[g0 + g]->buf : nullptr;
+            tab.row0[g] = on ? (int)row_offsets[g0 + g] : 0;
+            tab.rows[g] = on ? (int)(row_offsets[g0 + g + 1] - row_offsets[g0 + g]) : 0;
+        }
+        hipLaunchKernelGGL(syrk_f32_upper_bk64_grouped_kernel, dim3(nwg, ng), dim3(256), 0, (hipStream_t)stream, feats_dev, ld, d,
+                           tiles, tab);
+        TISE_LAUNCH_CHECK();
+    }
+    return TISE_OK;
 }
 
 int tise_stats_buffer(tise_stats_t* h, double** buf_dev, size_t* n_doubles) {

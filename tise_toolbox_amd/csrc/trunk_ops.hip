@@ -437,8 +437,11 @@ __global__ __launch_bounds__(256) void stem_conv3x3s2_split_u8_kernel(const uint
 
 // split tensor (N, HW, C), C % 32 == 0 -> fp32 (N, C) mean over the HW positions (AdaptiveAvgPool2d((1,1)) of the
 // last block): thread = (image, 8 channels), fixed summation order.
+// SPLIT_OUT: the mean is also written as a split row (N, 2C) -- the operand of the classifier layer, which runs as a 1x1
+// split-precision convolution on it (trunk.py fc_logits: the last library GEMM of the image loop, round 5).
+template <bool SPLIT_OUT>
 __global__ __launch_bounds__(256) void split_mean_kernel(const _Float16* __restrict__ x, int N, int HW,
-                                                         int C8, float* __restrict__ out) {
+                                                         int C8, float* __restrict__ out, _Float16* __restrict__ out_split) {
     const int C = C8 * 8;
     const int c8 = blockIdx.x * 256 + threadIdx.x;            // one (image = blockIdx.y, 8 channels) element per thread
     if (c8 >= C8) return;
@@ -455,8 +458,25 @@ __global__ __launch_bounds__(256) void split_mean_kernel(const _Float16* __restr
         for (int i = 0; i < 8; ++i) acc[i] += (float)vh[i] + (float)vl[i] * (1.f / 2048.f);
     }
     float* d = out + n * (int64_t)C + c8 * 8;
+    half8v oh, ol;
+    float vmax = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) d[i] = acc[i] / (float)HW;
+    for (int i = 0; i < 8; ++i) {
+        const float v = acc[i] / (float)HW;
+        d[i] = v;
+        if (SPLIT_OUT) {
+            const _Float16 h = (_Float16)v;
+            oh[i] = h;
+            ol[i] = (_Float16)((v - (float)h) * 2048.f);
+            vmax = (fabsf(v) <= vmax) ? vmax : fabsf(v);          // a NaN lands in vmax (the comparison fails) and raises the flag
+        }
+    }
+    if (SPLIT_OUT) {
+        _Float16* q2 = out_split + n * (int64_t)C * 2 + tise_ilv_off(c8 * 8, C);
+        *reinterpret_cast<half8v*>(q2) = oh;
+        *reinterpret_cast<half8v*>(q2 + 32) = ol;
+        tise_flag_split_overflow(vmax);
+    }
 }
 
 inline int grid_for(int64_t total) {
@@ -578,8 +598,18 @@ int tise_split_mean_nhwc(const void* x_dev, int n, int hw, int C, float* out_dev
     if (!x_dev || !out_dev || n < 0 || hw <= 0 || C <= 0 || C % 32) return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
     if (n > 65535) return TISE_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(split_mean_kernel, dim3((unsigned)((C / 8 + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const _Float16*>(x_dev), n, hw, C / 8, out_dev);
+    hipLaunchKernelGGL(split_mean_kernel<false>, dim3((unsigned)((C / 8 + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const _Float16*>(x_dev), n, hw, C / 8, out_dev, (_Float16*)nullptr);
+    TISE_LAUNCH_CHECK();
+    return TISE_OK;
+}
+
+int tise_split_mean_both_nhwc(const void* x_dev, int n, int hw, int C, float* out_dev, void* out_split_dev, void* stream) {
+    if (!x_dev || !out_dev || !out_split_dev || n < 0 || hw <= 0 || C <= 0 || C % 32) return TISE_ERR_INVALID_ARG;
+    if (n == 0) return TISE_OK;
+    if (n > 65535) return TISE_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(split_mean_kernel<true>, dim3((unsigned)((C / 8 + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const _Float16*>(x_dev), n, hw, C / 8, out_dev, reinterpret_cast<_Float16*>(out_split_dev));
     TISE_LAUNCH_CHECK();
     return TISE_OK;
 }

@@ -185,6 +185,25 @@ class StatsAccumulator:
         return mu, sigma
 
 
+def stats_update_grouped(accs, feats_sorted, offsets):
+    """ONE launch: rows [offsets[g], offsets[g + 1]) of ``feats_sorted`` (fp32 CUDA (rows, d), sorted by group) are folded into
+    ``accs[g]`` (StatsAccumulator) for every g (tise_stats_update_grouped)."""
+    _require_cuda(feats_sorted)
+    ng = len(accs)
+    if ng == 0:
+        return
+    if feats_sorted.dim() != 2 or feats_sorted.dtype != torch.float32 or feats_sorted.shape[1] != accs[0].dims:
+        raise ValueError("feats_sorted must be (rows, dims) float32")
+    if feats_sorted.stride(1) != 1:
+        feats_sorted = feats_sorted.contiguous()
+    offs = [int(o) for o in offsets]
+    if len(offs) != ng + 1 or offs[0] != 0 or offs[-1] != feats_sorted.shape[0]:
+        raise ValueError("offsets must run from 0 to the row count, one more entry than groups")
+    handles = (ctypes.c_void_p * ng)(*[a._h for a in accs])
+    arr = (ctypes.c_int64 * (ng + 1))(*offs)
+    _lib.call("tise_stats_update_grouped", handles, ng, _ptr(feats_sorted), arr, feats_sorted.stride(0), _stream())
+
+
 def _wrap_device_doubles(ptr, n, device, owner=None):
     """Zero-copy torch view of `n` doubles at device address `ptr` (__cuda_array_interface__)."""
     class _Holder:

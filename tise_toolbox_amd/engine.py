@@ -36,6 +36,8 @@ T_OIS = 2.1737587451934814     # object_fidelity/O-IS/object_centric_inception_s
 
 
 def require_gpu():
+    from .hostinfo import limit_torch_threads
+    limit_torch_threads()                                   # 256 visible hardware threads, 16 CPUs of cgroup quota: see hostinfo
     _lib.load()
     if not torch.cuda.is_available():
         raise _lib.TiseLibraryError(
@@ -113,8 +115,17 @@ class RealismEngine:
     def _trunk_u8(self, u8):
         pred = self.fused.forward_u8(u8, self.lut_dev)
         feats = pred.reshape(pred.shape[0], -1)
-        logits = self.model.logits(feats, bias=self.fc_bias) if self.with_logits else None
-        return feats, logits
+        return feats, self._logits(feats)
+
+    def _logits(self, feats):
+        """IS* logits of the pool3 rows just computed: the all-HIP trunk runs the classifier layer as a 1x1 split-precision
+        convolution on them (SplitTrunk.fc_logits); the MIOpen trunk and user-supplied models use the module's own fc."""
+        if not self.with_logits:
+            return None
+        if getattr(self.fused, "sfc", None) is not None and getattr(self.fused, "_feat_split", None) is not None \
+                and self.fused._feat_split.shape[0] == feats.shape[0]:
+            return self.fused.fc_logits(feats.shape[0], bias=self.fc_bias)
+        return self.model.logits(feats, bias=self.fc_bias)
 
     @torch.no_grad()
     def features_from_u8(self, batch_u8):
@@ -189,8 +200,8 @@ class RealismEngine:
         feats = pred.reshape(pred.shape[0], -1)
         if feats.stride(1) != 1:
             feats = feats.contiguous()
-        logits = self.model.logits(feats, bias=self.fc_bias) if self.with_logits else None
-        return feats, logits
+        used_fused = self.fused is not None and prenormalized
+        return feats, (self._logits(feats) if used_fused else (self.model.logits(feats, bias=self.fc_bias) if self.with_logits else None))
 
     # ---- accumulation ---------------------------------------------------------------------------
     def begin(self, n_total=None, temperature=T_COCO, splits=10, rule="coco", drop_first_class=False, fc_bias=None):

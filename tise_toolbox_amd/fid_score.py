@@ -477,14 +477,39 @@ def _class_statistics(path, model, batch_size, dims, num_workers, owner=None):
     loader = torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=False, drop_last=False,
                                          num_workers=min(32, _num_workers(num_workers, world)), collate_fn=img_data.collate_u8,
                                          pin_memory=True)
+    # The pool3 rows of the directory stay on the device (8 KB per crop); once the walk is complete they are sorted by class
+    # and folded into the 80 accumulators by ONE grouped launch (device.stats_update_grouped): every class's S is
+    # read-modify-written once per directory.  Round 4 ran one index_select + one 528-workgroup covariance launch per class
+    # present in a DEVICE BATCH, each a 2 x 33.5 MB read-modify-write of its S for a handful of rows.  Very large
+    # directories are flushed every FLUSH_ROWS crops.
+    FLUSH_ROWS = 1 << 18
+    index_of = {c: i for i, c in enumerate(names)}
+    acc_list = [accs[c] for c in names]
+    kept, kept_rows = [], 0
     base = lo
+
+    def flush():
+        nonlocal kept, kept_rows
+        if not kept_rows:
+            return
+        feats_all = torch.cat(kept) if len(kept) > 1 else kept[0]
+        first = base - kept_rows
+        cidx = np.fromiter((index_of[c] for c in classes[first:base]), dtype=np.int64, count=kept_rows)
+        order = np.argsort(cidx, kind="stable")                       # walk order kept inside a class
+        counts = np.bincount(cidx, minlength=len(names))
+        offsets = np.concatenate([[0], np.cumsum(counts)])
+        feats_sorted = feats_all.index_select(0, torch.from_numpy(order).to(feats_all.device))
+        device.stats_update_grouped(acc_list, feats_sorted, offsets)
+        kept, kept_rows = [], 0
+
     for batch in coalesce_batches(loader, engine.device, device_batch_images(batch_size)):
         feats = _forward_batch(engine, model, batch)
-        cls = classes[base:base + feats.shape[0]]
-        for c in sorted(set(cls)):
-            idx = torch.tensor([i for i, x in enumerate(cls) if x == c], device=feats.device)
-            accs[c].update(feats.index_select(0, idx))
+        kept.append(feats)
+        kept_rows += feats.shape[0]
         base += feats.shape[0]
+        if kept_rows >= FLUSH_ROWS:
+            flush()
+    flush()
     engine.check_numerics()                                # split-fp16 range guard, agreed on by all ranks before the reductions
     # every class is OWNED by one rank (``owner``: class -> rank, the same map on every rank and for both image sets):
     # its 33.57 MB buffer is reduced to that rank only, which alone finalises and solves it (calculate_per_class_fid) --

@@ -32,7 +32,7 @@ warnings.filterwarnings("ignore")
 
 _ENGINE = None
 _CONFIG = {"weights": None, "num_classes": 1000, "seed": 0, "temperature": T_COCO, "batch_size": 50,
-           "rule": "coco", "drop_first_class": False, "num_workers": 8, "fc_bias": "auto"}
+           "rule": "coco", "drop_first_class": False, "num_workers": 0, "fc_bias": "auto", "png_feed": "ring"}
 
 
 def configure(**kw):
@@ -100,23 +100,45 @@ def get_inception_score(images, splits=10):
     bs = _CONFIG["batch_size"]
     rank, world, _ = tdist.env_world()
     lo, hi = tdist.shard_range(n, rank, world)
-    dataset = img_data.Dataset(None, transform=None, file_names=images[lo:hi])
-    loader = torch.utils.data.DataLoader(dataset, batch_size=bs, shuffle=False, drop_last=False,
-                                         num_workers=_CONFIG["num_workers"], collate_fn=img_data.collate_u8,
-                                         pin_memory=True)
-    eng.begin(n_total=n, temperature=_CONFIG["temperature"], splits=splits, rule=_CONFIG["rule"],
-              drop_first_class=_CONFIG["drop_first_class"])
-    base = lo
     # --batch-size is the loader's batch; a trunk pass takes up to engine.device_batch_images of them (split membership
     # is by global index, so batching changes nothing: tests/test_gpu_kernels.py batch invariance)
+    from . import png_ring
     from .engine import coalesce_batches, device_batch_images
-    for batch in coalesce_batches(loader, eng.device, device_batch_images(bs)):
-        if isinstance(batch, (list, tuple)):              # images of different sizes: one trunk pass for the batch
-            eng.step_u8_list(batch, base)
-            base += len(batch)
-        else:
-            eng.step_u8(batch.to(eng.device, non_blocking=True), base)
-            base += batch.shape[0]
+    workers = _CONFIG["num_workers"] if _CONFIG["num_workers"] and _CONFIG["num_workers"] > 0 else png_ring.auto_workers(world)
+
+    def run(feed):
+        eng.begin(n_total=n, temperature=_CONFIG["temperature"], splits=splits, rule=_CONFIG["rule"],
+                  drop_first_class=_CONFIG["drop_first_class"])
+        base = lo
+        for batch in feed:
+            if isinstance(batch, (list, tuple)):              # images of different sizes: one trunk pass for the batch
+                eng.step_u8_list(batch, base)
+                base += len(batch)
+            else:
+                eng.step_u8(batch.to(eng.device, non_blocking=True), base)
+                base += batch.shape[0]
+
+    def dataloader_feed():
+        dataset = img_data.Dataset(None, transform=None, file_names=images[lo:hi])
+        loader = torch.utils.data.DataLoader(dataset, batch_size=bs, shuffle=False, drop_last=False,
+                                             num_workers=min(32, workers), collate_fn=img_data.collate_u8, pin_memory=True)
+        return coalesce_batches(loader, eng.device, device_batch_images(bs))
+
+    if _CONFIG.get("png_feed", "ring") == "ring" and hi > lo:
+        # decode processes -> shared page-locked ring -> side-stream H2D (png_ring.py); every image is used (no drop-last:
+        # inception_score_star_coco.py:44-51 feeds the images one by one), so the ring's loader batch is 1
+        ring = png_ring.PngRingLoader(images[lo:hi], 1, eng.device, group=device_batch_images(1), workers=workers)
+        try:
+            run(ring)
+        except png_ring.RaggedImages as e:
+            if world > 1:
+                raise RuntimeError(f"the ring feed under torchrun needs images of one size ({e})") from e
+            print(f"[tise] png feed: images of different sizes ({e}); falling back to the DataLoader path", file=sys.stderr)
+            run(dataloader_feed())
+        finally:
+            ring.close()
+    else:
+        run(dataloader_feed())
     eng.reduce()
     return eng.inception_score()
 

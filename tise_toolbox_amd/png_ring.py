@@ -44,31 +44,7 @@ class RaggedImages(ValueError):
     """The directory holds images of different sizes: the ring (one slot shape) cannot serve it."""
 
 
-def usable_cpus():
-    """CPUs this process may really use: the affinity mask AND the cgroup's CFS quota.  The GPU boxes show 256 hardware
-    threads and give the container ``cpu.max = 1600000 100000`` -- 16 CPUs of time per period; decode processes beyond the
-    quota are throttled in bursts and the feed gets SLOWER (12.5 k images/s with 16 workers, 8.7 k with 64, 5.9 k with 128:
-    profiles/r05b_host_decode_probe.txt; round 4's DataLoader feed fell the same way between 32 and 64 workers)."""
-    n = os.cpu_count() or 8
-    try:
-        n = len(os.sched_getaffinity(0))
-    except (AttributeError, OSError):
-        pass
-    for path in ("/sys/fs/cgroup/cpu.max",):                                   # cgroup v2
-        try:
-            quota, period = open(path).read().split()[:2]
-            if quota != "max":
-                n = min(n, max(1, -(-int(quota) // int(period))))
-        except (OSError, ValueError):
-            pass
-    try:                                                                       # cgroup v1
-        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-        if q > 0 and per > 0:
-            n = min(n, max(1, -(-q // per)))
-    except (OSError, ValueError):
-        pass
-    return n
+from .hostinfo import usable_cpus  # noqa: E402,F401  (affinity and cgroup CPU quota)
 
 
 def auto_workers(world=1):

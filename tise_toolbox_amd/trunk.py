@@ -320,6 +320,28 @@ class SplitTrunk(FusedTrunk):
         # nine in its operand load (conv_split.hip POOLH / VT; bit-identical).  TISE_POOL2_SPLIT=0: all nine taps in the consumer
         self.pool2_split = (os.environ.get("TISE_POOL2_SPLIT", "1") != "0" and self.fuse_pool and self.last_block >= 2 and
                             self.s4a.variant == "rowwin" and self.s4a.tn == 3)
+        # round 5: the classifier layer (IS* logits) as a 1x1 split-precision convolution on the pool3 row -- the global-mean
+        # kernel writes the row in split form as well -- with raw fp32 out (scale * conv: NO bias, which is exactly the IS*
+        # head of inception_score_star_coco.py:104-105; the bird / O-IS rules add the bias afterwards).  It replaces the
+        # torch / hipBLASLt GEMM, the last library kernel of the image loop.  TISE_FC=torch keeps the library GEMM.
+        self.sfc = None
+        self._feat_split = None
+        fc = getattr(model, "fc", None)
+        if (self.last_block == 3 and fc is not None and fc.in_features % 32 == 0 and os.environ.get("TISE_FC", "hip") == "hip"):
+            w = fc.weight.detach().float().reshape(fc.out_features, fc.in_features, 1, 1)
+            self.sfc = SplitConv(w, torch.zeros(fc.out_features), (1, 1), (0, 0), self.device, variant="fast")
+            self.fc_bias = fc.bias.detach().float().to(self.device) if fc.bias is not None else None
+
+    def fc_logits(self, n, bias=False):
+        """(n, classes) fp32 logits of the pool3 rows of the LAST forward pass (their split form was kept by _global_mean)."""
+        fs = self._feat_split
+        assert self.sfc is not None and fs is not None and fs.shape[0] == n, "fc_logits follows a forward pass of the same batch"
+        out = torch.empty((n, 1, 1, self.sfc.cout), dtype=torch.float32, device=fs.device)
+        self.sfc(fs, [(0, self.sfc.cout, out, 0, 1)])
+        out = out.view(n, self.sfc.cout)
+        if bias and self.fc_bias is not None:
+            out = out + self.fc_bias
+        return out
 
     # ---- helpers on split tensors (N, H, W, 2C) fp16 --------------------------------------------------
     @staticmethod
@@ -535,10 +557,13 @@ class SplitTrunk(FusedTrunk):
             a = fn[kind](a, P)
         return self._global_mean(a)
 
-    @staticmethod
-    def _global_mean(a):
+    def _global_mean(self, a):
         n, h, w, c2 = a.shape                                           # merge + global average, one pass
         c = c2 // 2
         feat = torch.empty((n, c), dtype=torch.float32, device=a.device)
-        _lib.call("tise_split_mean_nhwc", _p(a), n, h * w, c, _p(feat), _stream())
+        if self.sfc is not None and c == self.sfc.cin:                  # pool3: also as a split row, for the classifier layer
+            self._feat_split = torch.empty((n, 1, 1, 2 * c), dtype=torch.float16, device=a.device)
+            _lib.call("tise_split_mean_both_nhwc", _p(a), n, h * w, c, _p(feat), _p(self._feat_split), _stream())
+        else:
+            _lib.call("tise_split_mean_nhwc", _p(a), n, h * w, c, _p(feat), _stream())
         return feat.view(n, c, 1, 1)

@@ -121,7 +121,7 @@ def leg_ipc():
         t = torch.full((1 << 20,), 7, dtype=torch.int32, device="cuda:0")
         torch.cuda.synchronize()
         q.put(t)                                   # hipIpcGetMemHandle here, hipIpcOpenMemHandle in the child
-        ok = done.get(timeout=120)
+        ok = done.get(timeout=float(os.environ.get("TISE_IPC_PROBE_TIMEOUT", "120")))
         p.join(60)
         torch.cuda.synchronize()
         out["child_read_ok"] = ok
@@ -162,10 +162,13 @@ def main():
         leg = sys.argv[sys.argv.index("--leg") + 1]
         {"world1": leg_world1, "ipc": leg_ipc}[leg]()
         return
-    legs = sys.argv[1:] or ["world1", "ipc"]
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    legs = args or ["world1", "ipc"]
     out = {}
     for leg in legs:
-        out[leg] = {"with HSA_ENABLE_IPC_MODE_LEGACY=0": run_child(leg, True), "variable unset": run_child(leg, False)}
+        out[leg] = {"with HSA_ENABLE_IPC_MODE_LEGACY=0": run_child(leg, True)}
+        if "--with-var-only" not in sys.argv:
+            out[leg]["variable unset"] = run_child(leg, False)
     print(json.dumps(out, indent=1))
 
 
