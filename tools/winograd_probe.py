@@ -75,6 +75,12 @@ def probe(h, w, cin, cout, n):
         for k in range(16):
             gemms[k](Vs[k], [(0, cout, Ms[k], 0, 1)])
     t_gemm = timed(run_gemms)
+    # the same matrix work as ONE launch (timing only: the 16 positions stacked along M with one position's weights -- what a
+    # batched kernel with grid.z = position would cost; 16 separate launches of ~1 workgroup round each pay a tail per launch)
+    v_all = torch.cat(Vs, 1).contiguous()                                                           # (n, 16 th, tw, 2 cin)
+    m_all = torch.empty((n, 16 * th, tw, cout), dtype=torch.float32, device=dev)
+    t_batched = timed(lambda: gemms[0](v_all, [(0, cout, m_all, 0, 1)]))
+    del v_all, m_all
     run_gemms()
     M = torch.stack(Ms, -1).reshape(n, th, tw, cout, 4, 4)[:nchk]
     at = AT.float().to(dev)
@@ -87,7 +93,8 @@ def probe(h, w, cin, cout, n):
     flop_w = 2.0 * n * th * tw * 16 * cin * cout
     print(f"{h}x{w}x{cin}->{cout} 3x3, batch {n}: direct {t_direct_split:.3f} ms (raw-out {t_direct:.3f}) = {3 * flop / t_direct_split / 1e9:.0f} TF16; "
           f"Winograd matrix part alone (16 launches, {th * tw} tiles/image, K = {cin}) {t_gemm:.3f} ms = {3 * flop_w / t_gemm / 1e9:.0f} TF16 "
-          f"-> upper bound of the speed-up {t_direct_split / t_gemm:.2f}x (gate 1.3x, transforms not counted); "
+          f"-> upper bound of the speed-up {t_direct_split / t_gemm:.2f}x; as ONE batched launch {t_batched:.3f} ms = {3 * flop_w / t_batched / 1e9:.0f} TF16 "
+          f"-> {t_direct_split / t_batched:.2f}x (gate 1.3x; input / output transforms and their traffic NOT counted in either); "
           f"error vs fp64 of the output scale: direct {err_direct:.2e} (after ReLU {err_direct_relu:.2e}), Winograd {err_wino:.2e} (gate 2e-6)", flush=True)
 
 
