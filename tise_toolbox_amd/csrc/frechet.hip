@@ -782,24 +782,32 @@ __global__ __launch_bounds__(256) void sytrd_fused_kernel(double* __restrict__ A
 // (row j -> workgroup j / 4, one row per wave), so a row is revisited by the same XCD in every launch and the
 // 33.5 MB matrix stays spread over the eight 4 MB L2s; the grid starts at the first workgroup (rounded down to
 // a multiple of 8, which keeps the workgroup -> XCD map) that still owns a live row.
-__global__ __launch_bounds__(256) void sytrd_fused8_kernel(double* __restrict__ A, int n, int k, int wg0,
+// WAVES x RPW (round 5): rows per workgroup.  The per-column trace of the 4-wave form (profiles/r02f_sytrd_per_column_trace.txt,
+// r05h_sytrd_per_column_rows{4,8}.txt) falls almost LINEARLY from 14.6 us at k = 0 to 5.9 us; a fit a + b m + c m^2 over the
+// live rows m = n - k gives a = 5.6 us (x 2047 launches = 11.4 ms: the dependent-launch chain), b = 2.5 ns per row (5.2 ms) and
+// c m^2 = 3.9 us at k = 0 (2.7 ms in all: the only part that is matrix traffic -- rounds 2-4 read all 7.8 ms above the floor as
+// bandwidth).  Going from 4 to 8 rows per workgroup takes b to 1.6 ns: b = 0.7 ns per row + 7.2 ns per WORKGROUP (dispatch and
+// the O(n) bookkeeping every workgroup repeats).  The row loop reads LDS eight elements at a time with selects instead of a
+// branch and two exposed LDS round trips per element; chunks behind the row's end are skipped by a uniform branch.
+template <int WAVES, int RPW>
+__global__ __launch_bounds__(64 * WAVES) void sytrd_fused8_kernel(double* __restrict__ A, int n, int k, int wg0,
                                                            const double* __restrict__ vprev_g, double* __restrict__ vcur_g,
                                                            const double* __restrict__ p_prev, double* __restrict__ p_cur,
                                                            const double* __restrict__ sd_prev, int sd_lo, int sd_hi,
                                                            double* __restrict__ sd_cur, double* __restrict__ td,
                                                            double* __restrict__ te, double* __restrict__ tau_arr) {
+    constexpr int NT = 64 * WAVES, NU = 2048 / NT;                 // threads, bookkeeping elements per thread
     __shared__ double s_w[2048], s_vp[2048], s_vk[2048];
-    __shared__ double s_val[4];
+    __shared__ double s_val[WAVES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wg = wg0 + blockIdx.x;
-    const int j = wg * 4 + wave;                                  // this wave's row
-    const bool row_live = j > k && j < n;
+    const int jb = (wg * WAVES + wave) * RPW;                     // this wave's RPW consecutive rows
     const int c0 = (k + 1) & ~15;
     // ---- every global request first --------------------------------------------------------------
-    double xr[8], vpr[8], ppr[8], ar[32];
+    double xr[NU], vpr[NU], ppr[NU], ar[RPW][32];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = k + tid + 256 * u;
+    for (int u = 0; u < NU; ++u) {
+        const int i = k + tid + NT * u;
         xr[u] = i < n ? A[(int64_t)k * n + i] : 0.0;
         vpr[u] = (k > 0 && i < n) ? vprev_g[i] : 0.0;
         ppr[u] = (k > 0 && i < n) ? p_prev[i] : 0.0;
@@ -807,11 +815,16 @@ __global__ __launch_bounds__(256) void sytrd_fused8_kernel(double* __restrict__ 
     // the wave's whole trailing row (<= 32 segments of 64 doubles) is requested now: its latency hides under the
     // bookkeeping, and the row is never the limiter of memory-level parallelism (4 requests per lane in flight per
     // trip measured 1.7 us per 256-column trip: 19 us at k = 0)
-    double* row = A + (int64_t)(row_live ? j : k) * n;
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-        const int c = c0 + 64 * u + lane;
-        ar[u] = (row_live && c > k && c < n) ? row[c] : 0.0;
+    for (int r = 0; r < RPW; ++r) {
+        const int j = jb + r;
+        const bool row_live = j > k && j < n;
+        const double* row = A + (int64_t)(row_live ? j : k) * n;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int c = c0 + 64 * u + lane;
+            ar[r][u] = (row_live && c > k && c < n) ? row[c] : 0.0;
+        }
     }
     double tau = 0.0, alpha = 0.0, wk = 0.0, vpk = 0.0;
     if (k > 0) {
@@ -826,8 +839,8 @@ __global__ __launch_bounds__(256) void sytrd_fused8_kernel(double* __restrict__ 
     // ---- w_{k-1}, v_{k-1} -> LDS; row k with reflector k-1 applied; its tail norm -----------------
     double xs = 0.0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = k + tid + 256 * u;
+    for (int u = 0; u < NU; ++u) {
+        const int i = k + tid + NT * u;
         if (i < n) {
             double x = xr[u];
             if (k > 0) {
@@ -846,7 +859,9 @@ __global__ __launch_bounds__(256) void sytrd_fused8_kernel(double* __restrict__ 
     __shared__ double s_x[2];
     if (tid < 2 && k + tid < n) s_x[tid] = xr[0];
     __syncthreads();
-    xs = ((s_val[0] + s_val[1]) + s_val[2]) + s_val[3];
+    xs = s_val[0];
+#pragma unroll
+    for (int q = 1; q < WAVES; ++q) xs += s_val[q];              // fixed order: every workgroup gets the same bits
     const double xk = s_x[0], x0 = s_x[1];
     double beta, tau_k, scale;
     if (xs == 0.0 || !isfinite(xs)) { tau_k = 0.0; beta = x0; scale = 0.0; }
@@ -857,8 +872,8 @@ __global__ __launch_bounds__(256) void sytrd_fused8_kernel(double* __restrict__ 
         scale = 1.0 / (x0 - beta);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int i = k + tid + 256 * u;
+    for (int u = 0; u < NU; ++u) {
+        const int i = k + tid + NT * u;
         if (i < n) {
             const double v = (i == k) ? 0.0 : (i == k + 1) ? 1.0 : xr[u] * scale;
             s_vk[i] = v;
@@ -869,31 +884,69 @@ __global__ __launch_bounds__(256) void sytrd_fused8_kernel(double* __restrict__ 
     __syncthreads();
     // ---- the wave's row of the trailing block -------------------------------------------------------
     double pd = 0.0;
-    if (row_live) {
-        const double vpj = k > 0 ? s_vp[j] : 0.0, wj = k > 0 ? s_w[j] : 0.0;
-        double acc = 0.0;
 #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int c = c0 + 64 * u + lane;
-            if (c > k && c < n) {
-                double v = ar[u];
-                if (k > 0) {
-                    v -= __dadd_rn(__dmul_rn(vpj, s_w[c]), __dmul_rn(wj, s_vp[c]));
-                    row[c] = v;
+    for (int r = 0; r < RPW; ++r) {
+        const int j = jb + r;
+        if (j > k && j < n) {                                       // wave-uniform
+            double* row = A + (int64_t)j * n;
+            const double vpj = k > 0 ? s_vp[j] : 0.0, wj = k > 0 ? s_w[j] : 0.0;
+            double acc = 0.0;
+            // Branch-free, LDS reads batched eight elements at a time (round 5).  The first form -- `if (c > k && c < n)`
+            // around every element -- compiled to an exec-mask branch and two exposed LDS round trips PER ELEMENT (ds_read2 ->
+            // s_waitcnt lgkmcnt(0) -> ds_read -> s_waitcnt): 32 elements x ~200 cycles = the 3.8 ns per live row that the
+            // per-column trace shows as its linear term.  Reads use a clamped index (always inside the arrays), elements outside
+            // (k, n) are removed by selects, only the store keeps its predicate.
+            if (k > 0) {                                            // uniform: two straight-line bodies, no per-element control flow
+#pragma unroll
+                for (int ub = 0; ub < 32; ub += 8) {
+                    if (c0 + 64 * ub >= n) break;                   // uniform: the chunk lies behind the row's end
+                    double sw[8], sp[8], sk[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int cc = min(c0 + 64 * (ub + q) + lane, 2047);
+                        sk[q] = s_vk[cc]; sw[q] = s_w[cc]; sp[q] = s_vp[cc];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int c = c0 + 64 * (ub + q) + lane;
+                        const bool ok = c > k && c < n;
+                        const double v = ar[r][ub + q] - __dadd_rn(__dmul_rn(vpj, sw[q]), __dmul_rn(wj, sp[q]));
+                        if (ok) row[c] = v;
+                        const double t = v * sk[q];
+                        acc += ok ? t : 0.0;
+                    }
                 }
-                acc += v * s_vk[c];
+            } else {
+#pragma unroll
+                for (int ub = 0; ub < 32; ub += 8) {
+                    if (c0 + 64 * ub >= n) break;
+                    double sk[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sk[q] = s_vk[min(c0 + 64 * (ub + q) + lane, 2047)];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int c = c0 + 64 * (ub + q) + lane;
+                        const double t = ar[r][ub + q] * sk[q];
+                        acc += (c > k && c < n) ? t : 0.0;
+                    }
+                }
             }
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            p_cur[j] = acc;
-            pd = acc * s_vk[j];
+            acc = wave_sum(acc);
+            if (lane == 0) {
+                p_cur[j] = acc;
+                pd += acc * s_vk[j];
+            }
         }
     }
     __syncthreads();                                                // s_val reuse
     if (lane == 0) s_val[wave] = pd;
     __syncthreads();
-    if (tid == 0) sd_cur[wg] = ((s_val[0] + s_val[1]) + s_val[2]) + s_val[3];
+    if (tid == 0) {
+        double t = s_val[0];
+#pragma unroll
+        for (int q = 1; q < WAVES; ++q) t += s_val[q];
+        sd_cur[wg] = t;
+    }
 }
 
 __global__ void sytrd_last_kernel(const double* __restrict__ A, int n, double* __restrict__ td) {
@@ -1152,13 +1205,27 @@ int run_eigvalsh_inplace(tise_frechet* h, int n, hipStream_t st) {
         double* sd[2] = {h->fz + 2 * (size_t)h->d, h->fz + 2 * (size_t)h->d + SYF_G};
         double* tau_arr = h->fz + 2 * (size_t)h->d + 2 * SYF_G;
         double* vv[2] = {h->va, h->vb};
-        const int wg_end = ceil_div(n, 4);                           // workgroup g owns rows 4g .. 4g+3
+        // rows per workgroup (sytrd_fused8_kernel<WAVES>): 16 by default, TISE_SYTRD_WAVES=4 / 8 for the A/B (4 = rounds 2-4)
+        // TISE_SYTRD_ROWS = rows per workgroup: 8 (default, round 5: 8 waves x 1 row), 4 (rounds 2-4: 4 waves x 1 row), 16 (8 waves x 2
+        // rows), 82 (4 waves x 2 rows = 8).  Measured at n = 2048 (profiles/r05g_frechet_rows_per_workgroup.txt): 4 -> 19.6 ms,
+        // 8 -> 18.0, 82 -> 23.9, 16 -> 23.0 (a second row per wave doubles the wave's serial chain); 16 waves x 1 row needs 127
+        // VGPRs and spills 78 (39.8 ms)
+        static const int cfg = [] { const char* e = getenv("TISE_SYTRD_ROWS"); const int w = e ? atoi(e) : 8; return (w == 4 || w == 16 || w == 82) ? w : 8; }();
+        const int waves = cfg == 82 ? 8 : cfg;                       // rows per workgroup
+        const int wg_end = ceil_div(n, waves);                       // workgroup g owns rows waves * g .. waves * g + waves - 1
+        const int xcd_mask = ~7;                                     // the grid starts on a multiple of 8 workgroups: a row stays on one XCD (its L2) for the whole solve
         int sd_lo = 0, sd_hi = 0;
         for (int k = 0; k <= n - 2; ++k) {
-            const int wg0 = ((k + 1) / 4) & ~7;                      // first workgroup with a live row, XCD map kept
-            hipLaunchKernelGGL(sytrd_fused8_kernel, dim3(wg_end - wg0), dim3(256), 0, st, A, n, k, wg0, vv[(k + 1) & 1],
-                               vv[k & 1], pb[(k + 1) & 1], pb[k & 1], sd[(k + 1) & 1], sd_lo, sd_hi, sd[k & 1], h->td,
-                               h->te, tau_arr);
+            const int wg0 = ((k + 1) / waves) & xcd_mask;            // first workgroup with a live row
+#define TISE_SYTRD_LAUNCH(W, R)                                                                                     \
+            hipLaunchKernelGGL((sytrd_fused8_kernel<W, R>), dim3(wg_end - wg0), dim3(64 * W), 0, st, A, n, k, wg0, vv[(k + 1) & 1], \
+                               vv[k & 1], pb[(k + 1) & 1], pb[k & 1], sd[(k + 1) & 1], sd_lo, sd_hi, sd[k & 1], h->td,  \
+                               h->te, tau_arr)
+            if (cfg == 16) TISE_SYTRD_LAUNCH(8, 2);
+            else if (cfg == 8) TISE_SYTRD_LAUNCH(8, 1);
+            else if (cfg == 82) TISE_SYTRD_LAUNCH(4, 2);
+            else TISE_SYTRD_LAUNCH(4, 1);
+#undef TISE_SYTRD_LAUNCH
             sd_lo = wg0;
             sd_hi = wg_end;
         }
