@@ -8,7 +8,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof_bench && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $REPO/bench.py --steps 24 --warmup 2 --no-host-feed --no-cpu-baseline --no-cross-check --no-kernel-probe > $OUT/bench_steps24_under_rocprof.json 2> $OUT/bench_rocprof.err
+rm -rf /tmp/prof_bench && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- python3 $REPO/bench.py --steps 24 --warmup 2 --no-host-feed --no-cpu-baseline --no-cross-check --no-kernel-probe --png-images 0 > $OUT/bench_steps24_under_rocprof.json 2> $OUT/bench_rocprof.err
 python3 $REPO/tools/summarize_prof.py $(dirname $(find /tmp/prof_bench -name "*kernel_stats.csv" | head -1)) $OUT/bench_steps24_kernel_stats.md 8 > /dev/null 2> $OUT/summarize.err
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_LDS"; do
