@@ -302,13 +302,18 @@ def test_frechet_partial_last_panel_both_factorisations(dev, d, pivoted, monkeyp
     got = solver.distance(m1, s1, m2, s2)
     assert got["rank"] == d and abs(got["fid"] - want) <= 1e-9 * max(1.0, abs(want)), (got["fid"], want)
     solver.set_profiling(True)
-    solver.distance(m1, s1, m2, s2)
-    ph = solver.phase_ms()
+
+    def factor_ms():                                               # best of three: a single timed call can catch a hiccup of the box
+        best = float("inf")
+        for _ in range(3):
+            solver.distance(m1, s1, m2, s2)
+            best = min(best, solver.phase_ms()["pchol"])
+        return best
+    t_sel = factor_ms()
     monkeypatch.delenv("TISE_CHOL_PIVOTED", raising=False)
-    solver.distance(m1, s1, m2, s2)
-    ph2 = solver.phase_ms()
+    t_unpivoted = factor_ms()
     if pivoted and d >= 300:
-        assert ph["pchol"] > ph2["pchol"]                         # the switch really selected the slower, pivoted kernels
+        assert t_sel > t_unpivoted                                 # the switch really selected the slower, pivoted kernels
 
 
 def test_frechet_lost_prefactor_is_detected(dev):
