@@ -70,6 +70,12 @@ int tise_memcpy_h2d_async(void* dst_dev, const void* src_host, size_t bytes, voi
 int tise_resize_bilinear_u8(const uint8_t* src_dev, int n, int h, int w,
                             float* dst_dev, int oh, int ow, int nhwc,
                             const float* lut, uint8_t* u8_out_dev, void* stream);
+/* The same kernel with Pillow's BICUBIC filter (filter = 1; 0 = BILINEAR): replaces, for the CLIP metrics, the
+ * Resize(224, interpolation=BICUBIC) + ToTensor + Normalize of clip.load's preprocess (third-party `clip`,
+ * text_relevance/RP_coco.py:31,64; positional_alignment/PA.py:30,34) -- the table carries (v/255 - mean)/std;
+ * dst_dev planar (n, 3, oh, ow) with nhwc == 0.  Square inputs need no CenterCrop. */
+int tise_resize_u8(const uint8_t* src_dev, int n, int h, int w, float* dst_dev, int oh, int ow, int nhwc,
+                   const float* lut, uint8_t* u8_out_dev, int filter, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * (a7) Streaming activation statistics: n, s = sum_i x_i, S = sum_i x_i x_i^T in fp64 from

@@ -21,12 +21,23 @@ def bilinear_filter(x):
     return np.where(x < 1.0, 1.0 - x, 0.0)
 
 
-def precompute_coeffs(in_size, out_size):
+def bicubic_filter(x):
+    """Resample.c bicubic_filter, a = -0.5 (support 2): clip._transform's Resize(224, BICUBIC)
+    (text_relevance/RP_coco.py:31,64; positional_alignment/PA.py:30,34 through clip.load's preprocess)."""
+    a = -0.5
+    x = np.abs(x)
+    return np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1, np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+
+
+FILTERS = {"bilinear": (bilinear_filter, 1.0), "bicubic": (bicubic_filter, 2.0)}
+
+
+def precompute_coeffs(in_size, out_size, filter="bilinear"):
     """Resample.c precompute_coeffs() + normalize_coeffs_8bpc() for the whole axis.
 
     Returns (bounds int32 [out,2] = (xmin, count), kk int32 [out, ksize]).
     """
-    support = 1.0                                   # BILINEAR.support
+    bilinear_filter, support = FILTERS[filter]      # (the name below is the filter function of the chosen kind)
     scale = float(in_size) / out_size
     filterscale = max(scale, 1.0)
     support = support * filterscale
@@ -59,9 +70,9 @@ def _clip8(v):
     return np.clip(v >> PRECISION_BITS, 0, 255).astype(np.uint8)
 
 
-def _resample_axis0(img, out_size):
+def _resample_axis0(img, out_size, filter="bilinear"):
     """Resample along axis 0 of an (L, ...) uint8 array."""
-    bounds, kk = precompute_coeffs(img.shape[0], out_size)
+    bounds, kk = precompute_coeffs(img.shape[0], out_size, filter)
     out = np.empty((out_size,) + img.shape[1:], dtype=np.uint8)
     src = img.astype(np.int64)
     for xx in range(out_size):
@@ -73,8 +84,8 @@ def _resample_axis0(img, out_size):
     return out
 
 
-def resize_bilinear_u8(img, out_h, out_w):
-    """(H, W, C) uint8 -> (out_h, out_w, C) uint8, bit-exact to Image.resize(BILINEAR).
+def resize_u8(img, out_h, out_w, filter="bilinear"):
+    """(H, W, C) uint8 -> (out_h, out_w, C) uint8, bit-exact to Image.resize((out_w, out_h), BILINEAR | BICUBIC).
 
     Pillow runs the horizontal pass first (skipped when the width is unchanged),
     stores uint8, then the vertical pass (skipped when the height is unchanged).
@@ -82,10 +93,14 @@ def resize_bilinear_u8(img, out_h, out_w):
     img = np.ascontiguousarray(img)
     h, w = img.shape[:2]
     if w != out_w:
-        img = np.swapaxes(_resample_axis0(np.swapaxes(img, 0, 1), out_w), 0, 1)
+        img = np.swapaxes(_resample_axis0(np.swapaxes(img, 0, 1), out_w, filter), 0, 1)
     if h != out_h:
-        img = _resample_axis0(img, out_h)
+        img = _resample_axis0(img, out_h, filter)
     return np.ascontiguousarray(img)
+
+
+def resize_bilinear_u8(img, out_h, out_w):
+    return resize_u8(img, out_h, out_w, "bilinear")
 
 
 def to_tensor(img_u8):

@@ -151,3 +151,54 @@ def test_text_context_is_truncated_at_the_longest_caption_exactly(cuda_device, m
     a = RP_coco.embed_texts(towers, tok, many, cuda_device, 2048)
     cos = torch.nn.functional.cosine_similarity(a.float(), full.repeat(8, 1).float(), dim=-1)
     assert cos.min().item() >= 0.99999
+
+
+def test_clip_preprocess_on_the_device_equals_pillow_preprocess(cuda_device):
+    """clip._transform on the device (round 5, RP_coco.embed_paths): Pillow-exact BICUBIC 8-bit resample (tise_resize_u8,
+    filter 1) + CenterCrop + ToTensor / Normalize through a table against clip_model.preprocess (Pillow on the host, the
+    reference's ``preprocess(Image.open(p))``): the resized uint8 image bit for bit against Pillow and the oracle, the fp32
+    network input EQUAL element for element -- square 256 x 256 (the metric's images), the identity size, an up-scale and
+    two non-square shapes (crop)."""
+    import numpy as np
+    from PIL import Image
+    from oracle import resize_oracle
+    from tests import _cases
+    from tise_toolbox_amd import clip_model, device
+    dev = cuda_device
+    rng = np.random.default_rng(7)
+    for (h, w) in ((256, 256), (224, 224), (128, 128), (300, 200), (180, 333)):
+        imgs = np.stack([_cases.smooth_images(1, h, w, seed=int(rng.integers(1 << 20)))[0] if k % 2 == 0 else rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+                         for k in range(5)])
+        nh, nw, top, left = clip_model.preprocess_geometry(h, w)
+        x, u8 = device.resize_u8_lut(torch.from_numpy(imgs).to(dev), (nh, nw), clip_model.preprocess_lut(), filter="bicubic", return_u8=True)
+        for k in range(len(imgs)):
+            want_u8 = np.asarray(Image.fromarray(imgs[k]).resize((nw, nh), Image.BICUBIC))
+            assert np.array_equal(u8[k].cpu().numpy(), want_u8), (h, w, k)
+            assert np.array_equal(want_u8, resize_oracle.resize_u8(imgs[k], nh, nw, "bicubic"))
+        got = clip_model.preprocess_device(torch.from_numpy(imgs).to(dev)).cpu()
+        want = torch.stack([clip_model.preprocess(Image.fromarray(im)) for im in imgs])
+        assert got.shape == (5, 3, 224, 224) and torch.equal(got, want), (h, w, float((got - want).abs().max()))
+
+
+def test_rp_ring_feed_equals_dataloader_feed(cuda_device, tmp_path):
+    """RP_coco.embed_paths: the ring feed + device preprocess against the DataLoader feed (Pillow preprocess on worker
+    processes): the same embeddings bit for bit; an RGBA file follows RP_coco.py:64's convert("RGB") on both roads, and under
+    PA's rule (no conversion before the resize, PA.py:34) sends the directory to the DataLoader road."""
+    import numpy as np
+    from PIL import Image
+    from tests import _cases
+    from tise_toolbox_amd import RP_coco
+    dev = cuda_device
+    model, _ = RP_coco.build_towers(None, dev)
+    imgs = _cases.smooth_images(37, 256, 256, seed=4)
+    paths = []
+    for i, im in enumerate(imgs):
+        p = tmp_path / f"{i}.png"
+        (Image.fromarray(im).convert("RGBA") if i == 11 else Image.fromarray(im)).save(p)
+        paths.append(str(p))
+    a = RP_coco.embed_paths(model, paths, dev, 16, workers=3, feed="ring")
+    b = RP_coco.embed_paths(model, paths, dev, 16, workers=2, feed="dataloader")
+    assert a.shape == (37, 512) and torch.equal(a, b)
+    c = RP_coco.embed_paths(model, paths, dev, 16, workers=3, feed="ring", convert_first=False)      # PA's rule: RGBA -> DataLoader road
+    d = RP_coco.embed_paths(model, paths, dev, 16, workers=2, feed="dataloader", convert_first=False)
+    assert torch.equal(c, d)

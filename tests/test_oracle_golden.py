@@ -196,3 +196,15 @@ def test_rp_item_shards_add_up_to_the_reference_text(golden_dir, name):
         assert total[:, 1].sum() == n
         mean, std, _ = RP_coco.r_precision_from_bin_sums(total)
         assert f"R-precision: {mean} +- {std}" == str(g["expected_text"]), world
+
+
+def test_resize_oracle_bicubic_equals_pillow():
+    """oracle.resize_oracle with Pillow's BICUBIC filter (clip._transform's Resize(224, BICUBIC), RP_coco.py:31,64 / PA.py:30,34)
+    against the installed Pillow, bit for bit, on the CLIP geometry (256 -> 224), an up-scale, odd sizes and the identity."""
+    from PIL import Image
+    from oracle import resize_oracle
+    rng = np.random.default_rng(3)
+    for (h, w, oh, ow) in ((256, 256, 224, 224), (128, 128, 224, 224), (100, 77, 224, 163), (33, 50, 20, 91), (224, 224, 224, 224)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
+        assert np.array_equal(resize_oracle.resize_u8(img, oh, ow, "bicubic"), want), (h, w, oh, ow)

@@ -33,30 +33,16 @@ def parse_args(argv=None):
     parser.add_argument("--synthetic-weights", action="store_true",
                         help="seeded stand-in towers + word-hash tokenizer (plumbing / throughput only; results are tagged)")
     parser.add_argument("--batch-size", default=256, type=int)
-    parser.add_argument("--num-workers", default=8, type=int, help="image-decoding DataLoader workers")
+    parser.add_argument("--num-workers", default=0, type=int, help="image decode processes (0 = auto)")
+    parser.add_argument("--png-feed", default="ring", choices=["ring", "dataloader"])
     return parser.parse_args(argv)
 
 
-class _Images(torch.utils.data.Dataset):
-    def __init__(self, paths):
-        self.paths = paths
-
-    def __len__(self):
-        return len(self.paths)
-
-    def __getitem__(self, i):
-        from PIL import Image
-        return clip_model.preprocess(Image.open(self.paths[i]))               # clip's preprocess converts to RGB itself (:34)
-
-
-@torch.no_grad()
-def _embed_paths(model, paths, dev, batch, workers=8):
-    loader = torch.utils.data.DataLoader(_Images(paths), batch_size=batch, shuffle=False, num_workers=workers)
-    out = []
-    for x in loader:
-        f = model.encode_image(x.to(dev).half())
-        out.append(f / f.norm(dim=-1, keepdim=True))
-    return torch.cat(out).contiguous()
+def _embed_paths(model, paths, dev, batch, workers=0, feed="ring"):
+    """PA.py:34: ``preprocess(Image.open(img_path))`` -- no conversion before clip's resize, so only plain RGB files take the
+    ring + device preprocess (RP_coco.embed_paths)."""
+    from .RP_coco import embed_paths
+    return embed_paths(model, paths, dev, batch, workers, feed, convert_first=False)
 
 
 def pa_successes(img_emb, txt_emb, pair_index, logit_scale):
@@ -92,7 +78,7 @@ def main(argv=None):
                             for it in mine], dtype=np.int32)
         txt = embed_texts(model, tokenizer, list(table), dev, args.batch_size)
         img = _embed_paths(model, [os.path.join(args.image_dir, phrase, str(it["caption_id"]) + ".png") for it in mine],
-                           dev, args.batch_size, args.num_workers)
+                           dev, args.batch_size, args.num_workers, args.png_feed)
         ok = pa_successes(img, txt, torch.from_numpy(index).to(dev), scale)
         sums[pi, 0] = ok.double().sum()
         sums[pi, 1] = float(len(mine))

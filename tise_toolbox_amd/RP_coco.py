@@ -20,6 +20,7 @@ import argparse
 import os
 import pickle
 import random
+import sys
 
 import numpy as np
 import torch
@@ -39,7 +40,9 @@ def parse_args(argv=None):
                         help="seeded stand-in towers + word-hash tokenizer (plumbing / throughput only; results are tagged)")
     parser.add_argument("--seed", default=None, type=int, help="seed of the bin shuffle (reference: unseeded)")
     parser.add_argument("--batch-size", default=256, type=int)
-    parser.add_argument("--num-workers", default=8, type=int, help="image-decoding DataLoader workers")
+    parser.add_argument("--num-workers", default=0, type=int, help="image decode processes (0 = auto: the CPUs the process may really use)")
+    parser.add_argument("--png-feed", default="ring", choices=["ring", "dataloader"],
+                        help="ring: decode processes -> shared pinned ring, clip's preprocess on the device; dataloader: preprocess on DataLoader workers")
     return parser.parse_args(argv)
 
 
@@ -159,26 +162,55 @@ def embed_texts(model, tokenizer, captions, dev, batch):
     return out.contiguous()
 
 
-class _Images(torch.utils.data.Dataset):
-    def __init__(self, image_dir, ids):
-        self.image_dir, self.ids = image_dir, ids
+@torch.no_grad()
+def embed_paths(model, paths, dev, batch, workers=0, feed="ring", convert_first=True):
+    """Normalised image embeddings of the files ``paths``, in order.  Round 5: the images come through the PNG ring
+    (png_ring.py: decode processes -> shared page-locked ring -> side-stream H2D) as uint8 and clip's preprocess runs on the
+    device (clip_model.preprocess_device: Pillow-exact bicubic resample + crop + ToTensor / Normalize table) -- the reference's
+    ``preprocess(Image.open(f))`` per item (RP_coco.py:64, PA.py:34) on eight DataLoader workers shipped 602 KB of fp32 per image
+    through worker queues and bounded the CLI at ~3 k images/s.  ``convert_first``: RP_coco.py:64 converts to RGB BEFORE the
+    preprocess (``preprocess(Image.open(p).convert("RGB"))``: what the ring's workers do); PA.py:34 does not
+    (``preprocess(Image.open(p))``: clip resizes first and Pillow resamples RGBA premultiplied), so there only plain RGB files
+    may take the ring.  Files of different sizes (or, for PA, not plain RGB) take the DataLoader path."""
+    from . import png_ring
+    out = []
+
+    def consume(x):
+        f = model.encode_image(x.half())
+        out.append(f / f.norm(dim=-1, keepdim=True))
+    workers = int(workers) if workers and int(workers) > 0 else png_ring.auto_workers(tdist.world_size())
+    if feed == "ring" and len(paths):
+        ring = png_ring.PngRingLoader(paths, 1, dev, group=batch, workers=workers, rgb_only=not convert_first)
+        try:
+            for u8 in ring:
+                consume(clip_model.preprocess_device(u8))
+            return torch.cat(out).contiguous()
+        except png_ring.RaggedImages as e:
+            print(f"[tise] png feed: {e}; falling back to the DataLoader path", file=sys.stderr)
+            out.clear()
+        finally:
+            ring.close()
+    loader = torch.utils.data.DataLoader(_Paths(paths, convert_first), batch_size=batch, shuffle=False, num_workers=min(32, workers))
+    for x in loader:
+        consume(x.to(dev))
+    return torch.cat(out).contiguous() if out else torch.empty((0, 512), dtype=torch.float16, device=dev)
+
+
+class _Paths(torch.utils.data.Dataset):
+    def __init__(self, paths, convert_first=True):
+        self.paths, self.convert_first = paths, convert_first
 
     def __len__(self):
-        return len(self.ids)
+        return len(self.paths)
 
     def __getitem__(self, i):
         from PIL import Image
-        return clip_model.preprocess(Image.open(os.path.join(self.image_dir, str(self.ids[i]) + ".png")).convert("RGB"))
+        img = Image.open(self.paths[i])
+        return clip_model.preprocess(img.convert("RGB") if self.convert_first else img)   # (clip's preprocess converts to RGB itself, after the resize)
 
 
-@torch.no_grad()
-def embed_images(model, image_dir, caption_ids, dev, batch, workers=8):
-    loader = torch.utils.data.DataLoader(_Images(image_dir, caption_ids), batch_size=batch, shuffle=False, num_workers=workers)
-    out = []
-    for x in loader:
-        f = model.encode_image(x.to(dev).half())
-        out.append(f / f.norm(dim=-1, keepdim=True))
-    return torch.cat(out).contiguous()
+def embed_images(model, image_dir, caption_ids, dev, batch, workers=0, feed="ring"):
+    return embed_paths(model, [os.path.join(image_dir, str(i) + ".png") for i in caption_ids], dev, batch, workers, feed)
 
 
 def main(argv=None):
@@ -191,10 +223,21 @@ def main(argv=None):
     wpath, tag = tweights.resolve(args.weights, args.synthetic_weights, "clip")
     if wpath is not None and not args.vocab:
         raise RuntimeError("real CLIP weights need the BPE vocabulary: pass --vocab bpe_simple_vocab_16e6.txt.gz")
+    import time
+    timing = os.environ.get("TISE_TIMING") == "1" and rank == 0
+    t_ph = [time.perf_counter()]
+
+    def phase(label):
+        if timing:
+            torch.cuda.synchronize()
+            t_ph.append(time.perf_counter())
+            print(f"[tise timing] {label}: {t_ph[-1] - t_ph[-2]:.2f} s", file=sys.stderr, flush=True)
     model, scale = build_towers(wpath, dev)                            # clip.load on a GPU serves fp16 weights
     tokenizer = clip_model.BPETokenizer(args.vocab) if args.vocab else clip_model.HashTokenizer()
+    phase("towers built")
     with open(args.rp_input_file, "rb") as f:
         rp_input = pickle.load(f)
+    phase("pickle loaded")
     n_items = len(rp_input)
     seed = args.seed
     if world > 1:                                           # one permutation for all ranks
@@ -207,11 +250,15 @@ def main(argv=None):
     sums = np.zeros((10, 2), dtype=np.float64)
     if mine:
         captions, index = caption_table(mine)
+        phase("caption table")
         txt = embed_texts(model, tokenizer, captions, dev, args.batch_size)
-        img = embed_images(model, args.image_dir, [it["caption_id"] for it in mine], dev, args.batch_size, args.num_workers)
+        phase("text tower")
+        img = embed_images(model, args.image_dir, [it["caption_id"] for it in mine], dev, args.batch_size, args.num_workers, args.png_feed)
+        phase("images")
         # features are already normalised in the model's dtype, as CLIP.forward does before the matmul
         top1, _ = device.cosine_top1(img, txt, torch.from_numpy(index).to(dev), normalize=False, logit_scale=scale, want_p0=False)
         sums = bin_sums((top1 == 0).cpu().numpy(), lo, perm)
+        phase("retrieval + bins")
     acc = torch.from_numpy(sums).to(dev)
     tdist.all_reduce_sum_(acc)                              # per-bin {success, count}: the only exchange
     mean, std, scores = r_precision_from_bin_sums(acc.cpu().numpy())

@@ -42,6 +42,8 @@ SIGNATURES = {
     "tise_memcpy_h2d_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
     "tise_resize_bilinear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                          POINTER(c_float), c_void_p, c_void_p]),
+    "tise_resize_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                POINTER(c_float), c_void_p, c_int, c_void_p]),
     "tise_cosine_top1": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                   c_void_p, c_void_p]),
     "tise_gemm_f16": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,

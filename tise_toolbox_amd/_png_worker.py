@@ -25,7 +25,7 @@ import numpy as np
 from PIL import Image
 
 HDR_NEXT, HDR_CONSUMED, HDR_STOP, HDR_NCHUNKS, HDR_ERR, HDR_CHUNK, HDR_NSLOTS, HDR_H, HDR_W, HDR_NFILES, HDR_FILES_OFF, \
-    HDR_DONE_OFF, HDR_ERRTXT_OFF, HDR_STARTED = range(14)
+    HDR_DONE_OFF, HDR_ERRTXT_OFF, HDR_STARTED, HDR_RGBONLY = range(15)
 HDR_WORDS = 16
 ERRTXT_BYTES = 1024
 
@@ -74,6 +74,10 @@ def main(argv):
     lib = load_decoder()
     scratch = np.empty(0, dtype=np.uint8)
     gw, gh = ctypes.c_int(), ctypes.c_int()
+    # rgb_only: the consumer resamples the pixels itself and must see what Image.open(f) holds -- clip's preprocess resizes BEFORE
+    # it converts to RGB, and Pillow resamples an RGBA image with premultiplied alpha: only 3-channel RGB files may take this road
+    rgb_only = bool(hdr[HDR_RGBONLY])
+    pc = ctypes.c_int()
 
     def fail(c, text):
         fcntl.lockf(ctl_fd, fcntl.LOCK_EX, 8, 0)
@@ -111,6 +115,9 @@ def main(argv):
                 if lib is not None:
                     with open(name, "rb") as fh_:
                         blob = fh_.read()
+                    if rgb_only and lib.tise_png_probe(blob, len(blob), ctypes.byref(gw), ctypes.byref(gh), ctypes.byref(pc)) == PNG_OK \
+                            and pc.value != 3:
+                        raise ValueError(f"RAGGED {name}: not a plain RGB image (the device preprocess needs 3-channel files)")
                     need = lib.tise_png_scratch_bytes(h, w, len(blob))
                     if scratch.size < need:
                         scratch = np.empty(need + (need >> 2), dtype=np.uint8)
@@ -122,6 +129,8 @@ def main(argv):
                         raise ValueError(f"RAGGED {name}: {gh.value}x{gw.value} where the first image is {h}x{w}")
                     # UNSUPPORTED (palette, gray, 16-bit, interlaced, a JPEG ...) or CORRUPT: Pillow decides / raises
                 img = Image.open(name)
+                if rgb_only and img.mode != "RGB":
+                    raise ValueError(f"RAGGED {name}: mode {img.mode}, not a plain RGB image (the device preprocess needs 3-channel files)")
                 if img.size != (w, h):
                     raise ValueError(f"RAGGED {name}: {img.size[1]}x{img.size[0]} where the first image is {h}x{w}")
                 img = img.convert("RGB")                          # img_data.py:21

@@ -170,6 +170,34 @@ def preprocess(img):
     return torch.from_numpy(a).permute(2, 0, 1).contiguous()
 
 
+def preprocess_lut():
+    """3 x 256 fp32 table byte -> network input value with preprocess()'s own op order: float32(v) / 255.0, minus the mean,
+    divided by the std, all in float32 -- the ToTensor + Normalize of clip._transform as a look-up."""
+    a = np.arange(256, dtype=np.float32) / 255.0
+    return np.ascontiguousarray(np.stack([(a - np.float32(CLIP_MEAN[c])) / np.float32(CLIP_STD[c]) for c in range(3)]).astype(np.float32))
+
+
+def preprocess_geometry(h, w):
+    """(resized height, resized width, top, left) of clip._transform for an h x w image: Resize(224) of the shorter side,
+    CenterCrop(224)."""
+    s = 224 / min(w, h)
+    nw, nh = (224, max(224, round(h * s))) if w <= h else (max(224, round(w * s)), 224)
+    return nh, nw, (nh - 224) // 2, (nw - 224) // 2
+
+
+def preprocess_device(batch_u8):
+    """preprocess() for a (N, H, W, 3) uint8 CUDA batch of equally sized RGB images, on the device: Pillow-exact BICUBIC
+    8-bit resample (csrc/resize.hip, tise_resize_u8), the crop as a slice, ToTensor + Normalize through preprocess_lut().
+    Returns (N, 3, 224, 224) fp32 -- the values of torch.stack([preprocess(img) for img in batch]) bit for bit."""
+    from . import device
+    n, h, w, _ = batch_u8.shape
+    nh, nw, top, left = preprocess_geometry(h, w)
+    x = device.resize_u8_lut(batch_u8, (nh, nw), preprocess_lut(), filter="bicubic")
+    if (nh, nw) != (224, 224):
+        x = x[:, :, top:top + 224, left:left + 224].contiguous()
+    return x
+
+
 # ---- tokenizers -----------------------------------------------------------------------------------------
 def _bytes_to_unicode():
     bs = list(range(ord("!"), ord("~") + 1)) + list(range(ord("\xa1"), ord("\xac") + 1)) + list(range(ord("\xae"), ord("\xff") + 1))

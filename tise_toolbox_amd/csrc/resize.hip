@@ -38,11 +38,21 @@ double bilinear_filter(double x) {
     return x < 1.0 ? 1.0 - x : 0.0;
 }
 
-// Resample.c precompute_coeffs() + normalize_coeffs_8bpc()
-void precompute_coeffs(int in_size, int out_size, CoeffTable& t) {
+// Resample.c bicubic_filter (a = -0.5, support 2): the filter of clip._transform's Resize(224, BICUBIC)
+// (text_relevance/RP_coco.py:31,64 and positional_alignment/PA.py:30,34 through clip.load's preprocess)
+double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+// Resample.c precompute_coeffs() + normalize_coeffs_8bpc(); filter 0 = BILINEAR (support 1), 1 = BICUBIC (support 2)
+void precompute_coeffs(int in_size, int out_size, CoeffTable& t, int filter) {
     double scale = (double)in_size / out_size;
     double filterscale = scale < 1.0 ? 1.0 : scale;
-    double support = 1.0 * filterscale;
+    double support = (filter == 1 ? 2.0 : 1.0) * filterscale;
     int ksize = (int)ceil(support) * 2 + 1;
     t.in_size = in_size; t.out_size = out_size; t.ksize = ksize;
     t.bounds.assign((size_t)out_size * 2, 0);
@@ -58,7 +68,7 @@ void precompute_coeffs(int in_size, int out_size, CoeffTable& t) {
         if (xmax > in_size) xmax = in_size;
         xmax -= xmin;
         for (int x = 0; x < xmax; ++x) {
-            double w = bilinear_filter((x + xmin - center + 0.5) * ss);
+            double w = filter == 1 ? bicubic_filter((x + xmin - center + 0.5) * ss) : bilinear_filter((x + xmin - center + 0.5) * ss);
             k[x] = w;
             ww += w;
         }
@@ -74,7 +84,7 @@ void precompute_coeffs(int in_size, int out_size, CoeffTable& t) {
 
 struct DevPlan {
     int device;      // HIP device the table lives on (one process may drive several GPUs)
-    int h, w, oh, ow;
+    int h, w, oh, ow, filter;
     int ksx, ksy;
     int rt;          // output rows per workgroup
     int span;        // max source rows any row tile needs
@@ -88,13 +98,13 @@ struct DevPlan {
 // buffer is REUSED for the new plan when it is large enough, so steady state does no hipMalloc / hipFree (hipFree
 // is a device-wide synchronisation).
 struct PlanKey {
-    int device, h, w, oh, ow;
-    bool operator==(const PlanKey& o) const { return device == o.device && h == o.h && w == o.w && oh == o.oh && ow == o.ow; }
+    int device, h, w, oh, ow, filter;
+    bool operator==(const PlanKey& o) const { return device == o.device && h == o.h && w == o.w && oh == o.oh && ow == o.ow && filter == o.filter; }
 };
 struct PlanKeyHash {
     size_t operator()(const PlanKey& k) const {
         size_t x = (size_t)k.device;
-        for (int v : {k.h, k.w, k.oh, k.ow}) x = x * 1000003u ^ (size_t)v;
+        for (int v : {k.h, k.w, k.oh, k.ow, k.filter}) x = x * 1000003u ^ (size_t)v;
         return x;
     }
 };
@@ -103,11 +113,11 @@ std::mutex g_plan_mu;
 std::list<DevPlan> g_plans;                                                   // front = most recently used
 std::unordered_map<PlanKey, std::list<DevPlan>::iterator, PlanKeyHash> g_plan_index;
 
-int get_plan(int h, int w, int oh, int ow, DevPlan* out) {
+int get_plan(int h, int w, int oh, int ow, int filter, DevPlan* out) {
     int device = 0;
     TISE_HIP_CHECK(hipGetDevice(&device));
     std::lock_guard<std::mutex> lk(g_plan_mu);
-    const PlanKey key{device, h, w, oh, ow};
+    const PlanKey key{device, h, w, oh, ow, filter};
     auto hit = g_plan_index.find(key);
     if (hit != g_plan_index.end()) {
         g_plans.splice(g_plans.begin(), g_plans, hit->second);
@@ -115,11 +125,11 @@ int get_plan(int h, int w, int oh, int ow, DevPlan* out) {
         return TISE_OK;
     }
     CoeffTable tx, ty;
-    precompute_coeffs(w, ow, tx);
-    precompute_coeffs(h, oh, ty);
+    precompute_coeffs(w, ow, tx, filter);
+    precompute_coeffs(h, oh, ty, filter);
     DevPlan p;
     p.device = device;
-    p.h = h; p.w = w; p.oh = oh; p.ow = ow; p.ksx = tx.ksize; p.ksy = ty.ksize;
+    p.h = h; p.w = w; p.oh = oh; p.ow = ow; p.filter = filter; p.ksx = tx.ksize; p.ksy = ty.ksize;
     // pick the row tile so staged source rows + horizontal-pass rows fit comfortably in LDS
     const size_t lds_budget = 144 * 1024;
     int rt = 16;
@@ -164,7 +174,7 @@ int get_plan(int h, int w, int oh, int ow, DevPlan* out) {
         // the caller's stream(s) -- order the overwrite behind them with a device synchronisation only in this
         // (rare: > 8192 live sizes) case
         DevPlan victim = g_plans.back();
-        g_plan_index.erase(PlanKey{victim.device, victim.h, victim.w, victim.oh, victim.ow});
+        g_plan_index.erase(PlanKey{victim.device, victim.h, victim.w, victim.oh, victim.ow, victim.filter});
         g_plans.pop_back();
         TISE_HIP_CHECK(hipDeviceSynchronize());
         if (victim.device == device && victim.cap >= host.size()) { p.dev = victim.dev; p.cap = victim.cap; }
@@ -395,14 +405,14 @@ __global__ __launch_bounds__(256) void resize_bilinear_u8_kernel(
 
 }  // namespace
 
-extern "C" int tise_resize_bilinear_u8(const uint8_t* src_dev, int n, int h, int w, float* dst_dev, int oh, int ow,
-                                       int nhwc, const float* lut, uint8_t* u8_out_dev, void* stream) {
-    if (n < 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || !lut || (n > 0 && (!src_dev || (!dst_dev && !u8_out_dev))))
+static int resize_u8_impl(const uint8_t* src_dev, int n, int h, int w, float* dst_dev, int oh, int ow,
+                          int nhwc, const float* lut, uint8_t* u8_out_dev, int filter, void* stream) {
+    if (n < 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0 || !lut || (n > 0 && (!src_dev || (!dst_dev && !u8_out_dev))) || (filter != 0 && filter != 1))
         return TISE_ERR_INVALID_ARG;
     if (n == 0) return TISE_OK;
     if (n > 65535) return TISE_ERR_UNSUPPORTED;
     DevPlan p;
-    int rc = get_plan(h, w, oh, ow, &p);
+    int rc = get_plan(h, w, oh, ow, filter, &p);
     if (rc != TISE_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     float* lut_dev = nullptr;
@@ -427,4 +437,16 @@ extern "C" int tise_resize_bilinear_u8(const uint8_t* src_dev, int n, int h, int
     }
     TISE_LAUNCH_CHECK();
     return TISE_OK;
+}
+
+extern "C" int tise_resize_bilinear_u8(const uint8_t* src_dev, int n, int h, int w, float* dst_dev, int oh, int ow,
+                                       int nhwc, const float* lut, uint8_t* u8_out_dev, void* stream) {
+    return resize_u8_impl(src_dev, n, h, w, dst_dev, oh, ow, nhwc, lut, u8_out_dev, 0, stream);
+}
+
+// The same two-pass 8-bit resample with Pillow's BICUBIC filter (filter = 1; 0 = BILINEAR): clip._transform's
+// Resize(224, interpolation=BICUBIC) + ToTensor + Normalize through the table (RP_coco.py:64, PA.py:34).
+extern "C" int tise_resize_u8(const uint8_t* src_dev, int n, int h, int w, float* dst_dev, int oh, int ow, int nhwc,
+                              const float* lut, uint8_t* u8_out_dev, int filter, void* stream) {
+    return resize_u8_impl(src_dev, n, h, w, dst_dev, oh, ow, nhwc, lut, u8_out_dev, filter, stream);
 }

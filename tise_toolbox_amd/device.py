@@ -82,6 +82,30 @@ def resize_bilinear_u8(src_u8, out_hw=(299, 299), lut=None, channels_last=True, 
     return (out, u8) if return_u8 else out
 
 
+def resize_u8_lut(src_u8, out_hw, lut, filter="bicubic", channels_last=False, return_u8=False):
+    """(N,H,W,3) uint8 CUDA tensor -> (N,3,oh,ow) fp32 through a 3x256 byte -> value table, with Pillow's 8-bit two-pass
+    resample for ``filter`` "bilinear" or "bicubic" (tise_resize_u8).  The CLIP metrics' preprocess on the device:
+    clip._transform = Resize(224, BICUBIC) -> CenterCrop (a no-op for square images) -> ToTensor -> Normalize."""
+    _require_cuda(src_u8)
+    if src_u8.dtype != torch.uint8 or src_u8.dim() != 4 or src_u8.shape[3] != 3:
+        raise ValueError("src_u8 must be (N,H,W,3) uint8")
+    src_u8 = src_u8.contiguous()
+    n, h, w, _ = src_u8.shape
+    oh, ow = out_hw
+    lut = np.ascontiguousarray(lut, dtype=np.float32)
+    if channels_last:
+        store = torch.empty((n, oh, ow, 3), dtype=torch.float32, device=src_u8.device)
+        out = store.permute(0, 3, 1, 2)
+    else:
+        store = torch.empty((n, 3, oh, ow), dtype=torch.float32, device=src_u8.device)
+        out = store
+    u8 = torch.empty((n, oh, ow, 3), dtype=torch.uint8, device=src_u8.device) if return_u8 else None
+    _lib.call("tise_resize_u8", _ptr(src_u8), n, h, w, _ptr(store), oh, ow, 1 if channels_last else 0,
+              lut.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _ptr(u8) if u8 is not None else None,
+              {"bilinear": 0, "bicubic": 1}[filter], _stream())
+    return (out, u8) if return_u8 else out
+
+
 def resize_u8_only(src_u8, out_hw=(299, 299), out=None):
     """(N,H,W,3) uint8 CUDA tensor -> the Pillow-exact resized uint8 image (N,oh,ow,3); no float output (the stem
     convolution applies the input table itself: SplitTrunk.forward_u8).  ``out``: preallocated contiguous

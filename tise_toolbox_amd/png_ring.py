@@ -35,13 +35,14 @@ import torch
 
 from . import _lib
 from ._png_worker import (ERRTXT_BYTES, HDR_CHUNK, HDR_CONSUMED, HDR_DONE_OFF, HDR_ERR, HDR_ERRTXT_OFF, HDR_FILES_OFF, HDR_H,
-                          HDR_NCHUNKS, HDR_NEXT, HDR_NFILES, HDR_NSLOTS, HDR_STARTED, HDR_STOP, HDR_W, HDR_WORDS)
+                          HDR_NCHUNKS, HDR_NEXT, HDR_NFILES, HDR_NSLOTS, HDR_RGBONLY, HDR_STARTED, HDR_STOP, HDR_W, HDR_WORDS)
 
 _WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_png_worker.py")
 
 
 class RaggedImages(ValueError):
-    """The directory holds images of different sizes: the ring (one slot shape) cannot serve it."""
+    """The directory holds images of different sizes (the ring has one slot shape) or, with ``rgb_only``, files that are not
+    plain 3-channel RGB: the caller falls back to its DataLoader path."""
 
 
 from .hostinfo import usable_cpus  # noqa: E402,F401  (affinity and cgroup CPU quota)
@@ -57,7 +58,7 @@ class PngRingLoader:
     NBUF = 3
     pregrouped = True
 
-    def __init__(self, files, batch_size, device, group=1, workers=None, chunk=8, start=True):
+    def __init__(self, files, batch_size, device, group=1, workers=None, chunk=8, start=True, rgb_only=False):
         self.files = list(files)
         self.bs = int(batch_size)
         self.group = max(1, int(group))
@@ -74,6 +75,7 @@ class PngRingLoader:
         self.first_item_rows = 0
         self.t_started = None
         self.on_all_decoded = None                                            # hook: called once when the last chunk is in the ring
+        self.rgb_only = bool(rgb_only)                                        # RGBA / palette / gray files are refused (RaggedImages) instead of converted
         if self.n_rows and start:
             self.start()
 
@@ -113,6 +115,7 @@ class PngRingLoader:
         self.hdr[HDR_NCHUNKS], self.hdr[HDR_CHUNK], self.hdr[HDR_NSLOTS] = n_chunks, self.chunk, nslots
         self.hdr[HDR_H], self.hdr[HDR_W], self.hdr[HDR_NFILES] = h, w, len(names)
         self.hdr[HDR_FILES_OFF], self.hdr[HDR_DONE_OFF], self.hdr[HDR_ERRTXT_OFF] = files_off, done_off, err_off
+        self.hdr[HDR_RGBONLY] = 1 if self.rgb_only else 0
         self.done = np.frombuffer(self.ctl, dtype=np.uint8, count=n_chunks, offset=done_off)
         np.frombuffer(self.ctl, dtype=np.int64, count=len(names) + 1, offset=files_off)[:] = offs
         blob_off = files_off + 8 * (len(names) + 1)
