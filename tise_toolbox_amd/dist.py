@@ -34,10 +34,11 @@ def init_from_env(backend=None, force=None):
     """Initialise the default process group from torchrun's environment (no-op for world size 1 unless ``force`` /
     TISE_DIST_FORCE=1 asks for a one-rank group, whose collectives are then executed like any other group's).
 
-    HSA_ENABLE_IPC_MODE_LEGACY is NOT set here any more (rounds 1-4 set it to 0 blind): the image exports it, a
-    one-rank RCCL group does not need it, and what it governs -- hipIpcGetMemHandle between processes -- is probed by
-    tools/rccl_probe.py (DESIGN.md section 5 records the outcome).  A launcher that starts several ranks (bench._self_launch)
-    passes the variable on from its own environment."""
+    HSA_ENABLE_IPC_MODE_LEGACY: rounds 1-4 set it to 0 blind.  Measured in round 5 (tools/rccl_probe.py,
+    profiles/r05a_rccl_world1.txt): a one-rank RCCL group comes up with and without it; device memory shared between two
+    PROCESSES on this driver (hipIpcGetMemHandle / OpenMemHandle, what RCCL's intra-node transport does between ranks) works
+    with the variable = 0 and never arrives with it unset.  So it is defaulted to 0 exactly where it matters: a multi-rank
+    nccl group (an explicit value in the environment wins); a one-rank group leaves the environment alone."""
     global _FORCED
     rank, world, local_rank = env_world()
     if force is None:
@@ -55,6 +56,8 @@ def init_from_env(backend=None, force=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
+            if world > 1:
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # inter-process device-memory IPC needs it here (measured, see above)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         _FORCED = world == 1
     return rank, world, local_rank
