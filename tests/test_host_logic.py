@@ -363,6 +363,33 @@ def test_png_ring_protocol_order_drop_last_and_ragged(tmp_path):
     assert png_ring.auto_workers(1) >= 2 and png_ring.auto_workers(8) >= 2
 
 
+@pytest.mark.timeout(180)
+def test_png_ring_reports_a_killed_worker_instead_of_waiting_for_its_chunk(tmp_path):
+    """A decode worker that is killed (out of memory, a signal) while it holds a claimed chunk: the surviving workers fill the
+    ring and wait for the consumer, the consumer waits for the chunk nobody will finish.  The loader must raise, not hang."""
+    import time
+    from PIL import Image
+    from tests import _cases
+    from tise_toolbox_amd import _png_worker, png_ring
+    imgs = _cases.smooth_images(45, 32, 32, seed=12)
+    files = []
+    for i, im in enumerate(imgs):
+        files.append(str(tmp_path / f"{i:04d}.png"))
+        Image.fromarray(im).save(files[-1])
+    ld = png_ring.PngRingLoader(files, 1, "cpu", workers=2, chunk=2)           # 23 chunks, 8 slots
+    ld.start()
+    t0 = time.time()
+    while int(ld.hdr[_png_worker.HDR_NEXT]) < ld.nslots + 2 and time.time() - t0 < 60:      # nobody consumes: both workers end up
+        time.sleep(0.01)                                                               # blocked, each holding a claimed chunk
+    assert int(ld.hdr[_png_worker.HDR_NEXT]) == ld.nslots + 2
+    ld.procs[0].kill()
+    ld.procs[0].wait()
+    with pytest.raises(RuntimeError, match="worker died"):
+        for _ in ld.iter_host():
+            pass
+    assert all(p.poll() is not None for p in ld.procs)
+
+
 def _png_bytes(img, ft, split=1):
     """A PNG file image of `img` (h, w, 3 | 4) whose rows all use filter type `ft` (5: a different one per row), the
     compressed stream cut into `split` IDAT chunks, with an ancillary chunk in front."""

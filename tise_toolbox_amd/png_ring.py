@@ -148,9 +148,16 @@ class PngRingLoader:
             if spins % 2000 == 0:                                             # ~ every 0.4 s: is anybody still alive?
                 if self.hdr[HDR_ERR]:
                     raise self._error()
-                if all(p.poll() is not None for p in self.procs) and not self.done[c]:
+                codes = [p.poll() for p in self.procs]
+                # a worker that was killed (out of memory, a signal) may hold a claimed chunk that nobody will ever finish: the others
+                # keep running until the ring is full and then wait for this consumer, which waits for that chunk -- so ANY abnormal
+                # exit is an error here, not only the death of all of them
+                if any(rc not in (None, 0) for rc in codes) and not self.done[c]:
+                    raise RuntimeError("a png decode worker died before the ring was complete "
+                                       f"(exit codes {sorted(set(rc for rc in codes if rc is not None))})")
+                if all(rc is not None for rc in codes) and not self.done[c]:
                     raise RuntimeError("png decode workers exited before the ring was complete "
-                                       f"(exit codes {sorted(set(p.returncode for p in self.procs))})")
+                                       f"(exit codes {sorted(set(codes))})")
             time.sleep(0.0002)
         if self.done[c] == 2:
             raise self._error()
