@@ -47,12 +47,26 @@ __device__ __forceinline__ void compute(const unsigned char* st, int lane, int w
     for (int t = 0; t < 4; ++t) {
         const unsigned char* b = st + 128 * 128 + (wn * 4 + t) * 2048;
         const half8_t bh = *reinterpret_cast<const half8_t*>(b + f16o), bl = *reinterpret_cast<const half8_t*>(b + (f16o ^ 64));
+#ifndef ORDER
+#define ORDER 0
+#endif
+#if ORDER == 0
+        // the product kernel's order: the two MFMAs on the correction accumulator of a block are one MFMA apart
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             ac[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[i], ac[i][t], 0, 0, 0);
             am[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[i], am[i][t], 0, 0, 0);
             ac[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[i], ac[i][t], 0, 0, 0);
         }
+#else
+        // ORDER 1: every accumulator is touched again only after >= 7 other MFMAs
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ac[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, ah[i], ac[i][t], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) am[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, ah[i], am[i][t], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ac[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, al[i], ac[i][t], 0, 0, 0);
+#endif
     }
 }
 
