@@ -54,6 +54,21 @@ int tise_host_unregister(void* host_ptr);
 int tise_memcpy_h2d_async(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * (a2) PNG row filters on the device.  Replaces the second half of ``Image.open(f).convert("RGB")`` of
+ * Dataset.__getitem__ (image_realism/FID/img_data.py:19-25; third-party Pillow: zlib inflate, then the five row filters
+ * of RFC 2083 section 6).  The feed's decode processes only inflate a file into a ring slot (libtise_png.so,
+ * csrc/png_decode.c: tise_png_inflate_slot); the slots are copied to HBM as they are and this call reconstructs the
+ * pixels.  Slot = [64-byte header | payload]; header byte 0: 0 = payload is h*w*3 RGB pixels (decoded on the host: copied),
+ * 3 / 4 = payload is h rows of (1 filter-type byte + w*3 / w*4 filtered bytes) -- None, Sub, Up, Average, Paeth are
+ * reversed and the alpha byte of RGBA is dropped (Pillow's convert("RGB") of an RGBA PNG: no blending).
+ *   slots_dev    n slots, slot_stride bytes apart (multiple of 4, 4-byte aligned base)
+ *   dst_dev      (n, h, w, 3) uint8, the layout tise_resize_u8 reads
+ * Bit-exact against Pillow (tests/test_gpu_png.py).  The filter-type bytes are trusted to be <= 4 (the host checks).
+ * ------------------------------------------------------------------------------------------ */
+int tise_png_unfilter_rgb8(const uint8_t* slots_dev, int64_t n, int64_t slot_stride, int h, int w, uint8_t* dst_dev,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * (a3) PIL-exact uint8 bilinear resize + ToTensor + input affine, fused.
  * Replaces transforms.Resize((299,299)) + ToTensor()   image_realism/FID/fid_score.py:208-213
  * (Pillow ImagingResample, 8bpc: 22-bit fixed-point coefficients, horizontal pass -> u8 ->

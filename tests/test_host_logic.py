@@ -495,3 +495,65 @@ def test_native_png_decoder_equals_pillow(monkeypatch):
         r = subprocess.run([sys.executable, "-c", code, tf.name], capture_output=True, env=dict(os.environ, TISE_PNG_ZLIB="1"))
     assert r.returncode == 0 and r.stdout[0] == 0, r.stderr[-500:]
     assert np.array_equal(np.frombuffer(r.stdout[1:], np.uint8).reshape(256, 256, 3), np.asarray(Image.open(io.BytesIO(good)).convert("RGB")))
+
+
+def test_item_schedule_properties(monkeypatch):
+    """engine.item_schedule: the device batches of a fed image set -- whole loader batches, at most the limit, short first and
+    last batches, a pure function of its arguments (every feed uses it: same files, same fp64 sums)."""
+    from tise_toolbox_amd.engine import item_schedule
+    monkeypatch.delenv("TISE_RAMP", raising=False)
+    assert item_schedule(30000, 50, 3000) == [500, 1000] + [3000] * 9 + [1000, 500]
+    assert item_schedule(12000, 50, 3000) == [500, 1000, 3000, 3000, 3000, 1000, 500]
+    assert item_schedule(3750, 50, 3000) == [500, 1000, 750, 1000, 500]            # a rank's share at 8 GPUs
+    assert item_schedule(45, 5, 3000) == [45] and item_schedule(45, 5, 15) == [15, 15, 15] and item_schedule(0, 5, 15) == []
+    assert item_schedule(2000, 50, 3000) == [500, 1000, 500]
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        bs = int(rng.integers(1, 130))
+        n = int(rng.integers(0, 700)) * bs
+        limit = int(rng.integers(1, 80)) * bs
+        s = item_schedule(n, bs, limit)
+        assert sum(s) == n and all(x > 0 and x % bs == 0 and x <= limit for x in s), (n, bs, limit, s)
+    monkeypatch.setenv("TISE_RAMP", "0")
+    assert item_schedule(30000, 50, 3000) == [3000] * 10
+
+
+def test_ipc_default_is_set_before_any_gpu_call(monkeypatch):
+    """ROCr reads HSA_ENABLE_IPC_MODE_LEGACY once, when HIP is initialised -- torch.cuda.is_available() and
+    set_device already do that -- so dist.init_from_env must have put the default into the environment BEFORE its first
+    torch.cuda call (multi-rank, backend not gloo); an explicit value wins; gloo and one-rank groups leave it alone."""
+    import torch
+    from tise_toolbox_amd import dist as tdist
+    seen = {}
+
+    def spy(name, ret):
+        def f(*a, **k):
+            seen.setdefault(name, os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))
+            return ret
+        return f
+    monkeypatch.setattr(torch.cuda, "is_available", spy("is_available", True))
+    monkeypatch.setattr(torch.cuda, "set_device", spy("set_device", None))
+    monkeypatch.setattr(tdist.dist, "init_process_group", spy("init_process_group", None))
+    monkeypatch.setattr(tdist.dist, "is_initialized", lambda: False)
+    monkeypatch.setattr(tdist, "_FORCED", False)                           # restored afterwards (the forced call below sets it)
+    for k, v in dict(RANK="1", WORLD_SIZE="4", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999").items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.delenv("TISE_DIST_BACKEND", raising=False)
+    assert tdist.init_from_env() == (1, 4, 1)
+    assert seen == {"is_available": "0", "set_device": "0", "init_process_group": "0"}
+    seen.clear()
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")                  # the user's explicit choice is kept
+    tdist.init_from_env()
+    assert seen["is_available"] == "1"
+    seen.clear()
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY")
+    tdist.init_from_env(backend="gloo")
+    assert seen == {"init_process_group": None}
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    tdist.init_from_env(force=True)
+    assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") is None
+    assert tdist.collective_timeout().total_seconds() == 120.0
+    monkeypatch.setenv("TISE_DIST_TIMEOUT_S", "7.5")
+    assert tdist.collective_timeout().total_seconds() == 7.5

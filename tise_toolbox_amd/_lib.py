@@ -40,6 +40,7 @@ SIGNATURES = {
     "tise_host_register": (c_int, [c_void_p, c_size_t]),
     "tise_host_unregister": (c_int, [c_void_p]),
     "tise_memcpy_h2d_async": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "tise_png_unfilter_rgb8": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     "tise_resize_bilinear_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                          POINTER(c_float), c_void_p, c_void_p]),
     "tise_resize_u8": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int,

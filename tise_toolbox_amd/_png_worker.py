@@ -6,6 +6,10 @@ shared-memory files inherited from the parent (memfd: the pixel ring and the con
 straight into ring slots, a chunk of consecutive walk-ordered files at a time.  8-bit RGB / RGBA non-interlaced PNGs are
 decoded by libtise_png.so (csrc/png_decode.c: libdeflate / zlib inflate + SSE unfilter, the same bytes as Pillow, 2-3x
 faster); every other file -- and every file when the library is absent or TISE_PNG_DECODER=pillow -- by Pillow itself.
+Two slot formats (header word IMG_BYTES): h * w * 3 = plain RGB pixels (the whole decode happens here), or
+tise_png_slot_bytes(h, w, bpp) = the device-unfilter format -- the worker only INFLATES a file into the slot (a 64-byte
+header whose first byte names the payload: 0 RGB pixels, 3 / 4 filtered rows of that many bytes per pixel) and the GPU
+reverses the row filters (csrc/png_unfilter.hip); a file outside the subset is still decoded here (payload = pixels).
 
 Control block (int64 header, see png_ring.HDR_*):
     next_chunk   next chunk to claim (claimed under a POSIX record lock on the control file)
@@ -25,8 +29,9 @@ import numpy as np
 from PIL import Image
 
 HDR_NEXT, HDR_CONSUMED, HDR_STOP, HDR_NCHUNKS, HDR_ERR, HDR_CHUNK, HDR_NSLOTS, HDR_H, HDR_W, HDR_NFILES, HDR_FILES_OFF, \
-    HDR_DONE_OFF, HDR_ERRTXT_OFF, HDR_STARTED, HDR_RGBONLY = range(15)
+    HDR_DONE_OFF, HDR_ERRTXT_OFF, HDR_STARTED, HDR_RGBONLY, HDR_IMG_BYTES = range(16)
 HDR_WORDS = 16
+SLOT_HDR = 64          # csrc/png_decode.c: TISE_PNG_SLOT_HDR (device-unfilter slots: [64-byte header | payload])
 ERRTXT_BYTES = 1024
 
 
@@ -49,6 +54,12 @@ def load_decoder():
         lib.tise_png_probe.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                        ctypes.POINTER(ctypes.c_int)]
         lib.tise_png_inflate_backend.restype = ctypes.c_int
+        lib.tise_png_slot_bytes.restype = ctypes.c_size_t
+        lib.tise_png_slot_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.tise_png_inflate_slot.restype = ctypes.c_int
+        lib.tise_png_inflate_slot.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                              ctypes.POINTER(ctypes.c_int)]
         return lib
     except (OSError, AttributeError):
         return None
@@ -68,10 +79,14 @@ def main(argv):
     done = np.frombuffer(ctl, dtype=np.uint8, count=n_chunks, offset=int(hdr[HDR_DONE_OFF]))
     offs = np.frombuffer(ctl, dtype=np.int64, count=n_files + 1, offset=int(hdr[HDR_FILES_OFF]))
     blob_off = int(hdr[HDR_FILES_OFF]) + 8 * (n_files + 1)
-    slots = np.frombuffer(ring, dtype=np.uint8, count=nslots * chunk * h * w * 3).reshape(nslots, chunk, h, w, 3)
+    img_bytes = int(hdr[HDR_IMG_BYTES]) or h * w * 3
+    framed = img_bytes != h * w * 3                                # device-unfilter slots: header + payload
+    slots = np.frombuffer(ring, dtype=np.uint8, count=nslots * chunk * img_bytes).reshape(nslots, chunk, img_bytes)
     ring_addr = slots.ctypes.data
-    img_bytes = h * w * 3
     lib = load_decoder()
+    if framed and lib is None:
+        raise SystemExit("device-unfilter slots need libtise_png.so")
+    mode = ctypes.c_int()
     scratch = np.empty(0, dtype=np.uint8)
     gw, gh = ctypes.c_int(), ctypes.c_int()
     # rgb_only: the consumer resamples the pixels itself and must see what Image.open(f) holds -- clip's preprocess resizes BEFORE
@@ -121,8 +136,13 @@ def main(argv):
                     need = lib.tise_png_scratch_bytes(h, w, len(blob))
                     if scratch.size < need:
                         scratch = np.empty(need + (need >> 2), dtype=np.uint8)
-                    rc = lib.tise_png_decode_rgb8(blob, len(blob), ring_addr + ((c % nslots) * chunk + (i - lo)) * img_bytes, h, w,
-                                                  scratch.ctypes.data, scratch.size, ctypes.byref(gw), ctypes.byref(gh))
+                    slot_addr = ring_addr + ((c % nslots) * chunk + (i - lo)) * img_bytes
+                    if framed:
+                        rc = lib.tise_png_inflate_slot(blob, len(blob), slot_addr, img_bytes, h, w, scratch.ctypes.data, scratch.size,
+                                                       ctypes.byref(gw), ctypes.byref(gh), ctypes.byref(mode))
+                    else:
+                        rc = lib.tise_png_decode_rgb8(blob, len(blob), slot_addr, h, w,
+                                                      scratch.ctypes.data, scratch.size, ctypes.byref(gw), ctypes.byref(gh))
                     if rc == PNG_OK:
                         continue
                     if rc == PNG_SIZE:
@@ -134,7 +154,11 @@ def main(argv):
                 if img.size != (w, h):
                     raise ValueError(f"RAGGED {name}: {img.size[1]}x{img.size[0]} where the first image is {h}x{w}")
                 img = img.convert("RGB")                          # img_data.py:21
-                dst[i - lo] = np.asarray(img)
+                if framed:
+                    dst[i - lo, :SLOT_HDR] = 0                    # mode 0: the payload is pixels
+                    dst[i - lo, SLOT_HDR:SLOT_HDR + h * w * 3] = np.asarray(img).reshape(-1)
+                else:
+                    dst[i - lo, :] = np.asarray(img).reshape(-1)
             done[c] = 1
         except Exception as e:                                    # noqa: BLE001 -- reported to the parent through the control block
             fail(c, f"{type(e).__name__}: {e}")

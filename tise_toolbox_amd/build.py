@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtise_hip.so")
-SOURCES = ["capi.hip", "stats.hip", "resize.hip", "is_score.hip", "frechet.hip", "trunk_ops.hip", "conv_split.hip", "conv_pipe.hip", "retrieval.hip", "clip_ops.hip"]
+SOURCES = ["capi.hip", "stats.hip", "resize.hip", "is_score.hip", "frechet.hip", "trunk_ops.hip", "conv_split.hip", "conv_pipe.hip", "retrieval.hip", "clip_ops.hip", "png_unfilter.hip"]
 HEADERS = ["common.h", "gemm_tile.h", "conv_epilogue.h", os.path.join("..", "..", "include", "tise_hip.h")]
 
 
@@ -45,13 +45,48 @@ def build_png(force=False, verbose=True):
     return PNG_LIB
 
 
-def build(force=False, verbose=True):
-    """Compile every HIP source for gfx950 into tise_toolbox_amd/libtise_hip.so (and the host PNG decoder, build_png)."""
+OBJ_DIR = os.path.join(CSRC, "_obj")       # per-source objects (git-ignored: *.o): a change to one kernel file recompiles that file only
+
+
+def _deps(src):
+    """Headers a source includes (one level of #include "..." is all csrc/ uses) + the public header."""
+    out = [os.path.join(CSRC, src), os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "tise_hip.h")]
+    with open(os.path.join(CSRC, src)) as f:
+        for line in f:
+            if line.startswith('#include "'):
+                out.append(os.path.join(CSRC, line.split('"')[1]))
+    return [p for p in out if os.path.exists(p)]
+
+
+def build(force=False, verbose=True, jobs=None):
+    """Compile every HIP source for gfx950 into tise_toolbox_amd/libtise_hip.so (and the host PNG decoder, build_png).
+    Each source becomes csrc/_obj/<name>.o (compiled in parallel, recompiled only when it or a header it includes is
+    newer), then one link."""
+    from concurrent.futures import ThreadPoolExecutor
     build_png(force, verbose)
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-           "-Wno-unused-value", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+    todo, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _deps(src)):
+            todo.append((src, obj))
+
+    def compile_one(item):
+        src, obj = item
+        cmd = [_hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[tise build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    if jobs is None:
+        jobs = max(1, min(len(todo) or 1, (os.cpu_count() or 4), int(os.environ.get("TISE_BUILD_JOBS", "8"))))
+    with ThreadPoolExecutor(jobs) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
     if verbose:
         print("[tise build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)

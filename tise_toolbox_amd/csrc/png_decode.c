@@ -4,7 +4,11 @@
  * ``Dataset.__getitem__`` (image_realism/FID/img_data.py:19-25; third-party Pillow 8.3.2 -> libpng-style decode):
  * 8-bit RGB or RGBA, non-interlaced PNGs (what ``Image.fromarray(...).save("x.png")`` and the generators' ``save_image``
  * write).  Anything else -- palette, gray, 16-bit, interlaced, tRNS, JPEG -- returns TISE_PNG_UNSUPPORTED and the worker
- * decodes that file with Pillow itself, so the result is Pillow's in every case.  PNG is lossless and its decode is fully
+ * decodes that file with Pillow itself; a file with ANY doubt about it -- a chunk whose CRC-32 does not match (IHDR, IDAT,
+ * IEND and every ancillary chunk walked), a zlib stream of the wrong length or checksum, a filter byte above 4 -- returns
+ * TISE_PNG_CORRUPT and Pillow decides (it raises its own error, or decodes what it tolerates: it does not check IDAT CRCs).
+ * So a return of TISE_PNG_OK means: every checksum of the file is right and the bytes are Pillow's
+ * (tests/test_png_fuzz.py: sanitizer build, seeded mutations, rc 0 => Pillow decodes to the same bytes).  PNG is lossless and its decode is fully
  * specified (RFC 2083: zlib inflate + the five row filters), so the bytes equal Pillow's; RGBA -> RGB drops the alpha
  * byte, which is what Pillow's convert("RGB") does (no blending).  tests/test_host_logic.py compares against Pillow.
  *
@@ -32,7 +36,9 @@ static inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | 
 /* ---- libdeflate through dlopen ------------------------------------------------------------------------------------ */
 typedef void* (*ld_alloc_fn)(void);
 typedef int (*ld_zlib_fn)(void*, const void*, size_t, void*, size_t, size_t*);
+typedef uint32_t (*ld_crc_fn)(uint32_t, const void*, size_t);
 static ld_zlib_fn g_ld_zlib = 0;
+static ld_crc_fn g_ld_crc = 0;
 static void* g_ld_dec = 0;
 static int g_ld_state = 0;       /* 0 untried, 1 usable, -1 absent */
 
@@ -46,11 +52,19 @@ static void ld_init(void) {
     ld_alloc_fn alloc = (ld_alloc_fn)dlsym(h, "libdeflate_alloc_decompressor");
     g_ld_zlib = (ld_zlib_fn)dlsym(h, "libdeflate_zlib_decompress");
     if (!alloc || !g_ld_zlib) return;
+    g_ld_crc = (ld_crc_fn)dlsym(h, "libdeflate_crc32");       /* carry-less-multiply CRC-32, ~10 x zlib's; optional */
     g_ld_dec = alloc();
     if (g_ld_dec) g_ld_state = 1;
 }
 
 int tise_png_inflate_backend(void) { ld_init(); return g_ld_state == 1 ? 1 : 0; }   /* 1 libdeflate, 0 zlib */
+
+/* CRC-32 of a chunk's type + body (RFC 2083 section 3.4), against the four bytes behind the body. */
+static int chunk_crc_ok(const uint8_t* type_and_body, size_t n, const uint8_t* stored) {
+    ld_init();
+    const uint32_t got = g_ld_crc ? g_ld_crc(0, type_and_body, n) : (uint32_t)crc32(0L, type_and_body, (uInt)n);
+    return got == be32(stored);
+}
 
 /* ---- unfilter: one row, BPP bytes per pixel, in place; `up` = the previous unfiltered row (NULL for the first) --------- */
 static inline int paeth(int a, int b, int c) {
@@ -148,7 +162,7 @@ static int png_parse(const uint8_t* f, size_t len, int* w, int* h, int* bpp, con
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     if (len < 8 + 25 || memcmp(f, sig, 8) != 0) return TISE_PNG_UNSUPPORTED;   /* not a PNG (a .jpg): Pillow's business */
     size_t p = 8;
-    int have_ihdr = 0, n_idat = 0;
+    int have_ihdr = 0, n_idat = 0, seen_iend = 0;
     const uint8_t* first = 0;
     size_t first_len = 0, gathered = 0;
     *scratch_used = 0;
@@ -157,6 +171,7 @@ static int png_parse(const uint8_t* f, size_t len, int* w, int* h, int* bpp, con
         const uint8_t* typ = f + p + 4;
         if ((size_t)cl > len - p - 12) return TISE_PNG_CORRUPT;
         const uint8_t* body = f + p + 8;
+        if (!chunk_crc_ok(typ, (size_t)cl + 4, body + cl)) return TISE_PNG_CORRUPT;   /* Pillow raises for header chunks, ignores IDAT's */
         if (!have_ihdr) {
             if (memcmp(typ, "IHDR", 4) != 0 || cl != 13) return TISE_PNG_CORRUPT;
             const uint32_t ww = be32(body), hh = be32(body + 4);
@@ -179,6 +194,7 @@ static int png_parse(const uint8_t* f, size_t len, int* w, int* h, int* bpp, con
             }
             ++n_idat;
         } else if (memcmp(typ, "IEND", 4) == 0) {
+            seen_iend = 1;
             break;
         } else if (memcmp(typ, "tRNS", 4) == 0 || memcmp(typ, "PLTE", 4) == 0) {
             return TISE_PNG_UNSUPPORTED;                           /* transparency key / palette: Pillow decides what they mean */
@@ -187,7 +203,7 @@ static int png_parse(const uint8_t* f, size_t len, int* w, int* h, int* bpp, con
         }
         p += 12 + (size_t)cl;
     }
-    if (!have_ihdr || n_idat == 0) return TISE_PNG_CORRUPT;
+    if (!have_ihdr || n_idat == 0 || !seen_iend) return TISE_PNG_CORRUPT;      /* a file cut before IEND: Pillow decides */
     if (n_idat == 1) { *idat = first; *idat_len = first_len; }
     else { *idat = scratch; *idat_len = gathered; *scratch_used = (gathered + 63) & ~(size_t)63; }
     return TISE_PNG_OK;
@@ -246,5 +262,58 @@ int tise_png_decode_rgb8(const uint8_t* file, size_t len, uint8_t* dst, int h, i
             for (int x = 0; x < w; ++x) { out[3 * x] = cur[4 * x]; out[3 * x + 1] = cur[4 * x + 1]; out[3 * x + 2] = cur[4 * x + 2]; }
         up = cur;
     }
+    return TISE_PNG_OK;
+}
+
+/* ---- the device-unfilter feed: inflate only ------------------------------------------------------------------------------
+ * A ring slot of the image feed (tise_toolbox_amd/png_ring.py, TISE_PNG_UNFILTER=device) is
+ *     [ 64-byte header | payload ]       header byte 0 = mode:  0  payload is h x w x 3 RGB pixels (decoded on the host)
+ *                                                               3  payload is h rows of (1 filter byte + w x 3 filtered bytes)
+ *                                                               4  the same with 4 bytes per pixel (RGBA)
+ * For modes 3 / 4 the worker has only INFLATED the file's zlib stream -- the five row filters of RFC 2083 section 6 (and the
+ * RGBA -> RGB drop) run on the GPU (csrc/png_unfilter.hip: tise_png_unfilter_rgb8), so a decode process spends ~0.3 ms per
+ * 256 x 256 image instead of ~0.65.  A file whose filtered rows do not fit the slot (an RGBA file in a ring sized for RGB)
+ * or whose rows are too long for the kernel's LDS tile is decoded completely here (mode 0). */
+#define TISE_PNG_SLOT_HDR 64
+#define TISE_PNG_DEVICE_ROW_MAX 8192        /* bytes of one filtered row the device kernel stages (png_unfilter.hip) */
+
+size_t tise_png_slot_bytes(int h, int w, int bpp) {
+    /* bpp = 0: pixels only.  8 bytes of slack: the kernel's row staging reads whole dwords. */
+    const size_t px = (size_t)h * w * 3, raw = bpp ? (size_t)h * ((size_t)w * bpp + 1) : 0;
+    const size_t pay = (px > raw ? px : raw) + 8;
+    return TISE_PNG_SLOT_HDR + ((pay + 63) & ~(size_t)63);
+}
+
+int tise_png_inflate_slot(const uint8_t* file, size_t len, uint8_t* slot, size_t slot_bytes, int h, int w,
+                          uint8_t* scratch, size_t scratch_bytes, int* got_w, int* got_h, int* mode_out) {
+    const uint8_t* idat; size_t idat_len, used;
+    int fw = 0, fh = 0, bpp = 0;
+    if (!file || !slot || !scratch || slot_bytes < TISE_PNG_SLOT_HDR) return TISE_PNG_CORRUPT;
+    int rc = png_parse(file, len, &fw, &fh, &bpp, &idat, &idat_len, scratch, scratch_bytes, &used);
+    if (got_w) *got_w = fw;
+    if (got_h) *got_h = fh;
+    if (rc != TISE_PNG_OK) return rc;
+    if (fw != w || fh != h) return TISE_PNG_SIZE;
+    const size_t stride = (size_t)w * bpp, raw_len = (size_t)h * (stride + 1);
+    uint8_t* pay = slot + TISE_PNG_SLOT_HDR;
+    memset(slot, 0, TISE_PNG_SLOT_HDR);
+    if (TISE_PNG_SLOT_HDR + raw_len + 8 > slot_bytes || stride + 1 > TISE_PNG_DEVICE_ROW_MAX) {
+        if (TISE_PNG_SLOT_HDR + (size_t)h * w * 3 > slot_bytes) return TISE_PNG_SCRATCH;
+        rc = tise_png_decode_rgb8(file, len, pay, h, w, scratch, scratch_bytes, got_w, got_h);
+        if (mode_out) *mode_out = 0;
+        return rc;
+    }
+    ld_init();
+    if (g_ld_state == 1) {
+        size_t got = 0;
+        if (g_ld_zlib(g_ld_dec, idat, idat_len, pay, raw_len, &got) != 0 || got != raw_len) return TISE_PNG_CORRUPT;
+    } else {
+        uLongf got = (uLongf)raw_len;
+        if (uncompress(pay, &got, idat, (uLong)idat_len) != Z_OK || got != raw_len) return TISE_PNG_CORRUPT;
+    }
+    for (int y = 0; y < h; ++y)
+        if (pay[(size_t)y * (stride + 1)] > 4) return TISE_PNG_CORRUPT;     /* the kernel trusts the filter bytes */
+    slot[0] = (uint8_t)bpp;
+    if (mode_out) *mode_out = bpp;
     return TISE_PNG_OK;
 }

@@ -30,17 +30,32 @@ def _collective():
     return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCED)
 
 
+def _ipc_default(world, backend):
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 for a multi-rank RCCL group, set BEFORE anything initialises HIP in this process: ROCr reads
+    its HSA_* switches once, at hsa_init, and torch.cuda.is_available() / set_device already run it.  Measured in
+    round 5 (tools/rccl_probe.py, profiles/r05a_rccl_world1.txt): device memory shared between two PROCESSES on this driver
+    (hipIpcGetMemHandle / OpenMemHandle -- RCCL's intra-node transport) works with the variable = 0 and never arrives with it
+    unset; a one-rank group comes up either way and leaves the environment alone.  An explicit value in the environment wins.
+    torchrun users may export it themselves; the package also applies this default at import (tise_toolbox_amd/__init__.py)
+    when WORLD_SIZE > 1, which is earlier still."""
+    if world > 1 and backend != "gloo":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def collective_timeout():
+    """Deadline of every collective of the job's process group (TISE_DIST_TIMEOUT_S, default 120 s): a rank that dies
+    mid-loop must not leave the others in barrier() / all_reduce until the launcher's own limit."""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("TISE_DIST_TIMEOUT_S", "120")))
+
+
 def init_from_env(backend=None, force=None):
     """Initialise the default process group from torchrun's environment (no-op for world size 1 unless ``force`` /
     TISE_DIST_FORCE=1 asks for a one-rank group, whose collectives are then executed like any other group's).
-
-    HSA_ENABLE_IPC_MODE_LEGACY: rounds 1-4 set it to 0 blind.  Measured in round 5 (tools/rccl_probe.py,
-    profiles/r05a_rccl_world1.txt): a one-rank RCCL group comes up with and without it; device memory shared between two
-    PROCESSES on this driver (hipIpcGetMemHandle / OpenMemHandle, what RCCL's intra-node transport does between ranks) works
-    with the variable = 0 and never arrives with it unset.  So it is defaulted to 0 exactly where it matters: a multi-rank
-    nccl group (an explicit value in the environment wins); a one-rank group leaves the environment alone."""
+    The group carries collective_timeout(); see _ipc_default for HSA_ENABLE_IPC_MODE_LEGACY."""
     global _FORCED
     rank, world, local_rank = env_world()
+    _ipc_default(world, backend or os.environ.get("TISE_DIST_BACKEND"))        # first: no torch.cuda call has run in here yet
     if force is None:
         force = os.environ.get("TISE_DIST_FORCE", "0") == "1"
     if (world > 1 or force) and not dist.is_initialized():
@@ -56,9 +71,7 @@ def init_from_env(backend=None, force=None):
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            if world > 1:
-                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # inter-process device-memory IPC needs it here (measured, see above)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=collective_timeout())
         _FORCED = world == 1
     return rank, world, local_rank
 

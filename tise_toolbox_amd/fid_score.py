@@ -155,7 +155,8 @@ def get_activations(images, model, batch_size=64, dims=2048, cuda=True, verbose=
     start = 0
     # the loader's batches are gathered into device batches (engine.device_batch_images): ``batch_size`` defines the
     # bookkeeping above, not the size of a trunk pass
-    for batch in coalesce_u8(_first(images, n_batches), engine.device, device_batch_images(batch_size)):   # :99
+    limit = device_batch_images(batch_size)
+    for batch in coalesce_u8(_first(images, n_batches), engine.device, limit, (n_used_imgs, batch_size)):   # :99
         f = _forward_batch(engine, model, batch)
         pred_dev[start:start + f.shape[0]] = f.reshape(f.shape[0], -1)                       # :113
         start += f.shape[0]
@@ -226,9 +227,23 @@ def calculate_activation_statistics(images, model, batch_size=64, dims=2048, cud
     if getattr(images, "pregrouped", False):              # img_data.U8CacheLoader(group=K): items are device batches already
         batches = iter(images)
     else:
-        batches = coalesce_u8(_first(images, n_batches), engine.device, device_batch_images(batch_size))
-    for batch in batches:
-        stats.update(_forward_batch(engine, model, batch))
+        limit = device_batch_images(batch_size)
+        batches = coalesce_u8(_first(images, n_batches), engine.device, limit, (n_batches * batch_size, batch_size))
+    err = None
+    try:
+        for batch in batches:
+            stats.update(_forward_batch(engine, model, batch))
+    except Exception as e:                                # noqa: BLE001 -- re-raised below, on EVERY rank
+        err = e
+    # A rank whose image loop failed (an unreadable file, a directory of ragged sizes, a dead decode worker) must not leave
+    # the others waiting in the all-reduce below: the failure is agreed on collectively and every rank raises.
+    if tdist.world_size() > 1:
+        if tdist.any_rank(err is not None):
+            if err is not None:
+                raise err
+            raise RuntimeError("the image loop failed on another rank (its own message says why)")
+    elif err is not None:
+        raise err
     engine.check_numerics()                               # split-fp16 range guard (no silent inf / NaN features)
     tdist.all_reduce_sum_(stats.buffer())
     if tdist.world_size() > 1 and stats.count() == 0:     # identical on every rank (read after the all-reduce)
@@ -333,9 +348,10 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
     shard, _ = tdist.shard_files(files, batch_size, rank, world)       # drop_last=True (:215-217), whole batches
     num_workers = _num_workers(num_workers, world)
     if _PNG_FEED["mode"] == "ring":
-        # decode workers -> shared page-locked ring -> side-stream H2D (png_ring.py).  Every rank decides alike: a directory
-        # with images of different sizes makes EVERY rank fall back (the size check below is made on the global list's first
-        # file by the workers of each rank; a rank that meets a different size raises, and the flag is agreed on collectively)
+        # decode workers -> shared page-locked ring -> side-stream H2D (png_ring.py).  A directory with images of different
+        # sizes: one process falls back to the DataLoader path below; under torchrun the rank that meets the odd file raises
+        # RaggedImages inside calculate_activation_statistics, which agrees on the failure collectively -- every rank raises
+        # (the others a generic RuntimeError) instead of waiting in the all-reduce
         from . import png_ring
         with _RING_LOCK:
             loader = _RING_PREFETCH.pop(path, None)
@@ -355,7 +371,7 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
             err = e
         finally:
             if loader is not None:
-                loader.close()
+                loader.close()                             # stops and joins the feeder thread before the ring is unregistered
         if err is None:
             wall = time.perf_counter() - t0
             if tdist.is_main() and len(shard):

@@ -128,9 +128,10 @@ class U8CacheLoader:
     DataLoader it replaces: ``len()`` = number of batches, drop_last=True semantics (fid_score.py:215-217).  ``rows`` =
     (lo, hi) restricts it to a shard of the cache (data-parallel runs).  ``h2d_seconds``: time the feeder spent reading
     and enqueueing (not waiting for buffers).
-    ``group`` = K > 1: the DEVICE batch is decoupled from ``batch_size`` -- an item is K consecutive batches (the last
-    item whatever whole batches remain), read, copied and handed over as one tensor; ``len()`` still counts batches of
-    ``batch_size`` (the drop-last bookkeeping of fid_score.py:90-96), ``pregrouped`` tells the consumer."""
+    ``group`` = K > 1: the DEVICE batch is decoupled from ``batch_size`` -- an item is up to K consecutive batches
+    (engine.item_schedule: short first and last items, equal ones between), read, copied and handed over as one tensor;
+    ``len()`` still counts batches of ``batch_size`` (the drop-last bookkeeping of fid_score.py:90-96), ``pregrouped``
+    tells the consumer."""
 
     NBUF = 3
     READERS = 4
@@ -160,9 +161,15 @@ class U8CacheLoader:
         n_rows = len(self) * self.bs                                    # whole batches only
         if n_rows == 0:
             return
-        item_rows = self.bs * self.group
-        nb = -(-n_rows // item_rows)                                     # items; the last one may be shorter
-        shape = (min(item_rows, n_rows),) + tuple(self.arr.shape[1:])
+        # device batches: the schedule every feed of the CLIs uses (engine.item_schedule: short first and last batches), so
+        # that the same files give the same fp64 sums -- the same FID to the last bit -- whichever feed delivered them
+        from .engine import item_schedule
+        sizes = item_schedule(n_rows, self.bs, self.bs * self.group)
+        starts = [0]
+        for r_ in sizes:
+            starts.append(starts[-1] + r_)
+        nb = len(sizes)
+        shape = (max(sizes),) + tuple(self.arr.shape[1:])
         row_bytes = int(np.prod(shape[1:]))
         data_offset = int(self.arr.offset)
         nbuf = min(self.NBUF, nb)
@@ -199,9 +206,9 @@ class U8CacheLoader:
                             return
                         consumed[k].synchronize()                        # ... and its stream is past that point
                         t0 = time.perf_counter()
-                        rows = min(item_rows, n_rows - b * item_rows)
+                        rows = sizes[b]
                         batch_bytes = rows * row_bytes
-                        off = data_offset + (self.lo + b * item_rows) * row_bytes
+                        off = data_offset + (self.lo + starts[b]) * row_bytes
                         step = -(-batch_bytes // self.READERS)
                         list(pool.map(lambda i: read_chunk(k, off, i * step, min(batch_bytes, (i + 1) * step)), range(self.READERS)))
                         with torch.cuda.stream(side):
@@ -225,7 +232,7 @@ class U8CacheLoader:
                     # the consumer came back for the second item: the first device batch is ENQUEUED, not finished (the trunk is
                     # asynchronous) -- so the steady-state rate is taken between two device events, not from this host time
                     self.first_item_done_at = time.perf_counter()
-                    self.first_item_rows = item_rows
+                    self.first_item_rows = sizes[0]
                     self.first_item_event = torch.cuda.Event(enable_timing=True)
                     self.first_item_event.record(cur)
                 cur.wait_event(ready[k])

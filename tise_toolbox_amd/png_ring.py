@@ -18,6 +18,12 @@ Here the parent touches no pixel:
     with an event its stream waits on -- the same contract as img_data.U8CacheLoader (``len()`` counts ``batch_size``
     batches: the drop-last bookkeeping of fid_score.py:90-96; ``pregrouped``).
 Workers can be started BEFORE the model is built (``start()``), so decoding overlaps the process's start-up.
+Round 6 (row a2's arithmetic on the GPU): with a device consumer the workers only INFLATE a file -- a ring slot holds the
+FILTERED scanlines behind a 64-byte header (csrc/png_decode.c: tise_png_inflate_slot) -- and the five PNG row filters and
+the RGBA -> RGB drop run in HBM (csrc/png_unfilter.hip: tise_png_unfilter_rgb8, on the feed's side stream after a device
+batch's copies); TISE_PNG_UNFILTER=host keeps the whole decode in the workers, and so does a host consumer (iter_host).
+Device batches follow engine.item_schedule (short first and last batches) and are clamped to engine.STAGING_BYTES_CAP of
+pixels for large images.
 All images must have the size of the first one; a different size raises ``RaggedImages`` and the caller falls back to the
 DataLoader path (ragged crop directories are O-FID's, which keeps that path).
 """
@@ -34,7 +40,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._png_worker import (ERRTXT_BYTES, HDR_CHUNK, HDR_CONSUMED, HDR_DONE_OFF, HDR_ERR, HDR_ERRTXT_OFF, HDR_FILES_OFF, HDR_H,
+from ._png_worker import (ERRTXT_BYTES, HDR_CHUNK, HDR_CONSUMED, HDR_DONE_OFF, HDR_ERR, HDR_ERRTXT_OFF, HDR_FILES_OFF, HDR_H, HDR_IMG_BYTES,
                           HDR_NCHUNKS, HDR_NEXT, HDR_NFILES, HDR_NSLOTS, HDR_RGBONLY, HDR_STARTED, HDR_STOP, HDR_W, HDR_WORDS)
 
 _WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_png_worker.py")
@@ -50,8 +56,15 @@ from .hostinfo import usable_cpus  # noqa: E402,F401  (affinity and cgroup CPU q
 
 def auto_workers(world=1):
     """Decode processes of one rank: the CPUs the process may really use (usable_cpus: affinity and cgroup quota; at most
-    128) shared by the ranks of the node, at least 2.  The parent needs little CPU of its own (it copies no pixel)."""
+    128) shared by the ranks of the node, at least 2.  The parent needs little CPU of its own (it copies no pixel).
+    On this pool's boxes (16 CPUs of quota): 16 at world 1, 8 / 4 / 2 at world 2 / 4 / 8."""
     return max(2, min(128, usable_cpus()) // max(1, world))
+
+
+def unfilter_on_device(device):
+    """Where the PNG row filters are reversed for a consumer on ``device``: on the GPU (default for a HIP device) unless
+    TISE_PNG_UNFILTER=host; a host consumer (iter_host, the u8 cache build) always gets pixels."""
+    return torch.device(device).type == "cuda" and os.environ.get("TISE_PNG_UNFILTER", "device") != "host"
 
 
 class PngRingLoader:
@@ -76,6 +89,8 @@ class PngRingLoader:
         self.t_started = None
         self.on_all_decoded = None                                            # hook: called once when the last chunk is in the ring
         self.rgb_only = bool(rgb_only)                                        # RGBA / palette / gray files are refused (RaggedImages) instead of converted
+        self.framed = unfilter_on_device(self.device)                         # slots = [header | filtered rows]: the GPU reverses the filters
+        self.feeder = None
         if self.n_rows and start:
             self.start()
 
@@ -91,6 +106,21 @@ class PngRingLoader:
             w, h = im.size
         self.h, self.w = h, w
         img_bytes = h * w * 3
+        if self.framed:
+            from . import _png_worker
+            lib = _png_worker.load_decoder()
+            bpp = 0
+            if lib is not None:
+                import ctypes
+                with open(self.files[0], "rb") as fh_:
+                    blob = fh_.read()
+                gw, gh, pc = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+                if lib.tise_png_probe(blob, len(blob), ctypes.byref(gw), ctypes.byref(gh), ctypes.byref(pc)) == 0:
+                    bpp = pc.value                                             # 3 or 4: the slots are sized for the first file's format
+            if lib is None or bpp == 0 or w * bpp + 1 > 8192:
+                self.framed = False                                            # no native decoder / a first file outside its subset / rows beyond the kernel's tile
+            else:
+                img_bytes = int(lib.tise_png_slot_bytes(h, w, bpp))
         n_chunks = -(-self.n_rows // self.chunk)
         self.workers = max(1, min(self.workers, n_chunks))
         # slots: two per worker (one being written, one waiting for its copy), capped at 1 GiB of pinned pixels
@@ -116,6 +146,7 @@ class PngRingLoader:
         self.hdr[HDR_H], self.hdr[HDR_W], self.hdr[HDR_NFILES] = h, w, len(names)
         self.hdr[HDR_FILES_OFF], self.hdr[HDR_DONE_OFF], self.hdr[HDR_ERRTXT_OFF] = files_off, done_off, err_off
         self.hdr[HDR_RGBONLY] = 1 if self.rgb_only else 0
+        self.hdr[HDR_IMG_BYTES] = img_bytes
         self.done = np.frombuffer(self.ctl, dtype=np.uint8, count=n_chunks, offset=done_off)
         np.frombuffer(self.ctl, dtype=np.int64, count=len(names) + 1, offset=files_off)[:] = offs
         blob_off = files_off + 8 * (len(names) + 1)
@@ -169,6 +200,9 @@ class PngRingLoader:
         img_data.build_u8_cache and by the CPU tests of the worker protocol."""
         if not self.n_rows:
             return
+        if self.procs and self.framed:
+            raise RuntimeError("iter_host needs pixel slots: construct the loader with a host device (or TISE_PNG_UNFILTER=host)")
+        self.framed = False
         self.start()
         stop = threading.Event()
         slots = np.frombuffer(self.ring, dtype=np.uint8).reshape(self.nslots, self.chunk, self.h, self.w, 3)
@@ -184,19 +218,33 @@ class PngRingLoader:
             self.close()
 
     # ---- iteration: device batches --------------------------------------------------------------------------------------
+    def item_sizes(self):
+        """Rows of the consecutive device batches: engine.item_schedule over ``group`` loader batches at most, clamped so that
+        one staging buffer holds at most STAGING_BYTES_CAP of pixels (the callers size ``group`` for 256 x 256 images; 1024 x
+        1024 files get 341-image device batches, not 3 x 9.4 GB of buffers -- ADVICE r5)."""
+        from .engine import STAGING_BYTES_CAP, item_schedule
+        cap_rows = max(self.bs, STAGING_BYTES_CAP // max(1, self.h * self.w * 3) // self.bs * self.bs)
+        return item_schedule(self.n_rows, self.bs, min(self.bs * self.group, cap_rows))
+
     def __iter__(self):
         if not self.n_rows:
             return
         self.start()
         dev = self.device
-        item_rows = self.bs * self.group
-        nb = -(-self.n_rows // item_rows)
+        sizes = self.item_sizes()
+        starts = [0]
+        for r in sizes:
+            starts.append(starts[-1] + r)
+        nb = len(sizes)
         nbuf = min(self.NBUF, nb)
-        shape = (min(item_rows, self.n_rows), self.h, self.w, 3)
+        max_rows = max(sizes)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        bufs = [torch.empty(shape, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-        for t in bufs:
+        bufs = [torch.empty((max_rows, self.h, self.w, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        # device-unfilter feed: the slots of a device batch land in ONE staging buffer (copies and the unfilter kernel are
+        # stream-ordered on the side stream, so it is free again when the next batch's first copy starts)
+        raw = torch.empty((max_rows, self.img_bytes), dtype=torch.uint8, device=dev) if self.framed else None
+        for t in bufs + ([raw] if raw is not None else []):
             t.record_stream(side)
         ring_np = np.frombuffer(self.ring, dtype=np.uint8)
         ring_addr = ring_np.ctypes.data
@@ -225,8 +273,8 @@ class PngRingLoader:
                     if stop.is_set():
                         return
                     consumed[k].synchronize()                                 # the consumer's stream is done with buffer k
-                    r0, r1 = b * item_rows, min((b + 1) * item_rows, self.n_rows)
-                    base = bufs[k].data_ptr()
+                    r0, r1 = starts[b], starts[b + 1]
+                    base = raw.data_ptr() if self.framed else bufs[k].data_ptr()
                     r = r0
                     while r < r1:
                         c = r // chunk
@@ -248,6 +296,8 @@ class PngRingLoader:
                             ev.synchronize()
                             self.hdr[HDR_CONSUMED] = cc + 1
                         r = hi
+                    if self.framed:                                           # row filters + RGBA -> RGB on the GPU, behind the copies
+                        _lib.call("tise_png_unfilter_rgb8", raw.data_ptr(), r1 - r0, img_bytes, self.h, self.w, bufs[k].data_ptr(), side_h)
                     ready[k].record(side)
                     out.put((k, r1 - r0))
                 while inflight:
@@ -258,6 +308,7 @@ class PngRingLoader:
                 out.put(e)
 
         th = threading.Thread(target=feeder, name="tise-png-feeder", daemon=True)
+        self.feeder = (th, stop, handed, side)
         th.start()
         try:
             for b in range(nb):
@@ -267,7 +318,7 @@ class PngRingLoader:
                 k, rows = item
                 cur = torch.cuda.current_stream(dev)
                 if b == 1:
-                    self.first_item_rows = item_rows
+                    self.first_item_rows = sizes[0]
                     self.first_item_event = torch.cuda.Event(enable_timing=True)
                     self.first_item_event.record(cur)
                 cur.wait_event(ready[k])
@@ -278,12 +329,22 @@ class PngRingLoader:
                 self.last_item_event = torch.cuda.Event(enable_timing=True)
                 self.last_item_event.record(torch.cuda.current_stream(dev))
         finally:
-            stop.set()
-            for h in handed:
-                h.release()
-            th.join()
-            side.synchronize()
+            self._stop_feeder()
             self.close()
+
+    def _stop_feeder(self):
+        """Stop and join the feeder thread and drain the side stream: nothing may still enqueue copies from the ring, or have
+        one in flight, when close() unregisters and unmaps it (a consumer-side exception used to reach close()
+        with the generator suspended and the feeder alive)."""
+        if self.feeder is None:
+            return
+        th, stop, handed, side = self.feeder
+        self.feeder = None
+        stop.set()
+        for h in handed:
+            h.release()
+        th.join()
+        side.synchronize()
 
     def steady_seconds(self):
         """Device time between the end of the first and of the last device batch's work (None with fewer than two)."""
@@ -293,6 +354,7 @@ class PngRingLoader:
         return self.first_item_event.elapsed_time(self.last_item_event) * 1e-3
 
     def close(self):
+        self._stop_feeder()
         if self.ctl is not None:
             try:
                 self.hdr[HDR_STOP] = 1
