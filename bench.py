@@ -680,13 +680,16 @@ def png_feed_leg(eng, data, lo, n, feed_batch, mu_ref, sigma_ref, solver, dev):
         from_files()                                                # page cache, pinned-ring registration path, allocator
         wall, loop, fid, loader = from_files()
         return {"images_per_s": n / wall, "seconds": wall, "image_loop_seconds": loop, "images": n, "feed_batch": feed_batch,
-                "device_batch": limit, "decode_processes": loader.workers, "host_hardware_threads": os.cpu_count(),
+                "device_batch": limit, "device_batches": loader.item_sizes() if hasattr(loader, "h") else None,
+                "decode_processes": loader.workers, "native_workers": loader.native is not None,
+                "row_filters": "device (csrc/png_unfilter.hip; the workers only inflate)" if loader.framed else "host",
+                "host_hardware_threads": os.cpu_count(),
                 "host_usable_cpus": png_ring.usable_cpus(), "all_decoded_after_s": loader.decode_seconds,
                 "png_bytes_per_image": png_bytes, "write_seconds_untimed": t_write,
                 "resident_same_images_per_s": n / t_res, "ratio_to_resident": (n / wall) / (n / t_res),
                 "fid": fid, "dfid_vs_resident": abs(fid - fid_res),
-                "note": "whole job from PNG FILES: start of the decode processes + PNG decode (csrc/png_decode.c, Pillow for files outside "
-                        "its subset) + H2D + image loop + reduce + finalize + Frechet (one-call form) + IS*; the same images from HBM, same "
+                "note": "whole job from PNG FILES: start of the decode processes (csrc/png_worker.c) + zlib inflate (csrc/png_decode.c, Pillow "
+                        "for files outside its subset) + H2D + PNG row filters on the device (csrc/png_unfilter.hip) + image loop + reduce + finalize + Frechet (one-call form) + IS*; the same images from HBM, same "
                         "code path, alongside (resident_same_images_per_s); host_usable_cpus = affinity and cgroup CPU quota"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

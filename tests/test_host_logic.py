@@ -557,3 +557,52 @@ def test_ipc_default_is_set_before_any_gpu_call(monkeypatch):
     assert tdist.collective_timeout().total_seconds() == 120.0
     monkeypatch.setenv("TISE_DIST_TIMEOUT_S", "7.5")
     assert tdist.collective_timeout().total_seconds() == 7.5
+
+
+@pytest.mark.timeout(300)
+def test_png_ring_native_workers_hand_unsupported_files_to_pillow(tmp_path, monkeypatch):
+    """Round 6: the feed's first-line workers are the native program (csrc/png_worker.c).  Files outside its subset -- palette,
+    gray, 16-bit, interlaced PNGs, a JPEG -- make it hand the chunk back; Python fallback workers (started on demand) redo
+    those chunks with Pillow.  Pixels == Image.open(f).convert("RGB") for every file either way, in order; a directory with
+    no such file never starts a Python process; TISE_PNG_WORKER=python keeps the round-5 workers."""
+    from PIL import Image
+    from tests import _cases
+    from tise_toolbox_amd import png_ring
+    imgs = _cases.smooth_images(37, 40, 56, seed=21)
+    files = []
+    for i, im in enumerate(imgs):
+        p = tmp_path / f"{i:04d}.png"
+        pil = Image.fromarray(im)
+        if i % 9 == 2:
+            pil.convert("P").save(p)
+        elif i % 9 == 4:
+            pil.convert("L").save(p)
+        elif i == 15:
+            pil.convert("RGBA").save(p)
+        elif i == 20:
+            p = tmp_path / f"{i:04d}png.jpg"
+            pil.save(p, "JPEG")
+        else:
+            pil.save(p)
+        files.append(str(p))
+    want = np.stack([np.asarray(Image.open(f).convert("RGB")) for f in files])
+    assert png_ring.native_worker() is not None, "tise_png_worker was not built"
+    for env, native in (({}, True), ({"TISE_PNG_WORKER": "python"}, False)):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ld = png_ring.PngRingLoader(files, 1, "cpu", workers=3, chunk=4)
+        assert (ld.native is not None) == native
+        got = np.zeros_like(want)
+        for lo, view in ld.iter_host():
+            got[lo:lo + len(view)] = view
+            started_py = len(ld.py_procs)
+        assert np.array_equal(got, want)
+        assert (started_py > 0) == native                                 # the native workers needed Pillow's help; the Python ones are complete
+    monkeypatch.delenv("TISE_PNG_WORKER")
+    plain = [f for i, f in enumerate(files) if i % 9 not in (2, 4) and i != 20]
+    ld = png_ring.PngRingLoader(plain, 1, "cpu", workers=2, chunk=3)
+    n = 0
+    for lo, view in ld.iter_host():
+        n += len(view)
+        assert not ld.py_procs
+    assert n == len(plain)

@@ -11,6 +11,12 @@ tise_png_slot_bytes(h, w, bpp) = the device-unfilter format -- the worker only I
 header whose first byte names the payload: 0 RGB pixels, 3 / 4 filtered rows of that many bytes per pixel) and the GPU
 reverses the row filters (csrc/png_unfilter.hip); a file outside the subset is still decoded here (payload = pixels).
 
+Since round 6 the feed's first-line workers are the native program csrc/png_worker.c (same protocol, up in ~2 ms instead
+of the ~0.15 s this file needs to import numpy and Pillow); a chunk holding a file outside the native decoder's subset is
+handed back (done byte 3) and THIS program, started with ``--fallback``, redoes such chunks -- the native library again
+for the files it takes, Pillow for the rest.  Without ``--fallback`` it is the complete worker it always was
+(TISE_PNG_WORKER=python, or no native program built).
+
 Control block (int64 header, see png_ring.HDR_*):
     next_chunk   next chunk to claim (claimed under a POSIX record lock on the control file)
     consumed     chunks the parent has finished with, in order: chunk c may be written once c < consumed + nslots
@@ -29,8 +35,9 @@ import numpy as np
 from PIL import Image
 
 HDR_NEXT, HDR_CONSUMED, HDR_STOP, HDR_NCHUNKS, HDR_ERR, HDR_CHUNK, HDR_NSLOTS, HDR_H, HDR_W, HDR_NFILES, HDR_FILES_OFF, \
-    HDR_DONE_OFF, HDR_ERRTXT_OFF, HDR_STARTED, HDR_RGBONLY, HDR_IMG_BYTES = range(16)
-HDR_WORDS = 16
+    HDR_DONE_OFF, HDR_ERRTXT_OFF, HDR_STARTED, HDR_RGBONLY, HDR_IMG_BYTES, HDR_NEED_PY = range(17)
+HDR_WORDS = 24
+DONE_OK, DONE_FAILED, DONE_HANDED_BACK, DONE_REDOING = 1, 2, 3, 4     # chunk states (0: not decoded yet); csrc/png_worker.c writes 1 / 2 / 3
 SLOT_HDR = 64          # csrc/png_decode.c: TISE_PNG_SLOT_HDR (device-unfilter slots: [64-byte header | payload])
 ERRTXT_BYTES = 1024
 
@@ -110,18 +117,33 @@ def main(argv):
     hdr[HDR_STARTED] += 1
     fcntl.lockf(ctl_fd, fcntl.LOCK_UN, 8, 0)
     parent = os.getppid()
+    fallback = len(argv) > 4 and argv[4] == "--fallback"
     while not hdr[HDR_STOP] and os.getppid() == parent:
-        fcntl.lockf(ctl_fd, fcntl.LOCK_EX, 8, 0)
-        c = int(hdr[HDR_NEXT])
-        if c < n_chunks:
-            hdr[HDR_NEXT] = c + 1
-        fcntl.lockf(ctl_fd, fcntl.LOCK_UN, 8, 0)
-        if c >= n_chunks:
-            break
-        while c >= int(hdr[HDR_CONSUMED]) + nslots:               # the slot still holds a chunk the parent has not copied
-            if hdr[HDR_STOP] or os.getppid() != parent:            # asked to leave, or the parent is gone
-                return 0
-            time.sleep(0.0005)
+        if fallback:
+            # redo chunks the native workers handed back (done == 3); leave when every chunk is decoded or failed
+            fcntl.lockf(ctl_fd, fcntl.LOCK_EX, 8, 0)
+            todo = np.flatnonzero(done == DONE_HANDED_BACK)
+            c = int(todo[0]) if todo.size else -1
+            if c >= 0:
+                done[c] = DONE_REDOING
+            fcntl.lockf(ctl_fd, fcntl.LOCK_UN, 8, 0)
+            if c < 0:
+                if bool(np.all((done == DONE_OK) | (done == DONE_FAILED))) or hdr[HDR_ERR]:
+                    break
+                time.sleep(0.001)
+                continue
+        else:
+            fcntl.lockf(ctl_fd, fcntl.LOCK_EX, 8, 0)
+            c = int(hdr[HDR_NEXT])
+            if c < n_chunks:
+                hdr[HDR_NEXT] = c + 1
+            fcntl.lockf(ctl_fd, fcntl.LOCK_UN, 8, 0)
+            if c >= n_chunks:
+                break
+            while c >= int(hdr[HDR_CONSUMED]) + nslots:               # the slot still holds a chunk the parent has not copied
+                if hdr[HDR_STOP] or os.getppid() != parent:            # asked to leave, or the parent is gone
+                    return 0
+                time.sleep(0.0005)
         dst = slots[c % nslots]
         lo, hi = c * chunk, min((c + 1) * chunk, n_files)
         try:

@@ -33,15 +33,26 @@ PNG_LIB = os.path.join(HERE, "libtise_png.so")
 PNG_SRC = os.path.join(CSRC, "png_decode.c")
 
 
+PNG_WORKER = os.path.join(HERE, "tise_png_worker")
+PNG_WORKER_SRC = os.path.join(CSRC, "png_worker.c")
+
+
 def build_png(force=False, verbose=True):
-    """gcc over csrc/png_decode.c -> tise_toolbox_amd/libtise_png.so: the host-side PNG decoder of the image feed's worker
-    processes (plain C, links zlib, dlopens libdeflate when present; no HIP, so a worker never loads the GPU runtime)."""
-    if not force and os.path.exists(PNG_LIB) and os.path.getmtime(PNG_LIB) >= os.path.getmtime(PNG_SRC):
-        return PNG_LIB
-    cmd = [os.environ.get("CC", "gcc"), "-O3", "-mssse3", "-msse4.1", "-fPIC", "-shared", "-o", PNG_LIB, PNG_SRC, "-lz", "-ldl"]
-    if verbose:
-        print("[tise build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    """gcc over csrc/png_decode.c -> tise_toolbox_amd/libtise_png.so: the host-side PNG decoder of the image feed (plain C,
+    links zlib, dlopens libdeflate when present; no HIP, so a worker never loads the GPU runtime); and over
+    csrc/png_worker.c + png_decode.c -> tise_toolbox_amd/tise_png_worker: the native decode process of the feed."""
+    cc = os.environ.get("CC", "gcc")
+    newest = max(os.path.getmtime(PNG_SRC), os.path.getmtime(PNG_WORKER_SRC))
+    if force or not os.path.exists(PNG_LIB) or os.path.getmtime(PNG_LIB) < os.path.getmtime(PNG_SRC):
+        cmd = [cc, "-O3", "-mssse3", "-msse4.1", "-fPIC", "-shared", "-o", PNG_LIB, PNG_SRC, "-lz", "-ldl"]
+        if verbose:
+            print("[tise build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    if force or not os.path.exists(PNG_WORKER) or os.path.getmtime(PNG_WORKER) < newest:
+        cmd = [cc, "-O3", "-mssse3", "-msse4.1", "-o", PNG_WORKER, PNG_WORKER_SRC, PNG_SRC, "-lz", "-ldl"]
+        if verbose:
+            print("[tise build]", " ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
     return PNG_LIB
 
 

@@ -40,10 +40,20 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._png_worker import (ERRTXT_BYTES, HDR_CHUNK, HDR_CONSUMED, HDR_DONE_OFF, HDR_ERR, HDR_ERRTXT_OFF, HDR_FILES_OFF, HDR_H, HDR_IMG_BYTES,
-                          HDR_NCHUNKS, HDR_NEXT, HDR_NFILES, HDR_NSLOTS, HDR_RGBONLY, HDR_STARTED, HDR_STOP, HDR_W, HDR_WORDS)
+from ._png_worker import (DONE_FAILED, DONE_OK, ERRTXT_BYTES, HDR_CHUNK, HDR_CONSUMED, HDR_DONE_OFF, HDR_ERR, HDR_ERRTXT_OFF, HDR_FILES_OFF, HDR_H,
+                          HDR_IMG_BYTES, HDR_NCHUNKS, HDR_NEED_PY, HDR_NEXT, HDR_NFILES, HDR_NSLOTS, HDR_RGBONLY, HDR_STARTED, HDR_STOP, HDR_W,
+                          HDR_WORDS)
 
 _WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_png_worker.py")
+_NATIVE_WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tise_png_worker")     # csrc/png_worker.c (build.build_png)
+
+
+def native_worker():
+    """Path of the native decode program, or None (not built, TISE_PNG_WORKER=python, or TISE_PNG_DECODER=pillow -- every
+    file through Pillow -- asked for the Python workers)."""
+    if os.environ.get("TISE_PNG_WORKER", "native") == "python" or os.environ.get("TISE_PNG_DECODER", "native") == "pillow":
+        return None
+    return _NATIVE_WORKER if os.access(_NATIVE_WORKER, os.X_OK) else None
 
 
 class RaggedImages(ValueError):
@@ -91,6 +101,8 @@ class PngRingLoader:
         self.rgb_only = bool(rgb_only)                                        # RGBA / palette / gray files are refused (RaggedImages) instead of converted
         self.framed = unfilter_on_device(self.device)                         # slots = [header | filtered rows]: the GPU reverses the filters
         self.feeder = None
+        self.py_procs = []                                                    # Python fallback workers (started when a native worker hands a chunk back)
+        self.native = None
         if self.n_rows and start:
             self.start()
 
@@ -151,16 +163,36 @@ class PngRingLoader:
         np.frombuffer(self.ctl, dtype=np.int64, count=len(names) + 1, offset=files_off)[:] = offs
         blob_off = files_off + 8 * (len(names) + 1)
         self.ctl[blob_off:blob_off + int(offs[-1])] = b"".join(names)
+        self.native = native_worker()
+        self.t_started = time.perf_counter()
+        if self.native is not None:
+            # first-line workers: the native program (up in ~2 ms; csrc/png_worker.c).  Chunks it hands back (a file outside
+            # its subset) are redone by Python workers started on demand (_start_fallback)
+            cmd = [self.native, str(self.ring_fd), str(self.ctl_fd), str(self.ring_size), str(self.ctl_size)]
+            for _ in range(self.workers):
+                self.procs.append(subprocess.Popen(cmd, pass_fds=(self.ring_fd, self.ctl_fd), stdin=subprocess.DEVNULL))
+        else:
+            for _ in range(self.workers):
+                self.procs.append(self._python_worker(fallback=False))
+        return self
+
+    def _python_worker(self, fallback):
         cmd = [sys.executable, "-S", _WORKER, str(self.ring_fd), str(self.ctl_fd), str(self.ring_size), str(self.ctl_size)]
+        if fallback:
+            cmd.append("--fallback")
         env = dict(os.environ)
         # site-packages must stay importable under -S (numpy, Pillow): hand the parent's path over
         env["PYTHONPATH"] = os.pathsep.join(p for p in sys.path if p)
         for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
             env[k] = "1"
-        self.t_started = time.perf_counter()
-        for _ in range(self.workers):
-            self.procs.append(subprocess.Popen(cmd, env=env, pass_fds=(self.ring_fd, self.ctl_fd), stdin=subprocess.DEVNULL))
-        return self
+        return subprocess.Popen(cmd, env=env, pass_fds=(self.ring_fd, self.ctl_fd), stdin=subprocess.DEVNULL)
+
+    def _start_fallback(self):
+        """A native worker met a file it does not decode and handed its chunk back (done byte 3, header NEED_PY): start the
+        Python workers that redo such chunks with Pillow -- as many as there are native ones (a directory of JPEGs hands
+        EVERY chunk back, and the native workers then cost nothing)."""
+        if not self.py_procs and self.ctl is not None:
+            self.py_procs = [self._python_worker(fallback=True) for _ in range(self.workers)]
 
     def _error(self):
         o = int(self.hdr[HDR_ERRTXT_OFF])
@@ -172,25 +204,28 @@ class PngRingLoader:
     def _wait_chunk(self, c, stop):
         """Block until chunk c is decoded (done byte set); raises on a worker error or a dead worker."""
         spins = 0
-        while not self.done[c]:
+        while self.done[c] not in (DONE_OK, DONE_FAILED):                     # 0 not decoded yet, 3 handed back, 4 being redone
             if stop.is_set():
                 return False
+            if self.hdr[HDR_NEED_PY] and not self.py_procs:
+                self._start_fallback()
             spins += 1
             if spins % 2000 == 0:                                             # ~ every 0.4 s: is anybody still alive?
                 if self.hdr[HDR_ERR]:
                     raise self._error()
-                codes = [p.poll() for p in self.procs]
+                codes = [p.poll() for p in self.procs + self.py_procs]
+                pending = self.done[c] not in (DONE_OK, DONE_FAILED)
                 # a worker that was killed (out of memory, a signal) may hold a claimed chunk that nobody will ever finish: the others
                 # keep running until the ring is full and then wait for this consumer, which waits for that chunk -- so ANY abnormal
                 # exit is an error here, not only the death of all of them
-                if any(rc not in (None, 0) for rc in codes) and not self.done[c]:
+                if any(rc not in (None, 0) for rc in codes) and pending:
                     raise RuntimeError("a png decode worker died before the ring was complete "
                                        f"(exit codes {sorted(set(rc for rc in codes if rc is not None))})")
-                if all(rc is not None for rc in codes) and not self.done[c]:
+                if all(rc is not None for rc in codes) and pending and not (self.hdr[HDR_NEED_PY] and not self.py_procs):
                     raise RuntimeError("png decode workers exited before the ring was complete "
                                        f"(exit codes {sorted(set(codes))})")
             time.sleep(0.0002)
-        if self.done[c] == 2:
+        if self.done[c] == DONE_FAILED:
             raise self._error()
         return True
 
@@ -360,13 +395,13 @@ class PngRingLoader:
                 self.hdr[HDR_STOP] = 1
             except (ValueError, TypeError):
                 pass
-        for p in self.procs:
+        for p in self.procs + self.py_procs:
             try:
                 p.wait(timeout=5)
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
-        self.procs = []
+        self.procs, self.py_procs = [], []
         if self.registered:
             try:
                 addr = np.frombuffer(self.ring, dtype=np.uint8).ctypes.data
