@@ -502,11 +502,11 @@ def test_item_schedule_properties(monkeypatch):
     last batches, a pure function of its arguments (every feed uses it: same files, same fp64 sums)."""
     from tise_toolbox_amd.engine import item_schedule
     monkeypatch.delenv("TISE_RAMP", raising=False)
-    assert item_schedule(30000, 50, 3000) == [500, 1000] + [3000] * 9 + [1000, 500]
-    assert item_schedule(12000, 50, 3000) == [500, 1000, 3000, 3000, 3000, 1000, 500]
-    assert item_schedule(3750, 50, 3000) == [500, 1000, 750, 1000, 500]            # a rank's share at 8 GPUs
+    assert item_schedule(30000, 50, 3000) == [50, 100, 250, 500, 1000, 1000, 1500, 2000, 2800, 2800] + [2750] * 6 + [1000, 500]
+    assert item_schedule(12000, 50, 3000) == [50, 100, 250, 500, 1000, 1000, 1500, 2000, 2050, 2050, 1000, 500]
+    assert item_schedule(3750, 50, 3000) == [50, 100, 250, 500, 1350, 1000, 500]            # a rank's share at 8 GPUs
     assert item_schedule(45, 5, 3000) == [45] and item_schedule(45, 5, 15) == [15, 15, 15] and item_schedule(0, 5, 15) == []
-    assert item_schedule(2000, 50, 3000) == [500, 1000, 500]
+    assert item_schedule(500, 50, 3000) == [50, 100, 350] and item_schedule(80, 1, 3000) == [80]
     rng = np.random.default_rng(0)
     for _ in range(300):
         bs = int(rng.integers(1, 130))

@@ -289,7 +289,8 @@ def device_batch_images(batch_size, image_bytes=256 * 256 * 3):
     return max(1, target // max(1, int(batch_size))) * int(batch_size)
 
 
-RAMP_IMAGES = (512, 1024)       # first (and, mirrored, last) device batches of a fed image set: see item_schedule
+RAMP_HEAD = (64, 128, 256, 512, 1024, 1024, 1536, 2048)     # first device batches of a fed image set (images; rounded to loader batches)
+RAMP_TAIL = (1024, 512)                                      # last ones: see item_schedule
 
 
 def item_schedule(n_rows, batch_size, limit):
@@ -298,15 +299,21 @@ def item_schedule(n_rows, batch_size, limit):
 
     A fixed device batch of 3000 images makes the trunk wait for the first 3000 decoded images (~0.135 s of a 0.46 s job
     from 12 000 files) and, when decode is the slower side, start its last 3000 only after the last file.
-    So the set opens with ~512 and ~1024 images (TISE_RAMP=0: off), closes with the mirror image, and runs equal batches of
-    at most ``limit`` in between.  Features are bit for bit independent of the batching (tests/test_gpu_kernels.py: batch
-    invariance); the fp64 sums depend on it in the last bits, which is why the schedule is a pure function of
-    (n_rows, batch_size, limit) and EVERY feed of the CLIs uses it: same files -> the same FID to the last bit."""
+    Measured in round 6 (tools/png_feed_probe.py, profiles/r06c_png_feed_timeline.txt): sixteen inflate-only workers deliver
+    ~36 k images/s against the trunk's 25.7 k, so after a start at [500, 1000] the jump to 3000 still left the device idle
+    for 22 ms, and the first 500 images cost 29 ms before anything ran.  So the set opens with a geometric ramp from ~64
+    images (a starved device loses nothing on a small pass), grows by at most ~1.5 x per batch towards ``limit`` (what a
+    decoder 1.3 x faster than the trunk can keep up with), and closes with two short batches (the device's last pass is
+    what remains after the last file is decoded).  TISE_RAMP=0: equal batches.  Features are bit for bit independent of
+    the batching (tests/test_gpu_kernels.py: batch invariance); the fp64 sums depend on it in the last bits, which is why
+    the schedule is a pure function of (n_rows, batch_size, limit) and EVERY feed of the CLIs uses it: same files -> the
+    same FID to the last bit."""
     bs = max(1, int(batch_size))
     limit = max(bs, (int(limit) // bs) * bs)
     n_rows = int(n_rows)
     if n_rows <= 0:
         return []
+
     def equal(n):                                           # n images (whole loader batches) in the fewest near-equal batches <= limit
         if n <= 0:
             return []
@@ -317,12 +324,21 @@ def item_schedule(n_rows, batch_size, limit):
             out[-1] += n % bs                                # (callers pass whole batches; kept total for any n)
         return out
 
-    ramp = [] if os.environ.get("TISE_RAMP", "1") == "0" else [min(limit, max(bs, (r // bs) * bs)) for r in RAMP_IMAGES]
-    if ramp and n_rows >= 2 * sum(ramp) + bs:
-        return ramp + equal(n_rows - 2 * sum(ramp)) + ramp[::-1]
-    if ramp and n_rows >= 4 * ramp[0]:                      # a rank's share at 8 GPUs, small sets: one short batch either side
-        return ramp[:1] + equal(n_rows - 2 * ramp[0]) + ramp[:1]
-    return equal(n_rows)
+    if os.environ.get("TISE_RAMP", "1") == "0":
+        return equal(n_rows)
+    rnd = lambda r: max(bs, (r // bs) * bs)                 # noqa: E731
+    tail = [rnd(r) for r in RAMP_TAIL if rnd(r) < limit]
+    if n_rows < sum(tail) + rnd(RAMP_HEAD[0]) + bs:
+        tail = []
+    rem = n_rows - sum(tail)
+    head = []
+    for r in RAMP_HEAD:
+        r = rnd(r)
+        if r >= limit or rem - r < r:                       # the ramp has reached the full batch, or what is left is no bigger than the step
+            break
+        head.append(r)
+        rem -= r
+    return head + equal(rem) + tail
 
 
 def coalesce_u8(batches, dev, limit, schedule=None):

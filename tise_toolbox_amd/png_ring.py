@@ -66,15 +66,77 @@ from .hostinfo import usable_cpus  # noqa: E402,F401  (affinity and cgroup CPU q
 
 def auto_workers(world=1):
     """Decode processes of one rank: the CPUs the process may really use (usable_cpus: affinity and cgroup quota; at most
-    128) shared by the ranks of the node, at least 2.  The parent needs little CPU of its own (it copies no pixel).
-    On this pool's boxes (16 CPUs of quota): 16 at world 1, 8 / 4 / 2 at world 2 / 4 / 8."""
-    return max(2, min(128, usable_cpus()) // max(1, world))
+    128) minus a reserve for the ranks' own threads (launching kernels, the feeder), shared by the ranks of the node, at
+    least 2.  Under a CFS quota every runnable thread beyond it gets the WHOLE cgroup throttled in bursts -- the kernel
+    launches included; measured on this pool's boxes (16 CPUs of quota; tools/png_feed_probe.py,
+    profiles/r06c_png_feed_timeline.txt): 16 / 14 / 12 / 10 / 8 inflate-only workers feed 23.2 / 23.1 / 23.0 / 22.4 / 20.5 k
+    images/s of a 25 k job, with two runs at 14-15 workers collapsing to 16 k when the box throttled.
+    On these boxes: 14 at world 1, 7 / 3 / 2 at world 2 / 4 / 8."""
+    n = min(128, usable_cpus())
+    return max(2, (n - max(2, n // 8)) // max(1, world))
 
 
 def unfilter_on_device(device):
     """Where the PNG row filters are reversed for a consumer on ``device``: on the GPU (default for a HIP device) unless
     TISE_PNG_UNFILTER=host; a host consumer (iter_host, the u8 cache build) always gets pixels."""
     return torch.device(device).type == "cuda" and os.environ.get("TISE_PNG_UNFILTER", "device") != "host"
+
+
+# One pixel ring is kept alive between loaders of a process (the two directories of an FID run, repeated evaluations): page-locking
+# 57 MB costs ~8 ms (hipHostRegister) and the first copy out of freshly registered pages another ~5 ms
+# (tools/ring_setup_probe.py, profiles/r06c_png_feed_timeline.txt) -- more than the decode of the first device batch.
+_RING_POOL = {"fd": -1, "map": None, "size": 0, "registered_on": None}
+_POOL_LOCK = threading.Lock()
+
+
+def _pool_take(size):
+    """(fd, mmap, device it is page-locked for | None) of a parked ring of exactly ``size`` bytes, or a fresh one."""
+    with _POOL_LOCK:
+        if _RING_POOL["map"] is not None and _RING_POOL["size"] == size:
+            out = (_RING_POOL["fd"], _RING_POOL["map"], _RING_POOL["registered_on"])
+            _RING_POOL.update(fd=-1, map=None, size=0, registered_on=None)
+            return out
+    fd = os.memfd_create("tise_png_ring")
+    os.ftruncate(fd, size)
+    return fd, mmap.mmap(fd, size), None
+
+
+def _pool_release(fd, m, registered_on):
+    """Unregister, unmap and close a ring."""
+    if m is None:
+        return
+    if registered_on is not None:
+        try:
+            addr = np.frombuffer(m, dtype=np.uint8).ctypes.data
+            with torch.cuda.device(registered_on):
+                _lib.call("tise_host_unregister", addr)
+        except Exception:                                                     # noqa: BLE001
+            pass
+    try:
+        m.close()
+    except (BufferError, ValueError):                                         # a numpy view still alive: the fd close below frees it with the process
+        pass
+    if fd >= 0:
+        os.close(fd)
+
+
+def _pool_park(fd, m, size, registered_on):
+    """Keep this ring for the next loader (one ring at most: whatever was parked before is released)."""
+    with _POOL_LOCK:
+        old = (_RING_POOL["fd"], _RING_POOL["map"], _RING_POOL["registered_on"])
+        _RING_POOL.update(fd=fd, map=m, size=size, registered_on=registered_on)
+    _pool_release(*old)
+
+
+def _pool_drop():
+    with _POOL_LOCK:
+        old = (_RING_POOL["fd"], _RING_POOL["map"], _RING_POOL["registered_on"])
+        _RING_POOL.update(fd=-1, map=None, size=0, registered_on=None)
+    _pool_release(*old)
+
+
+import atexit  # noqa: E402
+atexit.register(_pool_drop)
 
 
 class PngRingLoader:
@@ -92,7 +154,7 @@ class PngRingLoader:
         self.chunk = max(1, int(chunk))
         self.procs, self.ring, self.ctl = [], None, None
         self.ring_fd = self.ctl_fd = -1
-        self.registered = False
+        self.registered, self.registered_on = False, None
         self.decode_seconds = None
         self.first_item_event = self.last_item_event = None
         self.first_item_rows = 0
@@ -101,6 +163,7 @@ class PngRingLoader:
         self.rgb_only = bool(rgb_only)                                        # RGBA / palette / gray files are refused (RaggedImages) instead of converted
         self.framed = unfilter_on_device(self.device)                         # slots = [header | filtered rows]: the GPU reverses the filters
         self.feeder = None
+        self.wait_decode_seconds = self.wait_buffer_seconds = 0.0             # feeder thread: waiting for a decoded chunk / for a free device buffer
         self.py_procs = []                                                    # Python fallback workers (started when a native worker hands a chunk back)
         self.native = None
         if self.n_rows and start:
@@ -147,11 +210,10 @@ class PngRingLoader:
         self.ctl_size = files_off + 8 * (len(names) + 1) + int(offs[-1]) + 8
         self.ring_size = nslots * self.chunk * img_bytes
         self.ctl_fd = os.memfd_create("tise_png_ctl")
-        self.ring_fd = os.memfd_create("tise_png_ring")
         os.ftruncate(self.ctl_fd, self.ctl_size)
-        os.ftruncate(self.ring_fd, self.ring_size)
         self.ctl = mmap.mmap(self.ctl_fd, self.ctl_size)
-        self.ring = mmap.mmap(self.ring_fd, self.ring_size)
+        self.ring_fd, self.ring, self.registered_on = _pool_take(self.ring_size)
+        self.registered = self.registered_on is not None
         self.hdr = np.frombuffer(self.ctl, dtype=np.int64, count=HDR_WORDS)
         self.hdr[:] = 0
         self.hdr[HDR_NCHUNKS], self.hdr[HDR_CHUNK], self.hdr[HDR_NSLOTS] = n_chunks, self.chunk, nslots
@@ -283,12 +345,17 @@ class PngRingLoader:
             t.record_stream(side)
         ring_np = np.frombuffer(self.ring, dtype=np.uint8)
         ring_addr = ring_np.ctypes.data
-        with torch.cuda.device(dev):
-            try:
-                _lib.call("tise_host_register", ring_addr, self.ring_size)
-                self.registered = True
-            except _lib.TiseStatusError as e:                                 # not fatal: the copies become synchronous
-                print(f"[tise] png ring: hipHostRegister failed ({e}); host->device copies will be staged", file=sys.stderr)
+        if self.registered and self.registered_on != dev:                     # a parked ring page-locked for another GPU of this process
+            with torch.cuda.device(self.registered_on):
+                _lib.call("tise_host_unregister", ring_addr)
+            self.registered, self.registered_on = False, None
+        if not self.registered:
+            with torch.cuda.device(dev):
+                try:
+                    _lib.call("tise_host_register", ring_addr, self.ring_size)
+                    self.registered, self.registered_on = True, dev
+                except _lib.TiseStatusError as e:                             # not fatal: the copies become synchronous
+                    print(f"[tise] png ring: hipHostRegister failed ({e}); host->device copies will be staged", file=sys.stderr)
         ready = [torch.cuda.Event() for _ in range(nbuf)]
         consumed = [torch.cuda.Event() for _ in range(nbuf)]
         handed = [threading.Semaphore(1) for _ in range(nbuf)]
@@ -304,17 +371,21 @@ class PngRingLoader:
                 c = 0
                 for b in range(nb):
                     k = b % nbuf
+                    tw = time.perf_counter()
                     handed[k].acquire()
                     if stop.is_set():
                         return
                     consumed[k].synchronize()                                 # the consumer's stream is done with buffer k
+                    self.wait_buffer_seconds += time.perf_counter() - tw
                     r0, r1 = starts[b], starts[b + 1]
                     base = raw.data_ptr() if self.framed else bufs[k].data_ptr()
                     r = r0
                     while r < r1:
                         c = r // chunk
+                        tw = time.perf_counter()
                         if not self._wait_chunk(c, stop):
                             return
+                        self.wait_decode_seconds += time.perf_counter() - tw
                         hi = min((c + 1) * chunk, r1, self.n_rows)
                         src = ring_addr + ((c % self.nslots) * chunk + (r - c * chunk)) * img_bytes
                         _lib.call("tise_memcpy_h2d_async", base + (r - r0) * img_bytes, src, (hi - r) * img_bytes, side_h)
@@ -402,26 +473,24 @@ class PngRingLoader:
                 p.kill()
                 p.wait()
         self.procs, self.py_procs = [], []
-        if self.registered:
-            try:
-                addr = np.frombuffer(self.ring, dtype=np.uint8).ctypes.data
-                with torch.cuda.device(self.device):
-                    _lib.call("tise_host_unregister", addr)
-            except Exception:                                                 # noqa: BLE001
-                pass
-            self.registered = False
         self.hdr = self.done = None
-        for m in (self.ring, self.ctl):
-            if m is not None:
-                try:
-                    m.close()
-                except (BufferError, ValueError):                             # a numpy view still alive: the fd close below frees it with the process
-                    pass
-        self.ring = self.ctl = None
-        for fd in (self.ring_fd, self.ctl_fd):
-            if fd >= 0:
-                os.close(fd)
-        self.ring_fd = self.ctl_fd = -1
+        if self.ctl is not None:
+            try:
+                self.ctl.close()
+            except (BufferError, ValueError):                                 # a numpy view still alive: the fd close below frees it with the process
+                pass
+        self.ctl = None
+        if self.ctl_fd >= 0:
+            os.close(self.ctl_fd)
+        self.ctl_fd = -1
+        if self.ring is not None:
+            # every worker has exited and the feeder is joined: nobody writes the ring any more.  A page-locked ring is parked for
+            # the next loader of this process (TISE_PNG_RING_POOL=0: released), anything else is released now
+            if self.registered and os.environ.get("TISE_PNG_RING_POOL", "1") != "0":
+                _pool_park(self.ring_fd, self.ring, self.ring_size, self.registered_on)
+            else:
+                _pool_release(self.ring_fd, self.ring, self.registered_on if self.registered else None)
+        self.ring, self.ring_fd, self.registered, self.registered_on = None, -1, False, None
 
     def __del__(self):
         try:
