@@ -253,7 +253,10 @@ def main():
                     help="skip the host_feed leg (N = 1, after the timed region: the same job fed from pinned HOST memory in "
                          "--feed-batch slices, as the CLI's --u8-cache path feeds it; reported next to `value`, never instead of it)")
     ap.add_argument("--feed-batch", type=int, default=50, help="loader batch of the host_feed leg (README.md:214-219: 50)")
-    ap.add_argument("--png-images", type=int, default=12000,
+    ap.add_argument("--no-cli-process", action="store_true",
+                    help="skip the cli_process object (N = 1, after the timed region: the README recipe `python -m tise_toolbox_amd.fid_score "
+                         "--path1 ref.npz --path2 DIR` run as a FRESH CHILD PROCESS on the png_feed files, wall clock + TISE_TIMING phases)")
+    ap.add_argument("--png-images", type=int, default=30000,
                     help="png_feed leg (N = 1, after the timed region, never `value`): this many images of the timed set are written as "
                          "PNG files and the job is run from the FILES through the CLIs' feed (png_ring.py); 0 skips the leg")
     args = ap.parse_args()
@@ -526,7 +529,9 @@ def main():
                                              float(res["fid"]), n_total / elapsed)
         out["png_feed"] = None
         if world == 1 and args.png_images > 0:
-            out["png_feed"] = png_feed_leg(eng, data, lo, min(args.png_images, n_rank), args.feed_batch, mu_ref, sigma_ref, solver, dev)
+            out["png_feed"] = png_feed_leg(eng, data, lo, min(args.png_images, n_rank), args.feed_batch, mu_ref, sigma_ref, solver, dev,
+                                           cli=not args.no_cli_process)
+            out["cli_process"] = out["png_feed"].pop("cli_process", None)
         if world == 1 and not args.no_cpu_baseline:
             # ---- CPU oracle on the first images of the timed set: the baseline AND the parity figures --------
             n_cpu = max(50, (min(args.cpu_sample, n_rank) // 50) * 50)
@@ -618,7 +623,50 @@ def _write_pngs(args):
     return hi - lo
 
 
-def png_feed_leg(eng, data, lo, n, feed_batch, mu_ref, sigma_ref, solver, dev):
+def cli_process_leg(png_dir, n, feed_batch, mu_ref, sigma_ref, tmp, fid_feed):
+    """What a USER waits for: the README recipe (README.md:214-219 of the reference: fid_score.py
+    --batch-size 50 --path1 <stats .npz> --path2 <image dir>) as a fresh child process -- interpreter start, imports, HIP
+    context, model + engine, the image loop from PNG files, the Frechet distance, exit -- timed from outside with a wall
+    clock, twice (the second run finds the page cache, the stand-in cache and the code objects warm).  The child is started
+    with subprocess (a new process; this one is never replaced).  Never `value`."""
+    import subprocess
+    ref = os.path.join(tmp, "ref_stats.npz")
+    np.savez(ref, mu=mu_ref.cpu().numpy(), sigma=sigma_ref.cpu().numpy())
+    outf = os.path.join(tmp, "cli_out.txt")
+    cmd = [sys.executable, "-m", "tise_toolbox_amd.fid_score", "--batch-size", str(feed_batch), "--path1", ref, "--path2", png_dir,
+           "--synthetic-weights", "--saved_file", outf]
+    env = dict(os.environ, TISE_TIMING="1")
+    env["PYTHONPATH"] = os.pathsep.join([ROOT] + [p for p in env.get("PYTHONPATH", "").split(os.pathsep) if p])
+    runs = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+        phases = {}
+        for ln in r.stderr.splitlines():
+            if ln.startswith("[tise timing] ") and " s after process start" in ln:
+                label, rest = ln[len("[tise timing] "):].rsplit(": ", 1)
+                phases[label.split(" (")[0]] = float(rest.split(" s after")[0])
+        feed = [ln for ln in r.stderr.splitlines() if ln.startswith("[tise] png feed")]
+        fid = None
+        try:
+            fid = float(open(outf).read().split("FID:")[1].split()[0])
+        except Exception:                                                  # noqa: BLE001
+            pass
+        runs.append({"seconds": wall, "returncode": r.returncode, "phases_s_after_process_start": phases,
+                     "feed_line": feed[-1][:400] if feed else None, "fid": fid,
+                     "stderr_tail": None if r.returncode == 0 else r.stderr[-600:]})
+    ok = all(x["returncode"] == 0 for x in runs)
+    return {"command": "python -m tise_toolbox_amd.fid_score --batch-size %d --path1 ref_stats.npz --path2 <dir of %d PNG files> --synthetic-weights"
+                       % (feed_batch, n),
+            "images": n, "seconds": runs[0]["seconds"], "seconds_second_run": runs[1]["seconds"],
+            "images_per_s": n / runs[0]["seconds"] if ok else None, "runs": runs,
+            "dfid_vs_png_feed": (abs(runs[1]["fid"] - fid_feed) if ok and runs[1]["fid"] is not None else None),
+            "note": "whole fresh child process, wall clock around subprocess.run: interpreter + imports + HIP context + model / engine + image "
+                    "loop from PNG files + Frechet distance + exit; phases from TISE_TIMING=1 (seconds after process start)"}
+
+
+def png_feed_leg(eng, data, lo, n, feed_batch, mu_ref, sigma_ref, solver, dev, cli=True):
     """Row a2 inside the bench: the first ``n`` images of the timed set are written as PNG FILES (Pillow, its default
     compression) and the job -- image loop + reduce + finalize + Frechet + IS* -- is run from the files through the feed of
     the drop-in CLIs: tise_toolbox_amd.png_ring (decode processes, csrc/png_decode.c -> shared page-locked ring ->
@@ -679,12 +727,15 @@ def png_feed_leg(eng, data, lo, n, feed_batch, mu_ref, sigma_ref, solver, dev):
         t_res = time.perf_counter() - t0
         from_files()                                                # page cache, pinned-ring registration path, allocator
         wall, loop, fid, loader = from_files()
-        return {"images_per_s": n / wall, "seconds": wall, "image_loop_seconds": loop, "images": n, "feed_batch": feed_batch,
+        cli_obj = cli_process_leg(d, n, feed_batch, mu_ref, sigma_ref, tmp, fid) if cli else None
+        return {"cli_process": cli_obj, "images_per_s": n / wall, "seconds": wall, "image_loop_seconds": loop, "images": n, "feed_batch": feed_batch,
                 "device_batch": limit, "device_batches": loader.item_sizes() if hasattr(loader, "h") else None,
                 "decode_processes": loader.workers, "native_workers": loader.native is not None,
                 "row_filters": "device (csrc/png_unfilter.hip; the workers only inflate)" if loader.framed else "host",
                 "host_hardware_threads": os.cpu_count(),
                 "host_usable_cpus": png_ring.usable_cpus(), "all_decoded_after_s": loader.decode_seconds,
+                "feeder_waited_s": {"for_decode": loader.wait_decode_seconds, "for_a_device_buffer": loader.wait_buffer_seconds,
+                                    "in_memcpy_calls": loader.enqueue_seconds, "for_copies_to_land": loader.wait_copy_seconds},
                 "png_bytes_per_image": png_bytes, "write_seconds_untimed": t_write,
                 "resident_same_images_per_s": n / t_res, "ratio_to_resident": (n / wall) / (n / t_res),
                 "fid": fid, "dfid_vs_resident": abs(fid - fid_res),

@@ -184,42 +184,47 @@ class SplitConv:
         self.cout_pad = max(-(-cout // (32 * t)) * 32 * t for t in (1, 2, 3, 4, 5))
         if self.variant == "pipe":                              # resident-weights sliding-window kernel (conv_pipe.hip)
             self.pipe_cfg = 34 if pipe_cfg is None else pipe_cfg
-            self._orig = (weight.detach().float().cpu(), bias.detach().float().cpu())       # see __call__
+            self._orig = (weight.detach().float(), bias.detach().float())                   # see __call__
         self.k = kh * kw * cin
         self.kpad = -(-self.k // 32) * 32
-        w = weight.detach().float().cpu()
+        # The packing runs ON THE DEVICE (round 6: 68 layers of host tensor arithmetic were 0.12 s of a CLI's start-up).  Every
+        # step is exact -- scaling by powers of two, permutations, zero padding, round-to-nearest-even conversions to fp16 --
+        # so host and device give the same bits; the power of two comes from frexp (the exponent field), not from log2.
+        dev = torch.device(device)
+        w = weight.detach().float().to(dev)
         amax = w.abs().reshape(cout, -1).amax(1).clamp_min(1e-30)
-        pre = torch.exp2(-torch.floor(torch.log2(amax)))            # exact powers of two: max |w * pre| in [1, 2)
+        _, ex = torch.frexp(amax)                                   # amax = m * 2**ex, m in [0.5, 1)
+        pre = torch.ldexp(torch.ones_like(amax), 1 - ex)            # exact powers of two: max |w * pre| in [1, 2)
         wk = (w * pre.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(cout, self.k)
-        wp = torch.zeros((self.cout_pad, self.kpad), dtype=torch.float32)
+        wp = torch.zeros((self.cout_pad, self.kpad), dtype=torch.float32, device=dev)
         wp[:cout, :self.k] = wk
-        self.w = split_planes(wp).to(device).contiguous()           # (2, Cout_pad, Kpad) fp16
+        self.w = split_planes(wp).contiguous()                      # (2, Cout_pad, Kpad) fp16
         if self.variant == "fast" and cin % 32 == 16:
             # default kernel, Cin = 32 * nfull + 16: K order = (tap, full 32-channel block) for all taps, then the
             # 16-channel tails two taps per 32-wide step (conv_split.hip, conv_split_fast_kernel)
             ntaps, nfull = kh * kw, cin // 32
-            w3 = torch.zeros((self.cout_pad, ntaps, cin), dtype=torch.float32)
+            w3 = torch.zeros((self.cout_pad, ntaps, cin), dtype=torch.float32, device=dev)
             w3[:cout] = wk.reshape(cout, ntaps, cin)
             full = w3[:, :, :nfull * 32].reshape(self.cout_pad, ntaps * nfull * 32)
-            tails = torch.zeros((self.cout_pad, (ntaps + 1) // 2 * 2, 16), dtype=torch.float32)
+            tails = torch.zeros((self.cout_pad, (ntaps + 1) // 2 * 2, 16), dtype=torch.float32, device=dev)
             tails[:, :ntaps] = w3[:, :, nfull * 32:]
-            self.w = split_planes(torch.cat([full, tails.reshape(self.cout_pad, -1)], 1)).to(device).contiguous()
+            self.w = split_planes(torch.cat([full, tails.reshape(self.cout_pad, -1)], 1)).contiguous()
             self.kpad = self.w.shape[2]
         if self.korder == "block":
             ntaps, nblk = kh * kw, cin // 32
-            w4 = torch.zeros((self.cout_pad, ntaps, nblk, 32), dtype=torch.float32)
+            w4 = torch.zeros((self.cout_pad, ntaps, nblk, 32), dtype=torch.float32, device=dev)
             w4[:cout] = wk.reshape(cout, ntaps, nblk, 32)
-            self.w = split_planes(w4.permute(0, 2, 1, 3).reshape(self.cout_pad, -1)).to(device).contiguous()
+            self.w = split_planes(w4.permute(0, 2, 1, 3).reshape(self.cout_pad, -1)).contiguous()
         # the default kernel reads the weights as ONE 128-byte line per (cout, 32-wide K block): [hi 32 | lo 32]
         # (conv_split_fast_kernel: 128-byte LDS-DMA rows); the planar (2, Cout_pad, Kpad) form serves "glds" / "pipe"
         self.w_fast = None
         if self.variant == "rowwin":
-            self._orig = (weight.detach().float().cpu(), bias.detach().float().cpu())       # see __call__
+            self._orig = (weight.detach().float(), bias.detach().float())                   # see __call__
             # row-window kernel: K order (kh, 32-channel block, kw) -- the kw taps of a (kh, block) group share one window;
             # Cin = 32 n + 16: each kh ends with the 16-channel tails, two taps per 32-wide step
             assert cin % 16 == 0 and self.tn in (2, 3, 4)
             nfull, tail = cin // 32, cin % 32
-            w4 = torch.zeros((self.cout_pad, kh, kw, cin), dtype=torch.float32)
+            w4 = torch.zeros((self.cout_pad, kh, kw, cin), dtype=torch.float32, device=dev)
             w4[:cout] = wk.reshape(cout, kh, kw, cin)
             per_kh = []
             for a in range(kh):
@@ -227,21 +232,21 @@ class SplitConv:
                     full = w4[:, a, :, :nfull * 32].reshape(self.cout_pad, kw, nfull, 32).permute(0, 2, 1, 3)
                     per_kh.append(full.reshape(self.cout_pad, nfull * kw * 32))
                 if tail:
-                    tl = torch.zeros((self.cout_pad, (kw + 1) // 2 * 2, 16), dtype=torch.float32)
+                    tl = torch.zeros((self.cout_pad, (kw + 1) // 2 * 2, 16), dtype=torch.float32, device=dev)
                     tl[:, :kw] = w4[:, a, :, nfull * 32:]
                     per_kh.append(tl.reshape(self.cout_pad, -1))
-            self.w = split_planes(torch.cat(per_kh, 1)).to(device).contiguous()
+            self.w = split_planes(torch.cat(per_kh, 1)).contiguous()
             self.kpad = self.w.shape[2]
         if self.variant in ("fast", "rowwin"):
             hi, lo = self.w[0], self.w[1]
             self.w_fast = torch.stack([hi.reshape(self.cout_pad, -1, 32), lo.reshape(self.cout_pad, -1, 32)], 2).contiguous()
             self.w = None
-        sc = torch.zeros(self.cout_pad, dtype=torch.float32)
-        sc[:cout] = 1.0 / pre
-        bs = torch.zeros(self.cout_pad, dtype=torch.float32)
-        bs[:cout] = bias.detach().float().cpu()
-        self.scale = sc.to(device)
-        self.bias = bs.to(device)
+        sc = torch.zeros(self.cout_pad, dtype=torch.float32, device=dev)
+        sc[:cout] = torch.ldexp(torch.ones_like(amax), ex - 1)      # 1 / pre, exactly
+        bs = torch.zeros(self.cout_pad, dtype=torch.float32, device=dev)
+        bs[:cout] = bias.detach().float().to(dev)
+        self.scale = sc
+        self.bias = bs
 
     def out_hw(self, h, w):
         oh = (h + 2 * self.padding[0] - self.kh) // self.stride[0] + 1

@@ -21,6 +21,29 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_FEED_STREAMS = {}
+
+
+def feed_stream(dev):
+    """THE side stream of the image feeds on ``dev`` (host->device copies of decoded chunks, the PNG unfilter kernel, the
+    gather copies of coalesce_u8): one per device and process, HIGH priority.
+
+    Round 6 measurement (tools/png_feed_probe.py, profiles/r06c_png_feed_timeline.txt): a fresh ``torch.cuda.Stream()`` per
+    loader comes from torch's round-robin pool and HIP maps streams onto a handful of hardware queues; every other loader
+    got a stream that shares its hardware queue with the stream the trunk runs on, and its 1 500 chunk copies (1.6 MB each)
+    then queued BEHIND the convolution launches -- 451 ms waiting for copies in a 470 ms job, 16 k images/s instead of 23 k,
+    alternating run by run.  A high-priority stream has its own queue: the copies and the short unfilter launches overtake
+    the trunk's kernels at workgroup granularity."""
+    dev = torch.device(dev)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _FEED_STREAMS.get(key)
+    if st is None:
+        lo, hi = torch.cuda.Stream.priority_range()            # (lowest, highest) = (0, -1) on this runtime
+        st = torch.cuda.Stream(device=dev, priority=hi)
+        _FEED_STREAMS[key] = st
+    return st
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 

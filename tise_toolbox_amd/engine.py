@@ -70,7 +70,8 @@ class RealismEngine:
             block = InceptionV3.BLOCK_INDEX_BY_DIM[dims]
             model = InceptionV3([block], weights=weights, num_classes=num_classes, seed=seed,
                                 normalize_input=normalize_input)
-        self.model = model.to(self.device).eval()
+        from .inception import to_device_flat
+        self.model = to_device_flat(model, self.device).eval()              # model.to(device), one copy per dtype
         # every rank must run the SAME parameters: the stand-in weights are calibrated with CPU convolutions
         # whose rounding depends on the host thread count, so rank 0's copy is broadcast (no-op for 1 process)
         tdist.broadcast_module_(self.model)
@@ -358,7 +359,7 @@ def coalesce_u8(batches, dev, limit, schedule=None):
         if schedule is not None and sched_i < len(schedule):
             return min(limit, schedule[sched_i])
         return limit
-    side = torch.cuda.Stream(device=dev)
+    side = device.feed_stream(dev)                         # one high-priority stream per device
     bufs, freed, keep = [None, None], [None, None], []
     cur, fill = 0, 0
     limit0, shape0 = limit, None

@@ -400,7 +400,8 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
 def _build_model(dims, weights, num_classes, seed):
     block_idx = InceptionV3.BLOCK_INDEX_BY_DIM[dims]
     model = InceptionV3([block_idx], weights=weights, num_classes=num_classes, seed=seed)
-    model.cuda()                                          # fid_score.py:232-233
+    from .inception import to_device_flat
+    to_device_flat(model, torch.device("cuda", torch.cuda.current_device()))     # model.cuda() (fid_score.py:232-233) in one copy
     return model
 
 

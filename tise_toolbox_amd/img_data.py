@@ -176,7 +176,8 @@ class U8CacheLoader:
         pinned = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
         dev = [torch.empty(shape, dtype=torch.uint8, device=self.device) for _ in range(nbuf)]
         views = [memoryview(p.numpy()).cast("B") for p in pinned]
-        side = torch.cuda.Stream(device=self.device)
+        from .device import feed_stream
+        side = feed_stream(self.device)                                 # one high-priority stream per device
         side.wait_stream(torch.cuda.current_stream(self.device))       # the device buffers may be memory that queued kernels still use
         for t in dev:
             t.record_stream(side)                                       # ... and the allocator must not recycle them under a copy still in flight

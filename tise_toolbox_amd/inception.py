@@ -218,13 +218,16 @@ def seeded_init_(net, seed=0, calibration="fid"):
         return net
     key = (seed, net.fc.out_features, calibration)
     if key in _SEEDED_CACHE:
-        net.load_state_dict(_SEEDED_CACHE[key])
+        # (the module tree may be a skeleton without storage -- build_inception3 -- so the tensors are ASSIGNED; clones, because
+        # the in-memory copy serves every later model of the process)
+        net.load_state_dict({k: v.clone() for k, v in _SEEDED_CACHE[key].items()}, assign=True)
         return net
     cached = _standin_cache_load(key)
     if cached is not None:
-        net.load_state_dict(cached)
         _SEEDED_CACHE[key] = cached
+        net.load_state_dict({k: v.clone() for k, v in cached.items()}, assign=True)
         return net
+    _materialize_(net)
     g = torch.Generator(device="cpu").manual_seed(seed)
     for name, m in net.named_modules():
         if isinstance(m, nn.Conv2d):
@@ -335,17 +338,38 @@ def _standin_cache_store(key, sd):
         pass
 
 
+def _materialize_(net):
+    """Give a skeleton built on the ``meta`` device real (uninitialised) CPU storage; counters start at zero."""
+    if any(p.is_meta for p in net.parameters()):
+        net.to_empty(device="cpu")
+        for m in net.modules():
+            if isinstance(m, nn.BatchNorm2d) and m.num_batches_tracked is not None:
+                m.num_batches_tracked.zero_()
+    return net
+
+
 def build_inception3(weights=None, num_classes=1000, seed=0, calibration="fid"):
     """Construct ``Inception3`` and load ``weights`` (a torchvision-format state_dict
-    path) or, when ``weights`` is None, the seeded stand-in parameters."""
-    net = Inception3(num_classes=num_classes, aux_logits=True)
+    path) or, when ``weights`` is None, the seeded stand-in parameters.
+
+    The module tree is built WITHOUT storage (``meta`` device) and the loaded tensors are assigned to it
+    (``load_state_dict(assign=True)``): torch's default initialisation of 96 convolutions (kaiming_uniform_ over 24 M
+    values) and the copy of every tensor into it were 0.11 s of a CLI process's start-up for values that are overwritten
+    at once (tools/startup_probe.py, profiles/r06d_startup.txt).  Only when stand-in weights have to be computed from
+    scratch (no cache file yet) does the skeleton get real storage first."""
+    with torch.device("meta"):
+        net = Inception3(num_classes=num_classes, aux_logits=True)
     if weights is not None:
         sd = torch.load(weights, map_location="cpu")
         if isinstance(sd, dict) and "state_dict" in sd:
             sd = sd["state_dict"]
-        net.load_state_dict(sd, strict=True)
+        net.load_state_dict(sd, strict=True, assign=True)
     else:
         seeded_init_(net, seed, calibration)
+        if any(p.is_meta for p in net.parameters()):        # a rank other than 0 of a multi-process run: rank 0 broadcasts
+            _materialize_(net)
+            for prm in net.parameters():
+                prm.detach().zero_()
     return net.eval()
 
 
@@ -440,6 +464,46 @@ class InceptionV3(nn.Module):
         ``logits`` end point (inception_score_star_bird.py:189): both WITH the bias.  ``fc_bias_for_rule`` maps the rules."""
         x = pool3.flatten(1)
         return self.fc(x) if bias else F.linear(x, self.fc.weight)
+
+
+@torch.no_grad()
+def to_device_flat(module, device):
+    """``module.to(device)`` with ONE host->device copy per dtype instead of one per tensor: the 566 parameters and buffers
+    of InceptionV3 are gathered into a flat host buffer, copied once, and every parameter / buffer becomes a view of the
+    device buffer (0.135 s -> ~0.02 s of a CLI's start-up; profiles/r06d_startup.txt).  Values, names, dtypes and
+    state_dict() are what ``.to(device)`` gives.  Tensors already on the device are left alone."""
+    device = torch.device(device)
+    groups = {}
+    for mod in module.modules():
+        for store in (mod._parameters, mod._buffers):
+            for name, t in store.items():
+                if t is not None and t.device != device and not t.is_meta:
+                    groups.setdefault(t.dtype, []).append((store, name, t))
+    for dtype, items in groups.items():
+        # distinct tensors only (a parameter shared by two modules must stay shared)
+        uniq, seen = [], {}
+        for store, name, t in items:
+            if id(t) not in seen:
+                seen[id(t)] = len(uniq)
+                uniq.append(t)
+        sizes = [t.numel() for t in uniq]
+        flat = torch.empty(sum(sizes), dtype=dtype)
+        off = 0
+        for t, n in zip(uniq, sizes):
+            flat[off:off + n] = t.detach().reshape(-1)
+            off += n
+        dflat = flat.to(device)
+        views, off = [], 0
+        for t, n in zip(uniq, sizes):
+            views.append(dflat[off:off + n].view(t.shape))
+            off += n
+        for store, name, t in items:
+            v = views[seen[id(t)]]
+            if isinstance(t, nn.Parameter):
+                store[name] = nn.Parameter(v, requires_grad=t.requires_grad)
+            else:
+                store[name] = v
+    return module
 
 
 def fc_bias_for_rule(rule, fc_bias="auto"):

@@ -164,6 +164,7 @@ class PngRingLoader:
         self.framed = unfilter_on_device(self.device)                         # slots = [header | filtered rows]: the GPU reverses the filters
         self.feeder = None
         self.wait_decode_seconds = self.wait_buffer_seconds = 0.0             # feeder thread: waiting for a decoded chunk / for a free device buffer
+        self.enqueue_seconds = self.wait_copy_seconds = 0.0                   # ... inside hipMemcpyAsync / waiting for copies to land (slot release)
         self.py_procs = []                                                    # Python fallback workers (started when a native worker hands a chunk back)
         self.native = None
         if self.n_rows and start:
@@ -335,7 +336,8 @@ class PngRingLoader:
         nb = len(sizes)
         nbuf = min(self.NBUF, nb)
         max_rows = max(sizes)
-        side = torch.cuda.Stream(device=dev)
+        from .device import feed_stream
+        side = feed_stream(dev)                                               # one high-priority stream per device (device.feed_stream)
         side.wait_stream(torch.cuda.current_stream(dev))
         bufs = [torch.empty((max_rows, self.h, self.w, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         # device-unfilter feed: the slots of a device batch land in ONE staging buffer (copies and the unfilter kernel are
@@ -388,7 +390,9 @@ class PngRingLoader:
                         self.wait_decode_seconds += time.perf_counter() - tw
                         hi = min((c + 1) * chunk, r1, self.n_rows)
                         src = ring_addr + ((c % self.nslots) * chunk + (r - c * chunk)) * img_bytes
+                        tw = time.perf_counter()
                         _lib.call("tise_memcpy_h2d_async", base + (r - r0) * img_bytes, src, (hi - r) * img_bytes, side_h)
+                        self.enqueue_seconds += time.perf_counter() - tw
                         if hi == min((c + 1) * chunk, self.n_rows):           # the whole chunk is on its way: its slot frees when the copy lands
                             ev = torch.cuda.Event()
                             ev.record(side)
@@ -397,10 +401,12 @@ class PngRingLoader:
                                 self.decode_seconds = time.perf_counter() - self.t_started
                                 if self.on_all_decoded is not None:
                                     self.on_all_decoded()
+                        tw = time.perf_counter()
                         while inflight and (len(inflight) > self.nslots // 2 or inflight[0][0].query()):
                             ev, cc = inflight.popleft()
                             ev.synchronize()
                             self.hdr[HDR_CONSUMED] = cc + 1
+                        self.wait_copy_seconds += time.perf_counter() - tw
                         r = hi
                     if self.framed:                                           # row filters + RGBA -> RGB on the GPU, behind the copies
                         _lib.call("tise_png_unfilter_rgb8", raw.data_ptr(), r1 - r0, img_bytes, self.h, self.w, bufs[k].data_ptr(), side_h)
