@@ -137,6 +137,12 @@ def _pool_drop():
 
 import atexit  # noqa: E402
 atexit.register(_pool_drop)
+# A process that fork()s while it holds page-locked (hipHostRegister'ed) memory gets children that crash inside the HIP runtime
+# (measured: DataLoader workers forked after a ring feed died with SIGSEGV -- tests/test_gpu_clip.py).  The parked ring is
+# therefore released before any fork of this interpreter (DataLoader workers, multiprocessing); subprocess launches -- the
+# decode workers -- do not run these hooks and do not need them.
+if hasattr(os, "register_at_fork"):
+    os.register_at_fork(before=_pool_drop)
 
 
 class PngRingLoader:

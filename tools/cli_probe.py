@@ -42,8 +42,11 @@ if __name__ == "__main__":
     from tise_toolbox_amd import png_ring
     print(f"host: {os.cpu_count()} hardware threads, usable (affinity and cgroup quota) {png_ring.usable_cpus()}; auto workers {png_ring.auto_workers()}", flush=True)
     # round 5: the shared-ring PNG feed (png_ring.py) at 32 / 64 / 128 decode processes and auto, against the DataLoader feed
-    for bs, nw, feed in ((50, 8, "ring"), (50, 12, "ring"), (50, 14, "ring"), (50, 16, "ring"), (50, 20, "ring"), (50, 32, "ring"), (50, 128, "ring"),
-                         (50, 0, "ring"), (50, 0, "ring"), (50, 16, "dataloader"), (50, 32, "dataloader")):
+    quick = len(sys.argv) > 2 and sys.argv[2] == "quick"      # round 6: the README recipe three times, nothing else
+    configs = ((50, 0, "ring"),) * 3 if quick else ((50, 8, "ring"), (50, 12, "ring"), (50, 14, "ring"), (50, 16, "ring"), (50, 20, "ring"),
+                                                     (50, 32, "ring"), (50, 128, "ring"), (50, 0, "ring"), (50, 0, "ring"),
+                                                     (50, 16, "dataloader"), (50, 32, "dataloader"))
+    for bs, nw, feed in configs:
         t0 = time.perf_counter()
         r = subprocess.run(base + ["--batch-size", str(bs), "--num-workers", str(nw), "--png-feed", feed], capture_output=True, text=True, env=env)
         dt = time.perf_counter() - t0
@@ -51,6 +54,8 @@ if __name__ == "__main__":
         timing = " | ".join(ln.replace("[tise timing] ", "") for ln in r.stderr.splitlines() if "[tise timing]" in ln)
         print(f"{feed:10s} batch {bs:3d} workers {nw:3d}: {dt:6.2f} s wall for {N} images incl. start-up -> {N / dt:7.0f} images/s   "
               f"{r.stdout.strip().splitlines()[-1] if r.stdout else r.stderr[-300:]}\n    {feedl[-1] if feedl else ''}\n    {timing}", flush=True)
+    if quick:
+        sys.exit(0)
     for bs, label in ((500, "first run (builds the cache, 32 workers)"), (500, "second run (from the cache)"), (500, "third run (from the cache)"),
                       (50, "README batch size, from the cache"), (50, "README batch size, from the cache, again")):
         t0 = time.perf_counter()
