@@ -416,6 +416,20 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(elapsed, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(elapsed.item())
+    # per-rank breakdown: with only the max-over-ranks time a straggler or a slow communicator cannot be
+    # told from a slow trunk.  loop_device = first launch of the image loop -> last (HIP events on this rank's stream);
+    # reduce = host wall from the end of the loop's enqueue to the completed all-reduce (it contains the wait for the device
+    # to finish the loop); first_collective = the reference side's all-reduce, communicator creation included
+    mine = torch.tensor([float(rank), n_rank, ev[0][0].elapsed_time(ev_tail[0]) * 1e-3, t_loop_host - t0, t_reduce_host - t_loop_host,
+                         ev_tail[0].elapsed_time(ev_tail[1]) * 1e-3, t_ref2 - t_ref1, t1 - t0, t_group_init], dtype=torch.float64, device=dev)
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(per_rank, mine)
+    rank_rows = [dict(zip(("rank", "images", "loop_device_s", "loop_host_enqueue_s", "reduce_host_s", "reduce_device_s",
+                           "first_collective_s", "total_s", "init_process_group_s"), [float(v) for v in t.tolist()])) for t in per_rank]
+    for r_ in rank_rows:
+        r_["rank"], r_["images"] = int(r_["rank"]), int(r_["images"])
 
     from tise_toolbox_amd.trunk import SplitTrunk
     conv_events = conv_timer or []
@@ -508,6 +522,7 @@ def main():
                                       "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                                       "launcher": os.environ.get("TISE_BENCH_LAUNCHER", "external" if world > 1 else "none")}},
             "reference_side": ref_side,
+            "ranks": rank_rows,
             "roofline": roofline,
             "stage_ms_per_device_batch": {"resize": resize_ms, "trunk": trunk_ms, "cov_syrk": syrk_ms},
             "allreduce_ms": allreduce_ms,
@@ -878,4 +893,15 @@ def cross_check_fp32(eng, data, chunks, lo, n_total, mu, sigma, mu_ref, sigma_re
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:                                              # noqa: BLE001
+        # a rank that fails must END -- non-zero, at once -- so that the launcher takes the other ranks down with it instead of
+        # leaving them in a collective until its timeout (dist.collective_timeout: 120 s): no interpreter shutdown, which
+        # would try to destroy the process group and wait for peers
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)

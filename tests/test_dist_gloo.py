@@ -229,3 +229,46 @@ def test_bench_self_launch_starts_fresh_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert e.value.code == 7
+
+
+_DEAD_RANK_SCRIPT = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import torch
+from tise_toolbox_amd import dist as tdist
+rank, world, _ = tdist.init_from_env(backend="gloo")
+buf = torch.ones(1 << 16, dtype=torch.float64)
+tdist.all_reduce_sum_(buf)                       # the group works
+assert float(buf[0]) == world
+for step in range(50):                           # "image loop"
+    time.sleep(0.02)
+    if rank == 1 and step == 10:
+        os._exit(9)                              # killed mid-loop: no clean-up, no goodbye
+tdist.all_reduce_sum_(buf)                       # rank 0 arrives alone
+tdist.barrier()
+print("rank", rank, "finished", flush=True)
+"""
+
+
+@pytest.mark.timeout(200)
+def test_a_rank_that_dies_mid_loop_takes_the_job_down(tmp_path):
+    """world-2 gloo job, rank 1 is killed in the middle of its loop.  Rank 0 must not sit in the all-reduce
+    until a launcher gives up: the group carries dist.collective_timeout() (TISE_DIST_TIMEOUT_S, default 120 s) and the lost
+    peer surfaces as an exception -> rank 0 exits non-zero, well inside 150 s."""
+    import subprocess
+    import time
+    script = tmp_path / "dead_rank.py"
+    script.write_text(_DEAD_RANK_SCRIPT.format(root=ROOT))
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   TISE_DIST_BACKEND="gloo", TISE_DIST_TIMEOUT_S="30")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    t0 = time.time()
+    out1, err1 = procs[1].communicate(timeout=150)
+    out0, err0 = procs[0].communicate(timeout=150)
+    took = time.time() - t0
+    assert procs[1].returncode == 9
+    assert procs[0].returncode not in (0, None), (out0, err0[-500:])
+    assert "finished" not in out0 and took < 150, took

@@ -273,4 +273,4 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    tdist.run_cli(main)

@@ -76,6 +76,26 @@ def init_from_env(backend=None, force=None):
     return rank, world, local_rank
 
 
+def run_cli(main):
+    """``if __name__ == "__main__"`` body of the CLIs.  One process: ``main()`` and nothing else.  A rank of a multi-process
+    job that raises must END at once with a non-zero code (traceback printed): the interpreter's normal shutdown would try
+    to tear the process group down and can wait for peers that are themselves waiting in a collective for this rank --
+    the launcher (torchrun) takes the other ranks down as soon as one of them has exited non-zero."""
+    if env_world()[1] <= 1:
+        return main()
+    import sys
+    import traceback
+    try:
+        return main()
+    except SystemExit:
+        raise
+    except BaseException:                                              # noqa: BLE001
+        traceback.print_exc()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(1)
+
+
 def shutdown():
     """Destroy the default group (a forced one-rank group included)."""
     global _FORCED

@@ -131,4 +131,4 @@ def main(argv=None):
 
 
 if __name__ == "__main__":
-    main()
+    tdist.run_cli(main)
