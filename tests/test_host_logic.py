@@ -606,3 +606,17 @@ def test_png_ring_native_workers_hand_unsupported_files_to_pillow(tmp_path, monk
         n += len(view)
         assert not ld.py_procs
     assert n == len(plain)
+
+
+def test_clip_preprocess_geometry_follows_torchvision_integer_rules():
+    """clip._transform = torchvision Resize(224) + CenterCrop(224).  torchvision 0.9.1
+    (transforms/functional.py resize: ``oh = int(size * h / w)`` for the longer side -- truncation; center_crop:
+    ``int(round((h - th) / 2.))``) -- known answers worked by hand from those two lines."""
+    from tise_toolbox_amd.clip_model import preprocess_geometry as g
+    assert g(256, 256) == (224, 224, 0, 0)
+    assert g(480, 640) == (224, 298, 0, 37)          # 224 * 640 / 480 = 298.67 -> 298 (round() would give 299); (298 - 224) / 2 = 37
+    assert g(640, 480) == (298, 224, 37, 0)
+    assert g(227, 300) == (224, 296, 0, 36)          # 296.04 -> 296; 72 / 2 = 36
+    assert g(300, 225) == (298, 224, 37, 0)          # 298.67 -> 298
+    assert g(229, 224) == (229, 224, 2, 0)           # (229 - 224) / 2 = 2.5 -> 2 (halves to even)
+    assert g(231, 224) == (231, 224, 4, 0)           # 3.5 -> 4

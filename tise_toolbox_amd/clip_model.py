@@ -161,10 +161,8 @@ def preprocess(img):
     (as the reference), returns a (3, 224, 224) fp32 tensor."""
     from PIL import Image
     w, h = img.size
-    s = 224 / min(w, h)
-    nw, nh = (224, max(224, round(h * s))) if w <= h else (max(224, round(w * s)), 224)
+    nh, nw, top, left = preprocess_geometry(h, w)
     img = img.resize((nw, nh), Image.BICUBIC)
-    left, top = (nw - 224) // 2, (nh - 224) // 2
     a = np.asarray(img.crop((left, top, left + 224, top + 224)).convert("RGB"), dtype=np.float32) / 255.0
     a = (a - np.array(CLIP_MEAN, dtype=np.float32)) / np.array(CLIP_STD, dtype=np.float32)
     return torch.from_numpy(a).permute(2, 0, 1).contiguous()
@@ -178,11 +176,16 @@ def preprocess_lut():
 
 
 def preprocess_geometry(h, w):
-    """(resized height, resized width, top, left) of clip._transform for an h x w image: Resize(224) of the shorter side,
-    CenterCrop(224)."""
-    s = 224 / min(w, h)
-    nw, nh = (224, max(224, round(h * s))) if w <= h else (max(224, round(w * s)), 224)
-    return nh, nw, (nh - 224) // 2, (nw - 224) // 2
+    """(resized height, resized width, top, left) of clip._transform for an h x w image, with torchvision's own integer
+    rules (third-party; clip/clip.py _transform -> torchvision.transforms.Resize(224) + CenterCrop(224)): the shorter side
+    becomes 224 and the longer one ``int(224 * long / short)`` -- TRUNCATED, not rounded (640 x 480 -> 298, not 299) --
+    and the crop starts at ``int(round((n - 224) / 2.0))`` (Python's round: halves go to the even integer).  Square
+    images -- the toolbox's 256 x 256 -- are unaffected; ADVICE r5 caught the one-pixel difference on other shapes."""
+    if w <= h:
+        nw, nh = 224, int(224 * h / w)
+    else:
+        nw, nh = int(224 * w / h), 224
+    return nh, nw, int(round((nh - 224) / 2.0)), int(round((nw - 224) / 2.0))
 
 
 def preprocess_device(batch_u8):
