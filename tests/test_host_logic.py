@@ -620,3 +620,25 @@ def test_clip_preprocess_geometry_follows_torchvision_integer_rules():
     assert g(300, 225) == (298, 224, 37, 0)          # 298.67 -> 298
     assert g(229, 224) == (229, 224, 2, 0)           # (229 - 224) / 2 = 2.5 -> 2 (halves to even)
     assert g(231, 224) == (231, 224, 4, 0)           # 3.5 -> 4
+
+
+def test_range_guard_hit_reruns_on_the_exact_path(monkeypatch, capsys):
+    """a split-fp16 run whose range guard fires is finished in-process on the exact-fp32 path
+    (engine.run_with_exact_fallback): second call with TISE_CONV=miopen; an exact run that raises is not retried."""
+    from tise_toolbox_amd.engine import run_with_exact_fallback
+    monkeypatch.delenv("TISE_CONV", raising=False)
+    calls = []
+
+    def job():
+        calls.append(os.environ.get("TISE_CONV", "split"))
+        if calls[-1] == "split":
+            raise FloatingPointError("range guard")
+        return 42
+    assert run_with_exact_fallback(job, "the test job") == 42 and calls == ["split", "miopen"]
+    assert "again on the exact-fp32 convolution path" in capsys.readouterr().err
+    monkeypatch.setenv("TISE_CONV", "miopen")
+
+    def bad():
+        raise FloatingPointError("still bad")
+    with pytest.raises(FloatingPointError):
+        run_with_exact_fallback(bad)

@@ -167,7 +167,8 @@ def check_split_overflow(what="InceptionV3 trunk", flag=None):
     if flag:
         raise FloatingPointError(
             f"{what}: an activation exceeded the fp16 range of the split-precision format (|v| > 65504) or was NaN; "
-            "run with TISE_CONV=miopen (fp32 convolutions) for these weights / inputs")
+            "the CLIs finish such a job on the exact-fp32 path by themselves (engine.run_with_exact_fallback); library callers: "
+            "TISE_CONV=miopen / --conv exact")
 
 
 class StatsAccumulator:

@@ -45,6 +45,23 @@ def require_gpu():
             "has no CPU fallback (the reference's --gpu '' CPU mode is not provided)")
 
 
+def run_with_exact_fallback(fn, what="the evaluation"):
+    """``fn()``; when the split-fp16 trunk's range guard fires (FloatingPointError from check_numerics: an activation beyond
+    the fp16 range of the operand format -- weights / inputs far from InceptionV3's) the job is run AGAIN, in this process,
+    on the exact-fp32 convolution path (``TISE_CONV=miopen``: a new engine, no exec) instead of telling the user to rerun
+    by hand.  Under torchrun every rank raises together (check_numerics is collective), so every rank
+    reruns.  ``--conv exact`` / TISE_CONV=miopen start there directly."""
+    import sys
+    try:
+        return fn()
+    except FloatingPointError as e:
+        if os.environ.get("TISE_CONV", "split") != "split":
+            raise
+        print(f"[tise] {e}\n[tise] running {what} again on the exact-fp32 convolution path (TISE_CONV=miopen)", file=sys.stderr, flush=True)
+        os.environ["TISE_CONV"] = "miopen"
+        return fn()
+
+
 class RealismEngine:
     def __init__(self, dims=2048, device_index=None, weights=None, num_classes=1000, seed=0,
                  channels_last=None, fold_bn=True, with_logits=False, model=None, normalize_input=True,

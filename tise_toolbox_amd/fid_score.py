@@ -37,7 +37,8 @@ import torch
 import torch.utils.data
 
 from . import _lib, device, dist as tdist, img_data, weights as tweights
-from .engine import RealismEngine, coalesce_batches, coalesce_u8, device_batch_images, frechet_solver, require_gpu
+from .engine import (RealismEngine, coalesce_batches, coalesce_u8, device_batch_images, frechet_solver, require_gpu,
+                     run_with_exact_fallback)
 from .inception import InceptionV3
 
 warnings.filterwarnings("ignore")          # fid_score.py:49
@@ -83,6 +84,9 @@ def _build_parser():
     parser.add_argument("--num-workers", type=int, default=0,
                         help="PNG decode processes (the reference hard-codes 8 DataLoader workers, fid_score.py:216); 0 = auto: "
                              "min(128, cpus / 2) shared by the ranks of the node")
+    parser.add_argument("--conv", type=str, default=None, choices=["split", "exact"],
+                        help="split: hand-written split-fp16 MFMA convolutions (fp32-class arithmetic, default); exact: fp32 "
+                             "convolutions (MIOpen).  A split run whose range guard fires is finished on the exact path automatically")
     parser.add_argument("--png-feed", type=str, default="ring", choices=["ring", "dataloader"],
                         help="ring: decode workers write into one shared page-locked ring the parent copies from (png_ring.py); "
                              "dataloader: torch DataLoader workers + collate + pin_memory (round 1-4 path, also the fallback "
@@ -666,13 +670,16 @@ def main(argv=None):
     if world == 1:
         os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu)        # reference: CUDA_VISIBLE_DEVICES = args.gpu (:243)
     _PNG_FEED["mode"] = args.png_feed
+    if args.conv is not None:
+        os.environ["TISE_CONV"] = "miopen" if args.conv == "exact" else "split"
     kind = "inception80" if (args.label == "O-FID" and args.num_classes == 80) else "inception"
     wpath, tag = tweights.resolve(args.weights, args.synthetic_weights, kind)
     if args.path1 is None:                                             # statistics-only
         if tdist.is_main():
             print([args.path2])
-        mu, sigma = save_statistics_of_path(args.path2, args.save_stats, args.batch_size, args.gpu, args.dims, wpath,
-                                            args.num_classes, args.seed, args.num_workers, args.u8_cache)
+        mu, sigma = run_with_exact_fallback(lambda: save_statistics_of_path(
+            args.path2, args.save_stats, args.batch_size, args.gpu, args.dims, wpath, args.num_classes, args.seed, args.num_workers,
+            args.u8_cache), "the statistics pass")
         if tdist.is_main():
             print(f"statistics of {args.path2} -> {args.save_stats}{tag}")
         return None
@@ -680,8 +687,8 @@ def main(argv=None):
     if tdist.is_main():
         print(paths)                                                   # :247
     if args.per_class:
-        per, skipped = calculate_per_class_fid(paths, args.batch_size, args.gpu, args.dims, wpath, args.num_classes,
-                                               args.seed, args.num_workers)
+        per, skipped = run_with_exact_fallback(lambda: calculate_per_class_fid(
+            paths, args.batch_size, args.gpu, args.dims, wpath, args.num_classes, args.seed, args.num_workers), "the per-class FID")
         mean = float(np.mean(list(per.values()))) if per else float("nan")
         if tdist.is_main():
             lines = [f"{args.label}[{c}]: {v}{tag}" for c, v in per.items()]
@@ -693,8 +700,9 @@ def main(argv=None):
                     f.write("\n".join(lines))
             print("\n".join(lines))
         return per
-    fid_value = calculate_fid_given_paths(paths, args.batch_size, args.gpu, args.dims, wpath, args.num_classes,
-                                          args.seed, args.save_stats, args.num_workers, args.u8_cache).item()
+    fid_value = run_with_exact_fallback(lambda: calculate_fid_given_paths(
+        paths, args.batch_size, args.gpu, args.dims, wpath, args.num_classes, args.seed, args.save_stats, args.num_workers,
+        args.u8_cache), "the FID").item()
     if tdist.is_main():
         if args.saved_file:
             with open(args.saved_file, "w") as f:

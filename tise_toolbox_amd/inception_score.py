@@ -44,9 +44,12 @@ def configure(**kw):
 
 def _engine():
     global _ENGINE
+    if _ENGINE is not None and getattr(_ENGINE, "_conv_mode", None) != os.environ.get("TISE_CONV", "split"):
+        _ENGINE = None                                   # the convolution path changed (engine.run_with_exact_fallback): build anew
     if _ENGINE is None:
         _ENGINE = RealismEngine(dims=2048, weights=_CONFIG["weights"], num_classes=_CONFIG["num_classes"],
                                 seed=_CONFIG["seed"], with_logits=True, fc_bias=_CONFIG["fc_bias"])
+    _ENGINE._conv_mode = os.environ.get("TISE_CONV", "split")
     return _ENGINE
 
 
@@ -185,7 +188,8 @@ def main(argv=None):
               batch_size=args.batch_size, rule=args.rule, drop_first_class=args.drop_first_class, fc_bias=args.fc_bias)
     images = load_data(args.image_folder)
     print(".......")
-    mean, std = get_inception_score(images, splits=args.splits)
+    from .engine import run_with_exact_fallback
+    mean, std = run_with_exact_fallback(lambda: get_inception_score(images, splits=args.splits), "the Inception Score")
     if tdist.is_main():
         if args.label == "O-IS":                                       # object_centric_inception_score.py:126-129
             text = f"O-IS: {mean} +-  {std}"

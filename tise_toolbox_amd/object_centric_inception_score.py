@@ -47,7 +47,7 @@ _ENGINES = {}
 
 
 def _engine(weights, num_classes, seed):
-    key = (weights, num_classes, seed)
+    key = (weights, num_classes, seed, os.environ.get("TISE_CONV", "split"))   # the convolution path is part of the key (exact-path rerun)
     if key not in _ENGINES:
         model = InceptionV3([3], normalize_input=False, weights=weights, num_classes=num_classes, seed=seed,
                             calibration="pm1")
@@ -120,8 +120,9 @@ def main(argv=None):
     print("Load images from: ", args.image_dir)
     imgs = IgnoreLabelDataset(args.image_dir)
     print("Calculating Inception Score...")
-    IS_mean, IS_std = inception_score(imgs, cuda=True, batch_size=32, resize=False, splits=10,      # :122
-                                      weights=wpath, seed=args.seed)
+    from .engine import run_with_exact_fallback
+    IS_mean, IS_std = run_with_exact_fallback(lambda: inception_score(imgs, cuda=True, batch_size=32, resize=False, splits=10,      # :122
+                                                                      weights=wpath, seed=args.seed), "the O-IS")
     if tdist.is_main():
         if args.saved_file:
             with open(args.saved_file, "w") as f:
