@@ -626,7 +626,7 @@ def test_range_guard_hit_reruns_on_the_exact_path(monkeypatch, capsys):
     """a split-fp16 run whose range guard fires is finished in-process on the exact-fp32 path
     (engine.run_with_exact_fallback): second call with TISE_CONV=miopen; an exact run that raises is not retried."""
     from tise_toolbox_amd.engine import run_with_exact_fallback
-    monkeypatch.delenv("TISE_CONV", raising=False)
+    monkeypatch.setenv("TISE_CONV", "split")            # (registers the variable's ABSENCE for the teardown: the function sets it itself)
     calls = []
 
     def job():
