@@ -80,7 +80,8 @@ def test_png_library_exports_its_header():
     build.build_png(force=False, verbose=False)
     text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "tise_png.h")).read(), flags=re.S)
     declared = sorted(set(re.findall(r"\b(tise_png_[a-z0-9_]+)\s*\(", text)))
-    assert declared == ["tise_png_decode_rgb8", "tise_png_inflate_backend", "tise_png_probe", "tise_png_scratch_bytes"]
+    assert declared == ["tise_png_decode_rgb8", "tise_png_inflate_backend", "tise_png_inflate_slot", "tise_png_probe",
+                        "tise_png_scratch_bytes", "tise_png_slot_bytes"]
     raw = ctypes.CDLL(build.PNG_LIB)
     for name in declared:
         getattr(raw, name)

@@ -202,31 +202,20 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(const ConvArgs 
 // tap of a valid output row can leave the image, so a tap change is ONE wave-uniform byte offset added to the four
 // always-loadable pointers (rows beyond M stay on the zero page).  Same products, another summation order: results
 // differ from the tap-major kernel in the last bits (as the row-window kernel's do).
-// DUO = true (round 5): 512 threads = TWO independent tiles, waves 0-3 and waves 4-7, each with its own LDS region, tile index
-// and epilogue -- the two waves of a SIMD are then partners inside ONE workgroup and the K loop locks them in ANTI-PHASE with
-// two joint barriers per K-step, half 1 one barrier behind half 0:
-//     half 0:  wait DMA(s) | B | fragments, issue DMA(s+1) | B | 48 MFMAs of step s      | wait ...
-//     half 1:       ... 48 MFMAs of step s-1 | wait DMA(s) | B | fragments, issue DMA(s+1) | B | 48 MFMAs ...
-// so in every barrier interval one half of the workgroup runs its matrix work while the other issues its LDS-DMA and waits for
-// it to land: matrix beside memory on every SIMD (MI355X_MICROARCH.md "Two waves per SIMD", items 5 and 9).  With two
-// INDEPENDENT 256-thread workgroups per CU the phases drift and collide: tools/probes/kstep_phase_probe.hip runs this K-step
-// with real LDS-DMA traffic in both forms -- 956-971 TFLOP/s (fp16 MFMA) for the independent workgroups (what the trunk's
-// deep-K layers reach), 1 300-1 340 for the anti-phase halves, 1 160-1 190 for the same 512 threads IN phase
-// (profiles/r05j_kstep_phase_probe.txt).  A half whose tile index lies behind the last tile (odd tile count) runs the same
-// barriers on the zero page and stores nothing (every row >= M).
-template <int TN, bool DBG = false, bool CBT = false, bool DUO = false, bool EARLY = false>
-__global__ __launch_bounds__(DUO ? 512 : 256, DUO ? 1 : 2) void conv_split_fast_kernel(const ConvArgs p) {
+// (Round 5's two other K-loop forms of this kernel -- DUO: two tiles per 512-thread workgroup in enforced anti-phase, -0.3 %;
+// EARLY: counted-wait K-step with two bare barriers, +0.3 %, inside the noise -- are kept as tools/probes/conv_duo_early.patch,
+// DESIGN.md section 4e; round 6 took them out of the library.)
+template <int TN, bool DBG = false, bool CBT = false>
+__global__ __launch_bounds__(256, 2) void conv_split_fast_kernel(const ConvArgs p) {
     constexpr int BN = 32 * TN;
     constexpr int A_BYTES = CS_BM * 128, B_BYTES = BN * 128;   // a stage: 128 pixel rows + BN cout rows of 128 B
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int T_BYTES = CS_BM * (BN * 2 + 16);
     constexpr int LDS_BYTES = (2 * STAGE > T_BYTES) ? 2 * STAGE : T_BYTES;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds_all[DUO ? 2 * LDS_BYTES : LDS_BYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
-    const int tid = DUO ? (threadIdx.x & 255) : threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: LDS / DMA addresses stay on the SALU
-    const int half = DUO ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
-    unsigned char* const lds = lds_all + half * LDS_BYTES;
     // 32-bit index arithmetic throughout the prologue (the launcher sends M >= 2^31 to the generic kernel): the 64-bit
     // divisions of the generic kernel cost several hundred instructions per workgroup, ~15 % of a 27-step tile
     const unsigned tiles_n = (unsigned)(p.Cout + BN - 1) / BN;
@@ -236,7 +225,6 @@ __global__ __launch_bounds__(DUO ? 512 : 256, DUO ? 1 : 2) void conv_split_fast_
         const unsigned q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = ((xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    if (DUO) bid = 2 * bid + (unsigned)half;                  // neighbouring tiles: the same m-tile's next n-tile (shared pixel operand in L2)
     const unsigned tile_m = bid / tiles_n;
     const int tile_n = (int)(bid - tile_m * tiles_n);
     const long long m0 = (long long)tile_m * CS_BM;
@@ -440,45 +428,6 @@ __global__ __launch_bounds__(DUO ? 512 : 256, DUO ? 1 : 2) void conv_split_fast_
     if (dbg && lane == 0) dbuf[wave * 512 + 480] = (int)(__builtin_amdgcn_s_memrealtime());
 #define CF_BAR() { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); }
     int step = 0;
-    if constexpr (DUO || EARLY) {
-        // K-step of a half:   B1 | issue DMA(s+1) | s_waitcnt vmcnt(pieces of one step) = DMA(s) landed | B2 | fragments + MFMAs of step s
-        // B1: every wave of the workgroup has finished the MFMAs (and fragment reads) of its previous step -> the stage DMA(s+1) writes is
-        // free.  B2: every wave's pieces of DMA(s) have landed.  Both are BARE s_barrier instructions: a __syncthreads() would put
-        // s_waitcnt vmcnt(0) in front and drain the DMA that is meant to stay in flight.  The counted wait leaves DMA(s+1) in flight,
-        // so a step's operands have one whole step to arrive (the 256-thread form issues DMA(s+1) right before the MFMAs of step s and
-        // waits for it right after them: its landing window is the MFMA phase alone).  Half 1 runs one barrier behind half 0: between
-        // two barriers one half issues and waits while the other computes.
-        constexpr int PIECES = 4 + TN;                         // LDS-DMA instructions per wave and step
-        CF_TAP()
-        CF_ISSUE(0)
-        if (DUO && half == 1) CF_BAR()
-        for (; step + 1 < nsteps; step += 2) {
-            CF_BAR()                                            // B1
-            if (ab_dma) CF_ISSUE(STAGE)                         // step+1 -> stage 1
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-            CF_BAR()                                            // B2
-            CF_HEAD(0)
-            if (ab_mma) CF_COMPUTE(0)
-            CF_BAR()
-            if (step + 2 < nsteps) {
-                if (ab_dma) CF_ISSUE(0)                         // step+2 -> stage 0
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            CF_BAR()
-            CF_HEAD(STAGE)
-            if (ab_mma) CF_COMPUTE(STAGE)
-        }
-        if (step < nsteps) {                                    // odd tail: its data sits in stage 0
-            CF_BAR()
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            CF_BAR()
-            CF_HEAD(0)
-            CF_COMPUTE(0)
-        }
-        if (DUO && half == 0) CF_BAR()                          // balance half 1's extra barrier
-    } else {
     CF_TAP()
     CF_ISSUE(0)
     for (; step + 1 < nsteps; step += 2) {
@@ -509,7 +458,6 @@ __global__ __launch_bounds__(DUO ? 512 : 256, DUO ? 1 : 2) void conv_split_fast_
         __syncthreads();
         CF_HEAD(0)
         CF_COMPUTE(0)
-    }
     }
     __syncthreads();
     if ((p.nseg & 0x400) && p.M > 0) return;                  // (M > 0 always: keeps the accumulators live)
@@ -1127,36 +1075,6 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
         TISE_LAUNCH_CHECK();
         return TISE_OK;
     }
-    // round 5: two tiles per 512-thread workgroup in anti-phase (conv_split_fast_kernel<.., DUO>).  TISE_CONV_DUO=0: the
-    // 256-thread form (two independent workgroups per CU) everywhere
-    static const bool duo_on = [] { const char* e = getenv("TISE_CONV_DUO"); return e && e[0] == '1'; }();
-    const long long duo_tiles = (tiles + 1) / 2;
-    if (fast && duo_on && tn >= 2 && tiles >= 512) {
-        const dim3 dgrid((unsigned)duo_tiles), dblock(512);
-#define TISE_DUO_LAUNCH(T, C)                                                                                        \
-        hipLaunchKernelGGL((conv_split_fast_kernel<T, false, C, true>), dgrid, dblock, 0, st, *args)
-        if (cbt) {
-            if (args->PH != 0 || args->PW != 0 || args->Cin % 32 != 0 || args->KH * args->KW < 2) return TISE_ERR_INVALID_ARG;
-            switch (tn) {
-                case 2: TISE_DUO_LAUNCH(2, true); break;
-                case 3: TISE_DUO_LAUNCH(3, true); break;
-                case 4: TISE_DUO_LAUNCH(4, true); break;
-                case 5: TISE_DUO_LAUNCH(5, true); break;
-                default: return TISE_ERR_INVALID_ARG;
-            }
-        } else {
-            switch (tn) {
-                case 2: TISE_DUO_LAUNCH(2, false); break;
-                case 3: TISE_DUO_LAUNCH(3, false); break;
-                case 4: TISE_DUO_LAUNCH(4, false); break;
-                case 5: TISE_DUO_LAUNCH(5, false); break;
-                default: return TISE_ERR_INVALID_ARG;
-            }
-        }
-#undef TISE_DUO_LAUNCH
-        TISE_LAUNCH_CHECK();
-        return TISE_OK;
-    }
     if (fast && cbt) {                                         // K order (channel block, tap): unpadded multi-tap layers
         if (args->PH != 0 || args->PW != 0 || args->Cin % 32 != 0 || args->KH * args->KW < 2) return TISE_ERR_INVALID_ARG;
         switch (tn) {
@@ -1165,17 +1083,6 @@ extern "C" int tise_conv_split_f16(const ConvArgs* args, int tn, void* stream) {
             case 4: hipLaunchKernelGGL((conv_split_fast_kernel<4, false, true>), grid, block, 0, st, *args); break;
             case 5: hipLaunchKernelGGL((conv_split_fast_kernel<5, false, true>), grid, block, 0, st, *args); break;
             default: return TISE_ERR_INVALID_ARG;
-        }
-        TISE_LAUNCH_CHECK();
-        return TISE_OK;
-    }
-    static const bool early_on = [] { const char* e = getenv("TISE_CONV_EARLY"); return e && e[0] == '1'; }();
-    if (fast && early_on && tn >= 2) {                        // A/B: early DMA issue + counted wait + two bare barriers per step, 256 threads
-        switch (tn) {
-            case 2: hipLaunchKernelGGL((conv_split_fast_kernel<2, false, false, false, true>), grid, block, 0, st, *args); break;
-            case 3: hipLaunchKernelGGL((conv_split_fast_kernel<3, false, false, false, true>), grid, block, 0, st, *args); break;
-            case 4: hipLaunchKernelGGL((conv_split_fast_kernel<4, false, false, false, true>), grid, block, 0, st, *args); break;
-            case 5: hipLaunchKernelGGL((conv_split_fast_kernel<5, false, false, false, true>), grid, block, 0, st, *args); break;
         }
         TISE_LAUNCH_CHECK();
         return TISE_OK;
