@@ -6,6 +6,7 @@ PyTorch is only plumbing here (device memory, streams): every function passes ra
 path in the product (see ``_lib.TiseLibraryError``).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -24,22 +25,63 @@ def _stream():
 _FEED_STREAMS = {}
 
 
+def _pick_independent_stream(dev):
+    """A normal-priority stream whose hardware queue is NOT the one the current stream's kernels sit in, found by trying:
+    a ~1.5 ms spin kernel goes to the current stream, one tiny host->device copy to each of eight pool streams, and the
+    first stream whose copy completes while the spin is still running is taken (None when none overtakes)."""
+    import time
+    cur = torch.cuda.current_stream(dev)
+    cands = [torch.cuda.Stream(device=dev) for _ in range(8)]
+    src = torch.zeros(64, dtype=torch.uint8).pin_memory()
+    dst = torch.empty(64, dtype=torch.uint8, device=dev)
+    cur.synchronize()
+    torch.cuda._sleep(3_000_000)                               # cycles on the current stream
+    end = torch.cuda.Event()
+    end.record(cur)
+    evs = []
+    for st in cands:
+        with torch.cuda.stream(st):
+            dst.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(st)
+        evs.append(ev)
+    chosen, t0 = None, time.perf_counter()
+    while chosen is None and not end.query() and time.perf_counter() - t0 < 0.05:
+        for i, ev in enumerate(evs):
+            if ev.query():
+                chosen = i
+                break
+    end.synchronize()
+    for st in cands:
+        st.synchronize()
+    return cands[chosen] if chosen is not None else None
+
+
 def feed_stream(dev):
     """THE side stream of the image feeds on ``dev`` (host->device copies of decoded chunks, the PNG unfilter kernel, the
-    gather copies of coalesce_u8): one per device and process, HIGH priority.
+    gather copies of coalesce_u8): one per device and process.
 
     Round 6 measurement (tools/png_feed_probe.py, profiles/r06c_png_feed_timeline.txt): a fresh ``torch.cuda.Stream()`` per
-    loader comes from torch's round-robin pool and HIP maps streams onto a handful of hardware queues; every other loader
-    got a stream that shares its hardware queue with the stream the trunk runs on, and its 1 500 chunk copies (1.6 MB each)
-    then queued BEHIND the convolution launches -- 451 ms waiting for copies in a 470 ms job, 16 k images/s instead of 23 k,
-    alternating run by run.  A high-priority stream has its own queue: the copies and the short unfilter launches overtake
-    the trunk's kernels at workgroup granularity."""
+    loader comes from torch's round-robin pool and HIP maps streams onto four hardware queues; every FOURTH stream shares
+    its queue with the stream the trunk runs on, and its 1 500 chunk copies (1.6 MB each) then queued BEHIND the convolution
+    launches -- 451 ms waiting for copies in a 470 ms job, 16 k images/s instead of 23 k, for every second loader of the
+    probe.  A HIGH-priority stream always has a queue of its own, but its operations hold the compute queue up while they
+    run: bench.py's host_feed leg (600 gather copies of 9.8 MB) fell from 0.98 to 0.89 of the resident rate
+    (tools/host_feed_ab.sh, profiles/r06i_feed_stream_ab.txt).  So: a normal-priority stream that is PROVEN to overtake a
+    kernel on the current stream (_pick_independent_stream, ~2 ms once per process); the high-priority stream only when
+    none does.  TISE_FEED_PRIORITY=high | normal forces either without the probe."""
     dev = torch.device(dev)
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
     st = _FEED_STREAMS.get(key)
     if st is None:
         lo, hi = torch.cuda.Stream.priority_range()            # (lowest, highest) = (0, -1) on this runtime
-        st = torch.cuda.Stream(device=dev, priority=hi)
+        mode = os.environ.get("TISE_FEED_PRIORITY", "auto")
+        if mode == "auto":
+            st = _pick_independent_stream(dev)
+        elif mode == "normal":
+            st = torch.cuda.Stream(device=dev)
+        if st is None:
+            st = torch.cuda.Stream(device=dev, priority=hi)
         _FEED_STREAMS[key] = st
     return st
 
