@@ -34,8 +34,12 @@ def _pick_independent_stream(dev):
     cands = [torch.cuda.Stream(device=dev) for _ in range(8)]
     src = torch.zeros(64, dtype=torch.uint8).pin_memory()
     dst = torch.empty(64, dtype=torch.uint8, device=dev)
+    for st in cands:                                           # first use creates a stream's queue (milliseconds): not inside the measurement
+        with torch.cuda.stream(st):
+            dst.copy_(src, non_blocking=True)
+        st.synchronize()
     cur.synchronize()
-    torch.cuda._sleep(3_000_000)                               # cycles on the current stream
+    torch.cuda._sleep(8_000_000)                               # ~4 ms of cycles on the current stream
     end = torch.cuda.Event()
     end.record(cur)
     evs = []
@@ -46,7 +50,7 @@ def _pick_independent_stream(dev):
             ev.record(st)
         evs.append(ev)
     chosen, t0 = None, time.perf_counter()
-    while chosen is None and not end.query() and time.perf_counter() - t0 < 0.05:
+    while chosen is None and not end.query() and time.perf_counter() - t0 < 0.1:
         for i, ev in enumerate(evs):
             if ev.query():
                 chosen = i
@@ -54,6 +58,9 @@ def _pick_independent_stream(dev):
     end.synchronize()
     for st in cands:
         st.synchronize()
+    if os.environ.get("TISE_FEED_DEBUG") == "1":
+        import sys
+        print(f"[tise] feed stream probe: stream {chosen} of {len(cands)} overtook the compute stream", file=sys.stderr)
     return cands[chosen] if chosen is not None else None
 
 
