@@ -128,7 +128,12 @@ def _pool_park(fd, m, size, registered_on):
     _pool_release(*old)
 
 
+_POOL_PID = os.getpid()
+
+
 def _pool_drop():
+    if os.getpid() != _POOL_PID:                                              # a forked child: the parked ring is the parent's
+        return
     with _POOL_LOCK:
         old = (_RING_POOL["fd"], _RING_POOL["map"], _RING_POOL["registered_on"])
         _RING_POOL.update(fd=-1, map=None, size=0, registered_on=None)
@@ -171,6 +176,7 @@ class PngRingLoader:
         self.feeder = None
         self.wait_decode_seconds = self.wait_buffer_seconds = 0.0             # feeder thread: waiting for a decoded chunk / for a free device buffer
         self.enqueue_seconds = self.wait_copy_seconds = 0.0                   # ... inside hipMemcpyAsync / waiting for copies to land (slot release)
+        self._pid = os.getpid()                                               # the process that owns the ring, the workers and the HIP registration
         self.py_procs = []                                                    # Python fallback workers (started when a native worker hands a chunk back)
         self.native = None
         if self.n_rows and start:
@@ -472,6 +478,11 @@ class PngRingLoader:
         return self.first_item_event.elapsed_time(self.last_item_event) * 1e-3
 
     def close(self):
+        if os.getpid() != getattr(self, "_pid", os.getpid()):
+            # a fork()ed child (a DataLoader worker) that inherited this object: its garbage collector may finalise it -- the ring,
+            # the decode processes and the HIP registration belong to the PARENT; touching them here stopped the parent's workers
+            # and crashed inside the HIP runtime (SIGSEGV in the worker, tests/test_gpu_clip.py under the full suite)
+            return
         self._stop_feeder()
         if self.ctl is not None:
             try:
