@@ -176,6 +176,7 @@ class PngRingLoader:
         self.feeder = None
         self.wait_decode_seconds = self.wait_buffer_seconds = 0.0             # feeder thread: waiting for a decoded chunk / for a free device buffer
         self.enqueue_seconds = self.wait_copy_seconds = 0.0                   # ... inside hipMemcpyAsync / waiting for copies to land (slot release)
+        self.copies_enqueued = 0
         self._pid = os.getpid()                                               # the process that owns the ring, the workers and the HIP registration
         self.py_procs = []                                                    # Python fallback workers (started when a native worker hands a chunk back)
         self.native = None
@@ -377,6 +378,7 @@ class PngRingLoader:
         stop = threading.Event()
         img_bytes, chunk = self.img_bytes, self.chunk
         side_h = side.cuda_stream
+        run_max = max(1, min(int(os.environ.get("TISE_RING_RUN", "8")), self.nslots // 4))   # chunks per copy at most (A/B: 1 = one copy per chunk)
 
         def feeder():
             try:
@@ -400,21 +402,33 @@ class PngRingLoader:
                         if not self._wait_chunk(c, stop):
                             return
                         self.wait_decode_seconds += time.perf_counter() - tw
-                        hi = min((c + 1) * chunk, r1, self.n_rows)
+                        # ONE copy for the run of chunks that are decoded already and sit in consecutive ring slots (at most
+                        # run_max of them: their slots are released together): the decoders run ahead of this loop most of the
+                        # time, and every operation on the feed stream -- copy, event -- has a fixed cost that grows when the host
+                        # is busy (round 6: tools/cli_copy_trace.sh -- slow runs had FAST copies that started late)
+                        c_last = c
+                        while (c_last + 1 - c < run_max and c_last + 1 < self.n_chunks and (c_last + 1) * chunk < r1
+                               and (c_last + 1) % self.nslots != 0 and self.done[c_last + 1] == DONE_OK):
+                            c_last += 1
+                        hi = min((c_last + 1) * chunk, r1, self.n_rows)
                         src = ring_addr + ((c % self.nslots) * chunk + (r - c * chunk)) * img_bytes
                         tw = time.perf_counter()
                         _lib.call("tise_memcpy_h2d_async", base + (r - r0) * img_bytes, src, (hi - r) * img_bytes, side_h)
                         self.enqueue_seconds += time.perf_counter() - tw
-                        if hi == min((c + 1) * chunk, self.n_rows):           # the whole chunk is on its way: its slot frees when the copy lands
+                        self.copies_enqueued += 1
+                        # chunks whose last row is now on its way: their slots free when this copy lands
+                        c_done = c_last if hi == min((c_last + 1) * chunk, self.n_rows) else c_last - 1
+                        if c_done >= c:
                             ev = torch.cuda.Event()
                             ev.record(side)
-                            inflight.append((ev, c))
-                            if c == self.n_chunks - 1:
+                            inflight.append((ev, c_done))
+                            if c_done == self.n_chunks - 1:
                                 self.decode_seconds = time.perf_counter() - self.t_started
                                 if self.on_all_decoded is not None:
                                     self.on_all_decoded()
                         tw = time.perf_counter()
-                        while inflight and (len(inflight) > self.nslots // 2 or inflight[0][0].query()):
+                        # release slots whose copies have landed; never let more than half the ring wait for its release
+                        while inflight and (inflight[-1][1] + 1 - int(self.hdr[HDR_CONSUMED]) > self.nslots // 2 or inflight[0][0].query()):
                             ev, cc = inflight.popleft()
                             ev.synchronize()
                             self.hdr[HDR_CONSUMED] = cc + 1

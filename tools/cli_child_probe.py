@@ -1,0 +1,33 @@
+"""Why is the README recipe slower as a CHILD of bench.py than alone?  Runs the CLI three times as a child of a parent that holds
+(a) nothing, (b) a HIP context + 30 GB of device memory, (c) + 6 GB of page-locked host memory, (d) + a one-rank RCCL group, and
+prints the child's wall time and its feed line (what the feeder thread waited for).   python tools/cli_child_probe.py DIR REF.npz"""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+d, ref = sys.argv[1], sys.argv[2]
+cmd = [sys.executable, "-m", "tise_toolbox_amd.fid_score", "--batch-size", "50", "--path1", ref, "--path2", d, "--synthetic-weights"]
+env = dict(os.environ, TISE_TIMING="1", PYTHONPATH=ROOT)
+
+
+def child(tag, n=3):
+    for i in range(n):
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        feed = [ln for ln in r.stderr.splitlines() if ln.startswith("[tise] png feed")]
+        print(f"{tag} run {i}: {dt:.2f} s | {feed[-1][17:260] if feed else r.stderr[-200:]}", flush=True)
+
+
+variants = [("default", {}), ("priority high", {"TISE_FEED_PRIORITY": "high"}), ("SDMA off", {"HSA_ENABLE_SDMA": "0"}),
+            ("event every 4 chunks", {"TISE_RING_EVENT_EVERY": "4"}), ("8 hw queues", {"GPU_MAX_HW_QUEUES": "8"}),
+            ("priority normal (pool stream, no probe)", {"TISE_FEED_PRIORITY": "normal"})]
+base = dict(env)
+for rnd in range(int(sys.argv[3]) if len(sys.argv) > 3 else 5):
+    for name, extra in variants:
+        env.clear(); env.update(base); env.update(extra)
+        child(f"[{name}] round {rnd}", 1)
+sys.exit(0)
