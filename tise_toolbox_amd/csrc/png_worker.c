@@ -8,7 +8,7 @@
  *
  * Why a native program: a Python worker needs ~0.15 s to import numpy + Pillow before its first file -- on a box with 16
  * CPUs of quota sixteen of them burn 2.4 CPU-seconds at start, a quarter of the whole 12 000-file job of bench.py's png_feed
- * leg (profiles/r06*_png_feed.txt) and a visible part of a CLI's start-up.  This one decodes its first file ~2 ms after
+ * leg (profiles/r06c_png_feed_timeline.txt) and a visible part of a CLI's start-up.  This one decodes its first file ~2 ms after
  * exec.
  *
  * A file this decoder does not take (TISE_PNG_UNSUPPORTED: palette / gray / 16-bit / interlaced / JPEG ...; TISE_PNG_CORRUPT;
