@@ -543,10 +543,17 @@ def main():
             out["host_feed"] = host_feed_leg(eng, data, lo, n_total, args.feed_batch, mu_ref, sigma_ref, solver, dev,
                                              float(res["fid"]), n_total / elapsed)
         out["png_feed"] = None
+        out["cli_process"] = None
         if world == 1 and args.png_images > 0:
-            out["png_feed"] = png_feed_leg(eng, data, lo, min(args.png_images, n_rank), args.feed_batch, mu_ref, sigma_ref, solver, dev,
-                                           cli=not args.no_cli_process)
-            out["cli_process"] = out["png_feed"].pop("cli_process", None)
+            # the extra legs must never cost the line its headline: a failure is recorded, not raised
+            try:
+                out["png_feed"] = png_feed_leg(eng, data, lo, min(args.png_images, n_rank), args.feed_batch, mu_ref, sigma_ref, solver, dev,
+                                               cli=not args.no_cli_process)
+                out["cli_process"] = out["png_feed"].pop("cli_process", None)
+            except Exception as e:                                       # noqa: BLE001
+                import traceback
+                traceback.print_exc()
+                out["png_feed"] = {"error": f"{type(e).__name__}: {e}"[:400]}
         if world == 1 and not args.no_cpu_baseline:
             # ---- CPU oracle on the first images of the timed set: the baseline AND the parity figures --------
             n_cpu = max(50, (min(args.cpu_sample, n_rank) // 50) * 50)
@@ -655,7 +662,7 @@ def cli_process_leg(png_dir, n, feed_batch, mu_ref, sigma_ref, tmp, fid_feed):
     runs = []
     for _ in range(2):
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
         wall = time.perf_counter() - t0
         phases = {}
         for ln in r.stderr.splitlines():
@@ -742,7 +749,12 @@ def png_feed_leg(eng, data, lo, n, feed_batch, mu_ref, sigma_ref, solver, dev, c
         t_res = time.perf_counter() - t0
         from_files()                                                # page cache, pinned-ring registration path, allocator
         wall, loop, fid, loader = from_files()
-        cli_obj = cli_process_leg(d, n, feed_batch, mu_ref, sigma_ref, tmp, fid) if cli else None
+        cli_obj = None
+        if cli:
+            try:
+                cli_obj = cli_process_leg(d, n, feed_batch, mu_ref, sigma_ref, tmp, fid)
+            except Exception as e:                                       # noqa: BLE001 -- a child that hangs or dies is a recorded failure of this leg only
+                cli_obj = {"error": f"{type(e).__name__}: {e}"[:400]}
         return {"cli_process": cli_obj, "images_per_s": n / wall, "seconds": wall, "image_loop_seconds": loop, "images": n, "feed_batch": feed_batch,
                 "device_batch": limit, "device_batches": loader.item_sizes() if hasattr(loader, "h") else None,
                 "decode_processes": loader.workers, "native_workers": loader.native is not None,
