@@ -424,6 +424,8 @@ def main():
                          ev_tail[0].elapsed_time(ev_tail[1]) * 1e-3, t_ref2 - t_ref1, t1 - t0, t_group_init], dtype=torch.float64, device=dev)
     per_rank = [mine]
     if world > 1:
+        if backend != "nccl":                                            # gloo (tests: several ranks on one GPU) gathers host tensors
+            mine = mine.cpu()
         per_rank = [torch.empty_like(mine) for _ in range(world)]
         torch.distributed.all_gather(per_rank, mine)
     rank_rows = [dict(zip(("rank", "images", "loop_device_s", "loop_host_enqueue_s", "reduce_host_s", "reduce_device_s",
