@@ -642,3 +642,19 @@ def test_range_guard_hit_reruns_on_the_exact_path(monkeypatch, capsys):
         raise FloatingPointError("still bad")
     with pytest.raises(FloatingPointError):
         run_with_exact_fallback(bad)
+
+
+def test_ring_device_batches_are_clamped_by_the_real_image_size():
+    """the callers size ``group`` for 256 x 256 images; the loader's device batches (and its three buffers) follow the REAL
+    size: at most engine.STAGING_BYTES_CAP of pixels per buffer, whole loader batches, never less than one."""
+    from tise_toolbox_amd import png_ring
+    from tise_toolbox_amd.engine import STAGING_BYTES_CAP
+    files = [f"{i:05d}.png" for i in range(1000)]
+    ld = png_ring.PngRingLoader(files, 50, "cpu", group=60, start=False)
+    ld.h = ld.w = 256
+    assert sum(ld.item_sizes()) == 1000 and max(ld.item_sizes()) <= 3000
+    for hw, want_max in ((1024, 300), (2048, 50), (8192, 50)):
+        ld.h = ld.w = hw
+        sizes = ld.item_sizes()
+        assert sum(sizes) == 1000 and all(s % 50 == 0 for s in sizes)
+        assert max(sizes) <= want_max and (max(sizes) * hw * hw * 3 <= STAGING_BYTES_CAP or max(sizes) == 50), (hw, sizes)
