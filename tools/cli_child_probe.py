@@ -23,7 +23,7 @@ def child(tag, n=3):
 
 
 variants = [("default", {}), ("priority high", {"TISE_FEED_PRIORITY": "high"}), ("SDMA off", {"HSA_ENABLE_SDMA": "0"}),
-            ("event every 4 chunks", {"TISE_RING_EVENT_EVERY": "4"}), ("8 hw queues", {"GPU_MAX_HW_QUEUES": "8"}),
+            ("one copy per chunk", {"TISE_RING_RUN": "1"}), ("8 hw queues", {"GPU_MAX_HW_QUEUES": "8"}),
             ("priority normal (pool stream, no probe)", {"TISE_FEED_PRIORITY": "normal"})]
 base = dict(env)
 for rnd in range(int(sys.argv[3]) if len(sys.argv) > 3 else 5):
