@@ -366,6 +366,8 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
         if loader is not None:
             loader.device = _engine_for(model, dims).device
         t0 = time.perf_counter()
+        from .hostinfo import cfs_throttle
+        thr0 = cfs_throttle()
         err, out = None, None
         try:
             out = calculate_activation_statistics(loader if loader is not None else [], model, batch_size, dims, cuda)
@@ -382,8 +384,10 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
                 sec = loader.steady_seconds()
                 steady = f"; after the first device batch {(len(shard) - loader.first_item_rows) / sec:.0f} images/s" if sec else ""
                 dec = f", all decoded {loader.decode_seconds:.2f} s after the workers started" if loader.decode_seconds else ""
+                thr1 = cfs_throttle()
                 dec += (f"; feeder waited {loader.wait_decode_seconds:.2f} s for decode, {loader.wait_buffer_seconds:.2f} s for a device buffer, "
-                        f"{loader.wait_copy_seconds + loader.enqueue_seconds:.2f} s on copies")
+                        f"{loader.wait_copy_seconds + loader.enqueue_seconds:.2f} s on copies; cgroup CPU throttling during the loop: "
+                        f"{thr1[0] - thr0[0]} periods, {(thr1[1] - thr0[1]) / 1e3:.0f} ms")
                 print(f"[tise] png feed: {len(shard)} images in {wall:.2f} s ({len(shard) / wall:.0f} images/s on this rank{steady}; "
                       f"{loader.workers} decode processes -> shared pinned ring{dec}; loader batch {batch_size}, device batch "
                       f"{device_batch_images(batch_size)})", file=sys.stderr)

@@ -39,3 +39,14 @@ def limit_torch_threads():
     if torch.get_num_threads() > n:
         torch.set_num_threads(n)
     return torch.get_num_threads()
+
+
+def cfs_throttle():
+    """(periods throttled, microseconds throttled) of this process's cgroup so far (cgroup v2 cpu.stat; (0, 0) when unknown): a
+    container that runs more threads than its CPU quota gets ALL of them -- the thread that launches kernels included -- stopped
+    for the rest of a 100 ms period."""
+    try:
+        d = dict(line.split() for line in open("/sys/fs/cgroup/cpu.stat"))
+        return int(d.get("nr_throttled", 0)), int(d.get("throttled_usec", 0))
+    except (OSError, ValueError):
+        return 0, 0

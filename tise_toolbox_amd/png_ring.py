@@ -213,7 +213,8 @@ class PngRingLoader:
         n_chunks = -(-self.n_rows // self.chunk)
         self.workers = max(1, min(self.workers, n_chunks))
         # slots: two per worker (one being written, one waiting for its copy), capped at 1 GiB of pinned pixels
-        nslots = max(2, min(2 * self.workers + 4, n_chunks, max(2, (1 << 30) // (self.chunk * img_bytes))))
+        nslots = max(2, min((2 * self.workers + 4) * max(1, int(os.environ.get("TISE_RING_SLOTS_MULT", "1"))), n_chunks,
+                            max(2, (1 << 30) // (self.chunk * img_bytes))))
         self.nslots, self.n_chunks, self.img_bytes = nslots, n_chunks, img_bytes
         names = [f.encode("utf-8", "surrogateescape") for f in self.files]
         offs = np.zeros(len(names) + 1, dtype=np.int64)
@@ -379,12 +380,14 @@ class PngRingLoader:
         img_bytes, chunk = self.img_bytes, self.chunk
         side_h = side.cuda_stream
         run_max = max(1, min(int(os.environ.get("TISE_RING_RUN", "8")), self.nslots // 4))   # chunks per copy at most (A/B: 1 = one copy per chunk)
+        ev_min = max(1, int(os.environ.get("TISE_RING_EVENT_CHUNKS", "1")))                  # chunks between two slot-release events at least (A/B)
 
         def feeder():
             try:
                 torch.cuda.set_device(dev)
                 inflight = deque()                                            # (event after the chunk's copies, chunk)
                 c = 0
+                last_copied = last_evented = -1                               # last chunk whose copy is enqueued / covered by an event
                 for b in range(nb):
                     k = b % nbuf
                     tw = time.perf_counter()
@@ -419,6 +422,12 @@ class PngRingLoader:
                         # chunks whose last row is now on its way: their slots free when this copy lands
                         c_done = c_last if hi == min((c_last + 1) * chunk, self.n_rows) else c_last - 1
                         if c_done >= c:
+                            last_copied = c_done
+                        # an event (= a barrier packet in the stream's compute queue) only every ev_min chunks, at the end of a device
+                        # batch, at the last chunk, or when a quarter of the ring waits for its release
+                        if last_copied > last_evented and (last_copied - last_evented >= ev_min or hi == r1 or last_copied == self.n_chunks - 1
+                                                            or last_copied + 1 - int(self.hdr[HDR_CONSUMED]) >= max(1, self.nslots // 4)):
+                            c_done = last_evented = last_copied
                             ev = torch.cuda.Event()
                             ev.record(side)
                             inflight.append((ev, c_done))

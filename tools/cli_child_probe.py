@@ -16,14 +16,19 @@ env = dict(os.environ, TISE_TIMING="1", PYTHONPATH=ROOT)
 def child(tag, n=3):
     for i in range(n):
         t0 = time.perf_counter()
-        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True)
+        extra_argv = env.pop("__argv", "").split()
+        r = subprocess.run(cmd + extra_argv, env=env, cwd=ROOT, capture_output=True, text=True)
+        if extra_argv:
+            env["__argv"] = " ".join(extra_argv)
         dt = time.perf_counter() - t0
         feed = [ln for ln in r.stderr.splitlines() if ln.startswith("[tise] png feed")]
-        print(f"{tag} run {i}: {dt:.2f} s | {feed[-1][17:260] if feed else r.stderr[-200:]}", flush=True)
+        line = feed[-1] if feed else r.stderr[-300:]
+        tail = line[line.find("feeder waited"):] if "feeder waited" in line else line[-200:]
+        print(f"{tag} run {i}: {dt:.2f} s | {line[17:60]} | {tail[:230]}", flush=True)
 
 
-variants = [("default", {}), ("priority high", {"TISE_FEED_PRIORITY": "high"}), ("SDMA off", {"HSA_ENABLE_SDMA": "0"}),
-            ("one copy per chunk", {"TISE_RING_RUN": "1"}), ("8 hw queues", {"GPU_MAX_HW_QUEUES": "8"}),
+variants = [("default", {}), ("default", {}), ("12 workers", {"__argv": "--num-workers 12"}), ("10 workers", {"__argv": "--num-workers 10"}), ("priority high", {"TISE_FEED_PRIORITY": "high"}), ("SDMA off", {"HSA_ENABLE_SDMA": "0"}),
+            ("one copy per chunk", {"TISE_RING_RUN": "1"}), ("ring x4, event per 32 chunks", {"TISE_RING_SLOTS_MULT": "4", "TISE_RING_EVENT_CHUNKS": "32", "TISE_RING_RUN": "16"}), ("8 hw queues", {"GPU_MAX_HW_QUEUES": "8"}),
             ("priority normal (pool stream, no probe)", {"TISE_FEED_PRIORITY": "normal"})]
 base = dict(env)
 for rnd in range(int(sys.argv[3]) if len(sys.argv) > 3 else 5):

@@ -39,10 +39,34 @@ if d:
     print(f"   run {i}: {len(d)} H2D copies: median {statistics.median(d):.0f} us, p90 {d[int(len(d) * 0.9)]:.0f} us, max {d[-1]:.0f} us, sum {sum(d) / 1e3:.0f} ms")
 k = glob.glob(f"/tmp/ct_{i}/**/*kernel_trace.csv", recursive=True)
 if k:
-    kr = [r for r in csv.DictReader(open(k[0])) if "png_unfilter" in r["Kernel_Name"]]
+    allk = list(csv.DictReader(open(k[0])))
+    kr = [r for r in allk if "png_unfilter" in r["Kernel_Name"]]
     du = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in kr)
     if du:
         print(f"   run {i}: {len(du)} unfilter launches: median {statistics.median(du):.0f} us, max {du[-1]:.0f} us, sum {sum(du) / 1e3:.1f} ms")
+    # how long does an unfilter launch wait AFTER the last copy of its device batch has landed?  (stream order: it may start at once)
+    cp = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in big)
+    import bisect
+    ends = [e for _, e in cp]; starts = [s for s, _ in cp]
+    waits = []
+    for r in sorted(kr, key=lambda r: int(r["Start_Timestamp"])):
+        ks = int(r["Start_Timestamp"])
+        j = bisect.bisect_right(ends, ks) - 1
+        if j >= 0:
+            waits.append((ks - ends[j]) / 1e3)
+    if waits:
+        print(f"   run {i}: unfilter start - end of the last copy before it: median {statistics.median(waits):.0f} us, max {max(waits):.0f} us, sum {sum(waits) / 1e3:.1f} ms")
+    # idle gaps of the copy engine between consecutive copies (end -> next start), beyond 1 ms
+    gaps = [(starts[j + 1] - ends[j]) / 1e3 for j in range(len(cp) - 1)]
+    big_gaps = [g for g in gaps if g > 1000]
+    print(f"   run {i}: gaps between consecutive copies > 1 ms: {len(big_gaps)}, sum {sum(big_gaps) / 1e3:.0f} ms; first copy -> last copy {(ends[-1] - starts[0]) / 1e6:.0f} ms")
+    # which queue ids do the trunk's kernels, the unfilter kernel use?
+    q = {}
+    for r in allk:
+        name = "unfilter" if "png_unfilter" in r["Kernel_Name"] else ("conv" if "conv_" in r["Kernel_Name"] else None)
+        if name:
+            q.setdefault(name, set()).add(r.get("Queue_Id"))
+    print(f"   run {i}: queue ids: {q}")
 PY
 done
 rm -rf $D
