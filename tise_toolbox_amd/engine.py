@@ -223,6 +223,35 @@ class RealismEngine:
         used_fused = self.fused is not None and prenormalized
         return feats, (self._logits(feats) if used_fused else (self.model.logits(feats, bias=self.fc_bias) if self.with_logits else None))
 
+    # ---- memory -----------------------------------------------------------------------------------
+    ACT_BYTES_PER_IMAGE = int(14.5 * 2**20)     # peak of a trunk pass per 256 x 256 image (tools/activation_memory_probe.py: 14.4 MiB at 250-1000, 13.5 at 3000)
+
+    def reserve_activations(self, images):
+        """ONE allocation of the trunk's peak footprint for a pass of ``images`` images, released at once into torch's caching
+        allocator -- the passes then split that block instead of asking the driver again and again.
+
+        Round 6 (tools/cli_child_probe.py, profiles/r06z_cli_copy_trace.txt): the device batches of a fed image set GROW (50, 100,
+        250 ... 3000 images), every larger pass needs larger blocks than the cache holds, and a fresh process ended with 54 GiB
+        reserved for a 39.5 GiB peak.  That is harmless when the driver hands out clean VRAM (1 ms per call) and ruinous when it
+        has to clear it first -- memory a previous process freed moments ago is cleared at ~45 GB/s: 0.97 s for 44 GB -- the
+        README recipe then took 4.2-4.4 s instead of 3.1-3.3 with the main thread inside hipMalloc while the feed piled up (what
+        round 6 first read as a "slow-copy mode").  With one allocation up front the worst case is one clearing of the peak.
+        No-op for the MIOpen trunk, for a size already reserved, and when the request exceeds 60 % of the free memory."""
+        from .trunk import SplitTrunk
+        images = int(images)
+        if images <= getattr(self, "_reserved_images", 0) or not isinstance(self.fused, SplitTrunk) or os.environ.get("TISE_RESERVE", "1") == "0":
+            return 0
+        nbytes = images * self.ACT_BYTES_PER_IMAGE
+        free, _total = torch.cuda.mem_get_info(self.device)
+        have = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)      # cached, free blocks
+        if nbytes <= have or nbytes > 0.6 * free:
+            self._reserved_images = images
+            return 0
+        x = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        del x
+        self._reserved_images = images
+        return nbytes
+
     # ---- accumulation ---------------------------------------------------------------------------
     def begin(self, n_total=None, temperature=T_COCO, splits=10, rule="coco", drop_first_class=False, fc_bias=None):
         """New image set.  ``rule`` also decides (unless ``fc_bias`` / the constructor's ``fc_bias`` force it) whether the

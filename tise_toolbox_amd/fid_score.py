@@ -160,6 +160,7 @@ def get_activations(images, model, batch_size=64, dims=2048, cuda=True, verbose=
     # the loader's batches are gathered into device batches (engine.device_batch_images): ``batch_size`` defines the
     # bookkeeping above, not the size of a trunk pass
     limit = device_batch_images(batch_size)
+    engine.reserve_activations(min(n_used_imgs, limit))
     for batch in coalesce_u8(_first(images, n_batches), engine.device, limit, (n_used_imgs, batch_size)):   # :99
         f = _forward_batch(engine, model, batch)
         pred_dev[start:start + f.shape[0]] = f.reshape(f.shape[0], -1)                       # :113
@@ -228,6 +229,7 @@ def calculate_activation_statistics(images, model, batch_size=64, dims=2048, cud
         n_batches = d0 // batch_size                      # ZeroDivisionError for an empty loader, as upstream
     engine = _engine_for(model, dims)
     stats = device.StatsAccumulator(dims, engine.device)
+    engine.reserve_activations(min(n_batches * batch_size, device_batch_images(batch_size)))      # one allocation of the passes' peak
     if getattr(images, "pregrouped", False):              # img_data.U8CacheLoader(group=K): items are device batches already
         batches = iter(images)
     else:
@@ -385,6 +387,10 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
                 steady = f"; after the first device batch {(len(shard) - loader.first_item_rows) / sec:.0f} images/s" if sec else ""
                 dec = f", all decoded {loader.decode_seconds:.2f} s after the workers started" if loader.decode_seconds else ""
                 thr1 = cfs_throttle()
+                if os.environ.get("TISE_ALLOC_TRACE") == "1":               # probe: how much of the loop went into hipMalloc (caching allocator misses)
+                    st = torch.cuda.memory_stats()
+                    dec += (f"; allocator: {st.get('num_device_alloc', 0)} device allocations, {st.get('reserved_bytes.all.peak', 0) / 2**30:.1f} GiB reserved, "
+                            f"{st.get('num_alloc_retries', 0)} retries")
                 dec += (f"; feeder waited {loader.wait_decode_seconds:.2f} s for decode, {loader.wait_buffer_seconds:.2f} s for a device buffer, "
                         f"{loader.wait_copy_seconds + loader.enqueue_seconds:.2f} s on copies; cgroup CPU throttling during the loop: "
                         f"{thr1[0] - thr0[0]} periods, {(thr1[1] - thr0[1]) / 1e3:.0f} ms")
@@ -432,6 +438,12 @@ def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_c
         if ld is not None and rest:
             ld.on_all_decoded = lambda: prefetch_png_ring(rest[0], batch_size, num_workers)
     t = _timing("decode workers started, building the model")
+    if os.environ.get("TISE_PREALLOC_GB"):                 # probe (tools/cli_child_probe.py): what does the first big hipMalloc of a process cost?
+        tp = time.perf_counter()
+        _x = torch.empty(int(float(os.environ["TISE_PREALLOC_GB"]) * 2**30), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        print(f"[tise timing] prealloc {os.environ['TISE_PREALLOC_GB']} GB: {time.perf_counter() - tp:.3f} s", file=sys.stderr, flush=True)
+        del _x
     model = _build_model(dims, weights, num_classes, seed)
     _engine_for(model, dims)                               # fold BatchNorm, pack the split weights, load the code objects
     t = _timing("model + engine ready", t)

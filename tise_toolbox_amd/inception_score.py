@@ -112,6 +112,7 @@ def get_inception_score(images, splits=10):
     def run(feed):
         eng.begin(n_total=n, temperature=_CONFIG["temperature"], splits=splits, rule=_CONFIG["rule"],
                   drop_first_class=_CONFIG["drop_first_class"])
+        eng.reserve_activations(min(hi - lo, device_batch_images(bs)))     # one allocation of the passes' peak (engine.reserve_activations)
         base = lo
         for batch in feed:
             if isinstance(batch, (list, tuple)):              # images of different sizes: one trunk pass for the batch

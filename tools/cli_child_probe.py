@@ -24,12 +24,12 @@ def child(tag, n=3):
         feed = [ln for ln in r.stderr.splitlines() if ln.startswith("[tise] png feed")]
         line = feed[-1] if feed else r.stderr[-300:]
         tail = line[line.find("feeder waited"):] if "feeder waited" in line else line[-200:]
-        print(f"{tag} run {i}: {dt:.2f} s | {line[17:60]} | {tail[:230]}", flush=True)
+        pre = [ln for ln in r.stderr.splitlines() if "prealloc" in ln]
+        print(f"{tag} run {i}: {dt:.2f} s | {line[17:60]} | {tail[:90]} | {pre[-1][14:] if pre else ''}", flush=True)
 
 
-variants = [("default", {}), ("default", {}), ("12 workers", {"__argv": "--num-workers 12"}), ("10 workers", {"__argv": "--num-workers 10"}), ("priority high", {"TISE_FEED_PRIORITY": "high"}), ("SDMA off", {"HSA_ENABLE_SDMA": "0"}),
-            ("one copy per chunk", {"TISE_RING_RUN": "1"}), ("ring x4, event per 32 chunks", {"TISE_RING_SLOTS_MULT": "4", "TISE_RING_EVENT_CHUNKS": "32", "TISE_RING_RUN": "16"}), ("8 hw queues", {"GPU_MAX_HW_QUEUES": "8"}),
-            ("priority normal (pool stream, no probe)", {"TISE_FEED_PRIORITY": "normal"})]
+variants = [("default (reserve)", {}), ("no reserve", {"TISE_RESERVE": "0"}), ("device batch 1000", {"TISE_DEVICE_BATCH": "1000"}),
+            ("default (reserve)", {}), ("no reserve", {"TISE_RESERVE": "0"})]
 base = dict(env)
 for rnd in range(int(sys.argv[3]) if len(sys.argv) > 3 else 5):
     for name, extra in variants:
