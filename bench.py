@@ -687,7 +687,10 @@ def cli_process_leg(png_dir, n, feed_batch, mu_ref, sigma_ref, tmp, fid_feed):
             "images_per_s": n / runs[0]["seconds"] if ok else None, "runs": runs,
             "dfid_vs_png_feed": (abs(runs[1]["fid"] - fid_feed) if ok and runs[1]["fid"] is not None else None),
             "note": "whole fresh child process, wall clock around subprocess.run: interpreter + imports + HIP context + model / engine + image "
-                    "loop from PNG files + Frechet distance + exit; phases from TISE_TIMING=1 (seconds after process start)"}
+                    "loop from PNG files + Frechet distance + exit; phases from TISE_TIMING=1 (seconds after process start).  The second run starts "
+                    "right after the first one freed ~45 GiB of VRAM: when the driver is still clearing that memory, the new process's first big "
+                    "allocation waits for it (up to ~1 s at ~45 GB/s: DESIGN.md section 4f) -- `seconds` is the common case, `seconds_second_run` the "
+                    "back-to-back case"}
 
 
 def png_feed_leg(eng, data, lo, n, feed_batch, mu_ref, sigma_ref, solver, dev, cli=True):
