@@ -11,6 +11,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch's own DataLoader pin-memory thread warns once per batch about an argument torch itself passes (14 000 lines per suite run)
+    config.addinivalue_line("filterwarnings", "ignore:The argument 'device' of Tensor:DeprecationWarning")
     # The GPU boxes show 256 hardware threads and grant the container 16 CPUs of cgroup quota: a 256-thread OpenMP team under
     # that quota is throttled in bursts (the CPU oracle's forward, and every rank subprocess's start-up, ran several times
     # slower than they need to).  Set before torch is imported, inherited by the rank subprocesses.
