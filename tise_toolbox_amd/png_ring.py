@@ -8,15 +8,17 @@ with 8 workers, 4 699 with 32, 3 565 with 64 on a 256-thread host -- falling wit
 (queues + collate + the pin-memory thread), not by zlib (profiles/r04h_cli_host_inclusive.txt).
 
 Here the parent touches no pixel:
-  * workers are stand-alone programs (``_png_worker.py``: numpy + Pillow only, started with subprocess -- no torch import,
-    no fork of a process that holds a GPU context, no multiprocessing machinery) that decode walk-ordered chunks of
-    ``chunk`` files straight into slots of an anonymous shared-memory ring (memfd, inherited file descriptors) and set one
-    ``done`` byte per chunk; chunks are claimed under a POSIX record lock, a slot is rewritten only after the parent has
-    copied the chunk that was in it (``consumed`` counter);
-  * the parent page-locks the ring ONCE (tise_host_register) and a feeder thread enqueues ``tise_memcpy_h2d_async`` copies of
-    finished chunks, in order, on a side stream into one of three device buffers; a device batch is handed to the consumer
-    with an event its stream waits on -- the same contract as img_data.U8CacheLoader (``len()`` counts ``batch_size``
-    batches: the drop-last bookkeeping of fid_score.py:90-96; ``pregrouped``).
+  * workers are stand-alone programs started with subprocess -- no torch import, no fork of a process that holds a GPU context,
+    no multiprocessing machinery: since round 6 the native ``tise_png_worker`` (csrc/png_worker.c, up in ~2 ms), with
+    ``_png_worker.py`` (numpy + Pillow only) as the fallback for chunks that hold a file outside the native decoder's subset
+    -- that decode walk-ordered chunks of ``chunk`` files straight into slots of an anonymous shared-memory ring (memfd,
+    inherited file descriptors) and set one ``done`` byte per chunk; chunks are claimed under a POSIX record lock, a slot is
+    rewritten only after the parent has copied the chunk that was in it (``consumed`` counter);
+  * the parent page-locks the ring ONCE (tise_host_register; the ring is parked for the next loader of the process) and a
+    feeder thread enqueues ``tise_memcpy_h2d_async`` copies of finished chunks -- one copy per run of chunks in consecutive
+    slots --, in order, on THE feed stream of the device (device.feed_stream) into one of three device buffers; a device
+    batch is handed to the consumer with an event its stream waits on -- the same contract as img_data.U8CacheLoader
+    (``len()`` counts ``batch_size`` batches: the drop-last bookkeeping of fid_score.py:90-96; ``pregrouped``).
 Workers can be started BEFORE the model is built (``start()``), so decoding overlaps the process's start-up.
 Round 6 (row a2's arithmetic on the GPU): with a device consumer the workers only INFLATE a file -- a ring slot holds the
 FILTERED scanlines behind a 64-byte header (csrc/png_decode.c: tise_png_inflate_slot) -- and the five PNG row filters and
