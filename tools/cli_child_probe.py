@@ -24,12 +24,11 @@ def child(tag, n=3):
         feed = [ln for ln in r.stderr.splitlines() if ln.startswith("[tise] png feed")]
         line = feed[-1] if feed else r.stderr[-300:]
         tail = line[line.find("feeder waited"):] if "feeder waited" in line else line[-200:]
-        pre = [ln for ln in r.stderr.splitlines() if "prealloc" in ln]
-        print(f"{tag} run {i}: {dt:.2f} s | {line[17:60]} | {tail[:90]} | {pre[-1][14:] if pre else ''}", flush=True)
+        ph = " ".join(ln.split(": ")[-1].split(" s after")[0] for ln in r.stderr.splitlines() if "[tise timing]" in ln)
+        print(f"{tag} run {i}: {dt:.2f} s | {line[17:60]} | phases {ph}", flush=True)
 
 
-variants = [("default (reserve)", {}), ("no reserve", {"TISE_RESERVE": "0"}), ("device batch 1000", {"TISE_DEVICE_BATCH": "1000"}),
-            ("default (reserve)", {}), ("no reserve", {"TISE_RESERVE": "0"})]
+variants = [("early HIP context (default)", {}), ("TISE_EARLY_HIP=0", {"TISE_EARLY_HIP": "0"})]
 base = dict(env)
 for rnd in range(int(sys.argv[3]) if len(sys.argv) > 3 else 5):
     for name, extra in variants:
