@@ -685,8 +685,6 @@ def main(argv=None):
     rank, world, local_rank = tdist.init_from_env()
     if world == 1:
         os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu)        # reference: CUDA_VISIBLE_DEVICES = args.gpu (:243)
-        from .hostinfo import warm_hip_context
-        warm_hip_context(0)                                            # the context's creation runs beside the walk / ring set-up / model load
     _PNG_FEED["mode"] = args.png_feed
     if args.conv is not None:
         os.environ["TISE_CONV"] = "miopen" if args.conv == "exact" else "split"

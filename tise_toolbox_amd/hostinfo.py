@@ -51,38 +51,3 @@ def cfs_throttle():
     except (OSError, ValueError):
         return 0, 0
 
-
-def warm_hip_context(device_index=0):
-    """Start creating the HIP primary context on ``device_index`` in a helper thread, through the libamdhip64 torch has loaded
-    (ctypes releases the GIL for the call), and return the thread.  A CLI process spends ~0.2 s in the context's creation; its
-    argument handling, directory walk, ring set-up and the host side of the model build can run beside it (round 6: the README
-    recipe as a process, profiles/r06z_startup_probe.txt).  hipInit / hipSetDevice / hipFree(0) are what the runtime itself
-    does on first use; they are thread-safe and idempotent, so torch's own lazy initialisation afterwards finds the work done.
-    Returns None when the library is not found or TISE_EARLY_HIP=0."""
-    import ctypes
-    import threading
-    if os.environ.get("TISE_EARLY_HIP", "1") == "0":
-        return None
-    path = None
-    try:
-        with open("/proc/self/maps") as f:
-            for line in f:
-                if "libamdhip64.so" in line:
-                    path = line.split()[-1]
-                    break
-        if path is None:
-            return None
-        hip = ctypes.CDLL(path)
-
-        def run():
-            try:
-                hip.hipInit(0)
-                hip.hipSetDevice(int(device_index))
-                hip.hipFree(None)                         # forces the primary context
-            except Exception:                              # noqa: BLE001 -- purely an optimisation
-                pass
-        th = threading.Thread(target=run, name="tise-hip-warm", daemon=True)
-        th.start()
-        return th
-    except OSError:
-        return None

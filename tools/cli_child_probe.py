@@ -28,7 +28,7 @@ def child(tag, n=3):
         print(f"{tag} run {i}: {dt:.2f} s | {line[17:60]} | phases {ph}", flush=True)
 
 
-variants = [("early HIP context (default)", {}), ("TISE_EARLY_HIP=0", {"TISE_EARLY_HIP": "0"})]
+variants = [("fast exit (default)", {}), ("TISE_FAST_EXIT=0", {"TISE_FAST_EXIT": "0"})]
 base = dict(env)
 for rnd in range(int(sys.argv[3]) if len(sys.argv) > 3 else 5):
     for name, extra in variants:
