@@ -809,3 +809,32 @@ def test_per_class_o_fid_at_80_classes(setup, tmp_path, monkeypatch):
         print("per-class O-FID", c, "device", per[c], "oracle", want)
         assert abs(per[c] - want) <= 1e-3, (c, per[c], want)
     print(f"CPU oracle on five classes: {time.perf_counter() - t0:.1f} s")
+
+
+@pytest.mark.timeout(600)
+def test_range_guard_hit_finishes_the_cli_on_the_exact_path(setup, tmp_path, monkeypatch, capfd):
+    """weights whose activations leave the fp16 range of the split format (the stand-in checkpoint with one
+    BatchNorm scale blown up) -- the CLI's split-fp16 run raises the range guard, and ``fid_score.main`` finishes the job in
+    the same process on the exact-fp32 convolution path; ``--conv exact`` gives the same number directly."""
+    from PIL import Image
+    from tise_toolbox_amd import fid_score
+    monkeypatch.setenv("TISE_MIOPEN_FIND", "0")                       # immediate-mode MIOpen: no solver search in a test
+    monkeypatch.setenv("TISE_CONV", "split")                          # (registers the variable for the teardown: the fallback sets it)
+    sd = {k: v.clone() for k, v in setup["sd"].items()}
+    sd["Conv2d_2b_3x3.bn.weight"] = sd["Conv2d_2b_3x3.bn.weight"] * 3.0e4    # 147 x 147 x 64 activations far beyond 65504
+    ck = tmp_path / "blown.pth"
+    torch.save(sd, ck)
+    gdir, rdir = tmp_path / "gen", tmp_path / "ref"
+    gdir.mkdir(); rdir.mkdir()
+    for i in range(12):
+        Image.fromarray(setup["gen"][i]).save(gdir / f"{i:03d}.png")
+        Image.fromarray(setup["ref"][i]).save(rdir / f"{i:03d}.png")
+    argv = ["--batch-size", "4", "--path1", str(rdir), "--path2", str(gdir), "--weights", str(ck)]
+    got = fid_score.main(argv)
+    err = capfd.readouterr().err
+    assert "again on the exact-fp32 convolution path" in err, err[-500:]
+    assert np.isfinite(got)
+    monkeypatch.setenv("TISE_CONV", "split")
+    exact = fid_score.main(argv + ["--conv", "exact"])
+    assert "again on the exact" not in capfd.readouterr().err
+    assert abs(got - exact) <= 1e-6 * max(1.0, abs(exact)), (got, exact)
