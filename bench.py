@@ -31,6 +31,13 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
                 of the split-fp16 trunk at the job's full size (N = 1 only)
   cpu_baseline  the CPU oracle (oracle/: numpy/scipy/torch-CPU restatement of the reference) timed on this host on
                 a bounded sample of the same workload (rank 0, N = 1 only)
+  host_feed     the same job fed from page-locked HOST memory in 50-image slices (N = 1, never `value`)
+  png_feed      the same job from 30 000 PNG FILES through the CLIs' feed: native inflate-only decode processes -> shared
+                page-locked ring -> H2D -> PNG row filters on the GPU (csrc/png_unfilter.hip); `ratio_to_resident` (N = 1, never `value`)
+  cli_process   the README recipe `python -m tise_toolbox_amd.fid_score --path1 ref.npz --path2 <those files>` as a FRESH CHILD
+                process, twice: wall clock + TISE_TIMING phases (N = 1, never `value`)
+  ranks         per-rank {loop_device_s, loop_host_enqueue_s, reduce_host_s, reduce_device_s, first_collective_s, total_s},
+                all-gathered: a straggler or a slow communicator can be told from a slow trunk (every N)
 """
 import argparse
 import json
