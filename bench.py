@@ -10,7 +10,7 @@ The JOB is BASELINE.json's metric and does not depend on the flags: IS* + FID of
 256x256x3 images -- decoded pixels already resident in HBM (PNG decode and the host->device copy are NOT in the timed
 region; DESIGN.md section 6 gives the host-inclusive rates of the CLI) -- against pre-computed reference statistics.
 A STEP is 1/K of the job = the hot path over 30 000 / K images (500 at the default K = 60, 1 500 at --steps 20; the
-device runs them in batches of up to 3000, engine.DEVICE_BATCH_DEFAULT -- the CLIs' default too; `--batch B` makes the job K*B images instead):
+device runs them in batches of up to 3000, engine.DEVICE_BATCH_DEFAULT; the feed legs and the CLIs: 1000, engine.FEED_DEVICE_BATCH_DEFAULT; `--batch B` makes the job K*B images instead):
     resize 256->299 (PIL-exact, csrc/resize.hip) -> InceptionV3 trunk (hand-written split-fp16 MFMA convolutions,
     csrc/conv_split.hip / conv_pipe.hip / trunk_ops.hip) + fc -> fp64 covariance/mean accumulation (csrc/stats.hip)
     -> IS* split sums (csrc/is_score.hip).
@@ -65,7 +65,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: "Peak BF16/FP16 MFMA ~2.
 # waves per SIMD; profiles/r03k_mfma_shape_probe.txt): reported next to the roofline, never used as its peak
 SUSTAINED_F16_MFMA_TFLOPS = 1585.0
 JOB_IMAGES = 30000         # BASELINE.json metric / configs[1]: 30k images (README.md:214-219 of the reference)
-from tise_toolbox_amd.engine import DEVICE_BATCH_DEFAULT as DEVICE_BATCH   # 3000: ONE device-batch default for the CLIs and this bench
+from tise_toolbox_amd.engine import DEVICE_BATCH_DEFAULT as DEVICE_BATCH   # 3000 for the resident job (the fed legs: engine.device_batch_images, 1000)
                                                                             # (a rank's share is cut into equal batches of at most this)
 
 
@@ -559,6 +559,9 @@ def main():
                 out["png_feed"] = png_feed_leg(eng, data, lo, min(args.png_images, n_rank), args.feed_batch, mu_ref, sigma_ref, solver, dev,
                                                cli=not args.no_cli_process)
                 out["cli_process"] = out["png_feed"].pop("cli_process", None)
+                # the in-leg resident reference is ONE run of the same 30 000 images and moves by a few per cent between runs;
+                # the line's headline rate is K timed steps: the steadier denominator, reported beside it
+                out["png_feed"]["ratio_to_value"] = out["png_feed"]["images_per_s"] / (n_total / elapsed)
             except Exception as e:                                       # noqa: BLE001
                 import traceback
                 traceback.print_exc()

@@ -557,7 +557,7 @@ def test_device_batch_is_decoupled_from_batch_size(setup, tmp_path, monkeypatch)
     from PIL import Image
     from tise_toolbox_amd import engine, fid_score
     from tise_toolbox_amd.inception import InceptionV3
-    assert engine.device_batch_images(50) == 3000 and engine.device_batch_images(64) == 2944
+    assert engine.device_batch_images(50) == 1000 and engine.device_batch_images(64) == 960
     assert engine.device_batch_images(3000) == 3000 and engine.device_batch_images(50, 4096 * 4096 * 3) == 50
     dev = setup["dev"]
     model = InceptionV3([3], seed=0).cuda()

@@ -300,14 +300,14 @@ def test_device_batch_rule_and_class_owners(monkeypatch):
     from tise_toolbox_amd import dist as tdist
     from tise_toolbox_amd.engine import device_batch_images
     monkeypatch.delenv("TISE_DEVICE_BATCH", raising=False)
-    assert device_batch_images(50) == 3000 and device_batch_images(64) == 2944 and device_batch_images(1) == 3000
-    assert device_batch_images(1000) == 3000 and device_batch_images(1001) == 2002 and device_batch_images(4096) == 4096
+    assert device_batch_images(50) == 1000 and device_batch_images(64) == 960 and device_batch_images(1) == 1000
+    assert device_batch_images(1000) == 1000 and device_batch_images(1001) == 1001 and device_batch_images(4096) == 4096
     assert device_batch_images(50, 4096 * 4096 * 3) == 50 and device_batch_images(7, 1024 * 1024 * 3) == 336     # 1 GiB cap: 341 images
     monkeypatch.setenv("TISE_DEVICE_BATCH", "120")
     assert device_batch_images(50) == 100 and device_batch_images(64) == 64 and device_batch_images(500) == 500
     # the reference's README recipe: 30 000 images at --batch-size 50 -> nothing dropped, 30 trunk passes instead of 600
     monkeypatch.delenv("TISE_DEVICE_BATCH")
-    assert tdist.n_used_images(30000, 50) == 30000 and 30000 // device_batch_images(50) == 10
+    assert tdist.n_used_images(30000, 50) == 30000 and 30000 // device_batch_images(50) == 30
     assert tdist.n_used_images(30003, 64) == 29952                      # fid_score.py:215-217 drop_last
     names = ["zebra", "cup", "traffic light", "dog", "person"]
     own = tdist.class_owners(names, 3)

@@ -316,21 +316,27 @@ class RealismEngine:
 
 
 # ---- device batch: decoupled from the loader's --batch-size ------------------------------------------------
-DEVICE_BATCH_DEFAULT = 3000      # images per trunk pass: ONE number for the CLIs and bench.py (round 5; the CLIs ran 1000 until
-                                 # round 4 while the bench ran 3000).  tools/batch_sweep_r04.sh, two alternating runs on one box:
-                                 # 1000 / 1500 / 2000 / 3000 -> 25.39 / 25.51 / 25.60 / 25.62 k images/s (the pooled-epilogue
-                                 # kernels walk whole images per workgroup, the tile tails of the 8 x 8 layers shrink);
-                                 # activations of a 3000-image pass: ~40 GB of the 288 GB
+DEVICE_BATCH_DEFAULT = 3000      # images per trunk pass of a job whose pixels are RESIDENT (bench.py's `value`).  tools/batch_sweep_r04.sh,
+                                 # two alternating runs on one box: 1000 / 1500 / 2000 / 3000 -> 25.39 / 25.51 / 25.60 / 25.62 k images/s
+                                 # (the pooled-epilogue kernels walk whole images per workgroup, the tile tails of the 8 x 8 layers
+                                 # shrink); activations of a 3000-image pass: 39.5 GiB of the 288 GB
+FEED_DEVICE_BATCH_DEFAULT = 1000 # images per trunk pass of a FED image set (the CLIs, bench.py's host_feed / png_feed / cli_process legs).
+                                 # Round 5 used 3000 here too.  Round 6: a fresh process pays for its device memory -- the driver clears
+                                 # VRAM that another process freed moments ago at ~45 GB/s when it hands it out again -- so the README
+                                 # recipe met 0 .. 1 s of hipMalloc for the 3000-image footprint (reserve_activations) and 0 .. 0.3 s for
+                                 # the 1000-image one (14.5 GiB), against 0.02-0.03 s more image loop per 30 000 images; and the feeds
+                                 # lose nothing: png_feed 0.948 / 0.951 of resident at 1000 / 1500 (0.94 at 3000), host_feed 0.986 / 0.991
+                                 # (0.98) -- finer pipelining of copies and passes (profiles/r06y_feed_device_batch.txt)
 STAGING_BYTES_CAP = 1 << 30      # uint8 pixels of one staging buffer / one pending ragged batch
 
 
 def device_batch_images(batch_size, image_bytes=256 * 256 * 3):
     """Images per trunk pass for a loader that delivers ``batch_size`` images at a time: whole loader batches up to
-    TISE_DEVICE_BATCH images (default DEVICE_BATCH_DEFAULT = 3000: the trunk's launches -- 85 per pass -- and tile tails are
-    amortised over 3000 images instead of the README recipe's 50, README.md:214-219) and at most 1 GiB of uint8 pixels.  The
+    TISE_DEVICE_BATCH images (default FEED_DEVICE_BATCH_DEFAULT = 1000: the trunk's launches -- 85 per pass -- and tile tails are
+    amortised over 1000 images instead of the README recipe's 50, README.md:214-219) and at most 1 GiB of uint8 pixels.  The
     reference's ``--batch-size`` keeps its one semantic role, the drop-last rule (fid_score.py:90-96,215-217);
     features do not depend on how images are batched (tests/test_gpu_kernels.py: batch invariance, bit for bit)."""
-    target = int(os.environ.get("TISE_DEVICE_BATCH", str(DEVICE_BATCH_DEFAULT)))
+    target = int(os.environ.get("TISE_DEVICE_BATCH", str(FEED_DEVICE_BATCH_DEFAULT)))
     cap = max(1, STAGING_BYTES_CAP // max(1, int(image_bytes)))
     target = max(1, min(target, cap))
     return max(1, target // max(1, int(batch_size))) * int(batch_size)
