@@ -50,8 +50,11 @@ def _timing(label, t0=None):
     if os.environ.get("TISE_TIMING") == "1" and tdist.is_main():
         now = time.time()
         try:
-            import psutil
-            born = psutil.Process().create_time()
+            # age of the process from the kernel's own clocks: start time in ticks since boot (/proc/self/stat field 22) against
+            # /proc/uptime.  (psutil's create_time adds the start ticks to /proc/stat's btime, a WHOLE second: its phase stamps
+            # were off by up to 1 s and could exceed the wall clock bench.py's cli_process leg measured around the process)
+            start_ticks = int(open("/proc/self/stat").read().rsplit(")", 1)[1].split()[19])
+            born = now - (float(open("/proc/uptime").read().split()[0]) - start_ticks / os.sysconf("SC_CLK_TCK"))
         except Exception:                                              # noqa: BLE001
             born = _T_IMPORT0
         extra = f" (+{now - t0:.2f} s)" if t0 is not None else ""
