@@ -10,7 +10,7 @@ The JOB is BASELINE.json's metric and does not depend on the flags: IS* + FID of
 256x256x3 images -- decoded pixels already resident in HBM (PNG decode and the host->device copy are NOT in the timed
 region; DESIGN.md section 6 gives the host-inclusive rates of the CLI) -- against pre-computed reference statistics.
 A STEP is 1/K of the job = the hot path over 30 000 / K images (500 at the default K = 60, 1 500 at --steps 20; the
-device runs them in batches of up to 3000, engine.DEVICE_BATCH_DEFAULT; the feed legs and the CLIs: 1000, engine.FEED_DEVICE_BATCH_DEFAULT; `--batch B` makes the job K*B images instead):
+device runs them in batches of up to 5000, engine.DEVICE_BATCH_DEFAULT; the feed legs and the CLIs: 1000, engine.FEED_DEVICE_BATCH_DEFAULT; `--batch B` makes the job K*B images instead):
     resize 256->299 (PIL-exact, csrc/resize.hip) -> InceptionV3 trunk (hand-written split-fp16 MFMA convolutions,
     csrc/conv_split.hip / conv_pipe.hip / trunk_ops.hip) + fc -> fp64 covariance/mean accumulation (csrc/stats.hip)
     -> IS* split sums (csrc/is_score.hip).
@@ -65,7 +65,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: "Peak BF16/FP16 MFMA ~2.
 # waves per SIMD; profiles/r03k_mfma_shape_probe.txt): reported next to the roofline, never used as its peak
 SUSTAINED_F16_MFMA_TFLOPS = 1585.0
 JOB_IMAGES = 30000         # BASELINE.json metric / configs[1]: 30k images (README.md:214-219 of the reference)
-from tise_toolbox_amd.engine import DEVICE_BATCH_DEFAULT as DEVICE_BATCH   # 3000 for the resident job (the fed legs: engine.device_batch_images, 1000)
+from tise_toolbox_amd.engine import DEVICE_BATCH_DEFAULT as DEVICE_BATCH   # 5000 for the resident job (the fed legs: engine.device_batch_images, 1000)
                                                                             # (a rank's share is cut into equal batches of at most this)
 
 
@@ -105,7 +105,7 @@ def synth_images_device(lo, hi, device, seed=0, shift=0.0, hw=256):
 
 def rank_batch(n_rank, preferred=DEVICE_BATCH, cap=DEVICE_BATCH):
     """Device batch of a rank: the largest divisor of the rank's image count that is <= cap (30 000 / 15 000 / 7 500 / 3 750
-    images at 1 / 2 / 4 / 8 GPUs -> 3000 / 3000 / 2500 / 1875); a count without a usable divisor runs `preferred` with a
+    images at 1 / 2 / 4 / 8 GPUs -> 5000 / 5000 / 3750 / 3750); a count without a usable divisor runs `preferred` with a
     short tail."""
     if n_rank <= 0:
         return preferred

@@ -316,10 +316,12 @@ class RealismEngine:
 
 
 # ---- device batch: decoupled from the loader's --batch-size ------------------------------------------------
-DEVICE_BATCH_DEFAULT = 3000      # images per trunk pass of a job whose pixels are RESIDENT (bench.py's `value`).  tools/batch_sweep_r04.sh,
-                                 # two alternating runs on one box: 1000 / 1500 / 2000 / 3000 -> 25.39 / 25.51 / 25.60 / 25.62 k images/s
-                                 # (the pooled-epilogue kernels walk whole images per workgroup, the tile tails of the 8 x 8 layers
-                                 # shrink); activations of a 3000-image pass: 39.5 GiB of the 288 GB
+DEVICE_BATCH_DEFAULT = 5000      # images per trunk pass of a job whose pixels are RESIDENT (bench.py's `value`: a rank's share is cut into equal
+                                 # batches of at most this).  Two alternating runs per size on one box, images/s of the driver's command:
+                                 # round 4 (tools/batch_sweep_r04.sh) 1000 / 1500 / 2000 / 3000 -> 25.39 / 25.51 / 25.60 / 25.62 k;
+                                 # round 6 (profiles/r06ad_device_batch_sweep.txt) 3000 / 3750 / 5000 / 6000 / 7500 -> 26.05 / 26.13 / 26.23 / 26.17 / 26.18 k
+                                 # (the pooled-epilogue kernels walk whole images per workgroup, the tile tails of the 8 x 8 layers shrink,
+                                 # 85 launch boundaries per pass); activations of a 5000-image pass: 71 GiB of the 288 GB
 FEED_DEVICE_BATCH_DEFAULT = 1000 # images per trunk pass of a FED image set (the CLIs, bench.py's host_feed / png_feed / cli_process legs).
                                  # Round 5 used 3000 here too.  Round 6: a fresh process pays for its device memory -- the driver clears
                                  # VRAM that another process freed moments ago at ~45 GB/s when it hands it out again -- so the README

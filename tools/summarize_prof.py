@@ -79,7 +79,7 @@ def main():
             agg[key] += (e - s) / 1e6
             cnt[key] += 1
         lines += ["", f"## steady state: last {K} device batches of the timed loop (one resize launch = one device batch: bench.py "
-                  "cuts a rank's images into equal device batches of at most 3000 -- round 4; 1000 before -- whatever --steps is)", "",
+                  "cuts a rank's images into equal device batches of at most engine.DEVICE_BATCH_DEFAULT -- 5000 since round 6, 3000 in rounds 4-5, 1000 before -- whatever --steps is)", "",
                   f"window {span:.2f} ms = {span/K:.3f} ms per device batch; sum of kernel durations {sum(agg.values()):.2f} ms", "",
                   "| kernel | ms per device batch | launches per device batch |", "|---|---:|---:|"]
         for k, v in agg.most_common(30):
