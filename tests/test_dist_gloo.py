@@ -180,11 +180,11 @@ def test_shard_files_global_drop_last():
 
 def test_bench_strong_scaling_shards_cover_the_job_once():
     """bench.py --scaling strong (SURVEY 8(d) Config 3): ONE 30k set, contiguous 30000/N images per rank, device
-    batches that divide a rank's range (3000/3000/2500/1875 at 1/2/4/8 GPUs: the largest divisor <= 3000)."""
+    batches that divide a rank's range (5000/5000/3750/3750 at 1/2/4/8 GPUs: the largest divisor <= 5000)."""
     sys.path.insert(0, ROOT)
     import bench
     from tise_toolbox_amd import dist as tdist
-    want_batch = {1: 3000, 2: 3000, 4: 2500, 8: 1875}
+    want_batch = {1: 5000, 2: 5000, 4: 3750, 8: 3750}
     for world in (1, 2, 3, 4, 8):
         covered = []
         for r in range(world):
