@@ -198,7 +198,7 @@ def test_bench_strong_scaling_shards_cover_the_job_once():
         assert covered[0][0] == 0 and covered[-1][1] == 30000
         assert all(x[1] == y[0] for x, y in zip(covered[:-1], covered[1:]))
     assert bench.rank_batch(1250) == 1250 and bench.rank_batch(100) == 100 and bench.rank_batch(10000) == 5000 and bench.rank_batch(14000) == 3500
-    assert bench.rank_batch(6002) == 3000                              # 2 x 3001: no divisor in 128 .. 3000 -> 3000 with a short tail
+    assert bench.rank_batch(10006) == 5000                             # 2 x 5003: no divisor in 128 .. 5000 -> 5000 with a short tail
 
 
 def test_bench_self_launch_starts_fresh_ranks(monkeypatch):
