@@ -4,7 +4,7 @@
 TAG=${1:-r06z}
 REPO=$(pwd); O=$REPO/gpurun_out/$TAG; mkdir -p $O
 bash tools/run_profiles.sh $TAG > $O/run_profiles.log 2>&1
-T0=$(date +%s.%N); python3 bench.py > $O/bench_default_1gpu.json 2> $O/bench_default.err; T1=$(date +%s.%N); echo "python bench.py (all legs): $(echo "$T1 - $T0" | bc) s wall" > $O/bench_default_wall.txt
+T0=$(date +%s.%N); python3 bench.py > $O/bench_default_1gpu.json 2> $O/bench_default.err; T1=$(date +%s.%N); python3 -c "print('python bench.py (all legs): %.1f s wall' % ($T1 - $T0))" > $O/bench_default_wall.txt    # (no bc on the boxes)
 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-cross-check > $O/bench_driver_cmd_steps20.json 2> $O/bench_driver.err
 python3 tools/png_feed_probe.py 30000 14,16,12,14 2>&1 | grep "workers\|resident" > $O/png_feed_timeline_30000.txt
 python3 tools/png_feed_probe.py 12000 14,12,10,8 2>&1 | grep "workers\|resident" > $O/png_feed_timeline_12000.txt
