@@ -658,3 +658,53 @@ def test_ring_device_batches_are_clamped_by_the_real_image_size():
         sizes = ld.item_sizes()
         assert sum(sizes) == 1000 and all(s % 50 == 0 for s in sizes)
         assert max(sizes) <= want_max and (max(sizes) * hw * hw * 3 <= STAGING_BYTES_CAP or max(sizes) == 50), (hw, sizes)
+
+
+class _Tattler:
+    """finaliser that reports the pid it ran in"""
+    def __init__(self, path):
+        self.path, self.me = path, self
+    def __del__(self):
+        with open(self.path, "a") as f:
+            f.write(f"{os.getpid()}\n")
+
+
+class _Churn(torch.utils.data.Dataset):
+    """every item allocates enough container objects to push the worker's collector through all generations"""
+    def __len__(self):
+        return 8
+    def __getitem__(self, i):
+        import gc
+        junk = [[j] for j in range(20000)]
+        del junk
+        gc.collect()
+        return torch.tensor([os.getpid()])
+
+
+def test_dataloader_workers_do_not_finalise_the_parents_garbage(tmp_path):
+    """img_data.worker_init (gc.freeze in every forked DataLoader worker): a cycle that is garbage in the parent at fork time --
+    in the product an engine with its HIP handles -- must not be finalised inside a worker; device.StatsAccumulator /
+    FrechetSolver additionally refuse to destroy their handle from another pid."""
+    import gc
+    from tise_toolbox_amd import device, img_data
+    log = tmp_path / "finalised.txt"
+    gc.collect()
+    gc.disable()
+    try:
+        _Tattler(str(log))                                         # unreachable at once, kept alive by its own cycle
+        loader = torch.utils.data.DataLoader(_Churn(), batch_size=2, num_workers=2, worker_init_fn=img_data.worker_init)
+        pids = set(int(p) for b in loader for p in b.flatten().tolist())
+        del loader
+    finally:
+        gc.enable()
+    assert os.getpid() not in pids and len(pids) >= 1               # the items really came from forked workers
+    ran_in = set(int(x) for x in log.read_text().split()) if log.exists() else set()
+    assert not (ran_in & pids), (ran_in, pids)                      # never inside a worker
+    gc.collect()
+    assert os.getpid() in set(int(x) for x in log.read_text().split())   # the parent collects it
+    # the handle classes: close() from a foreign pid drops the handle without calling the library
+    for cls in (device.StatsAccumulator, device.FrechetSolver):
+        obj = cls.__new__(cls)
+        obj._h, obj._pid = __import__("ctypes").c_void_p(1234), os.getpid() + 1
+        obj.close()                                                # would crash in tise_*_destroy(0x4d2) if it called it
+        assert not obj._h

@@ -25,7 +25,7 @@ import sys
 import numpy as np
 import torch
 
-from . import _lib, clip_model, device, dist as tdist, weights as tweights
+from . import _lib, clip_model, device, dist as tdist, img_data, weights as tweights
 
 
 def parse_args(argv=None):
@@ -190,7 +190,8 @@ def embed_paths(model, paths, dev, batch, workers=0, feed="ring", convert_first=
             out.clear()
         finally:
             ring.close()
-    loader = torch.utils.data.DataLoader(_Paths(paths, convert_first), batch_size=batch, shuffle=False, num_workers=min(32, workers))
+    loader = torch.utils.data.DataLoader(_Paths(paths, convert_first), batch_size=batch, shuffle=False, num_workers=min(32, workers),
+                                         worker_init_fn=img_data.worker_init)
     for x in loader:
         consume(x.to(dev))
     return torch.cat(out).contiguous() if out else torch.empty((0, 512), dtype=torch.float16, device=dev)

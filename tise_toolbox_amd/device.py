@@ -229,14 +229,18 @@ class StatsAccumulator:
         if self.device.type != "cuda":
             raise _lib.TiseLibraryError("StatsAccumulator needs a HIP device")
         self._h = ctypes.c_void_p()
+        self._pid = os.getpid()
         with torch.cuda.device(self.device):
             _lib.call("tise_stats_create", self.dims, ctypes.byref(self._h))
         self._keep = []
 
     def close(self):
-        if self._h:
+        # Only the process that created the handle may destroy it: a forked child (a DataLoader worker of the ragged-crop
+        # path) inherits this object, and when ITS garbage collector finalises an unreachable copy the destroy would call
+        # hipFree in a process that must not touch the parent's HIP context (crash: "DataLoader worker exited unexpectedly")
+        if self._h and os.getpid() == getattr(self, "_pid", None):
             _lib.load().tise_stats_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        self._h = ctypes.c_void_p()
 
     def __del__(self):
         try:
@@ -323,13 +327,14 @@ class FrechetSolver:
         if self.device.type != "cuda":
             raise _lib.TiseLibraryError("FrechetSolver needs a HIP device")
         self._h = ctypes.c_void_p()
+        self._pid = os.getpid()
         with torch.cuda.device(self.device):
             _lib.call("tise_frechet_create", self.dims, ctypes.byref(self._h))
 
     def close(self):
-        if self._h:
+        if self._h and os.getpid() == getattr(self, "_pid", None):      # never from a forked child (StatsAccumulator.close)
             _lib.load().tise_frechet_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        self._h = ctypes.c_void_p()
 
     def __del__(self):
         try:

@@ -25,6 +25,7 @@ Deviations from the reference, all deliberate (SURVEY.md notes N3-N5):
     configs[4]: one FID per object class, crops grouped by the ``{class}`` token of ``{stem}_{class}_{k}.png``,
     object_fidelity/crop_object.py:45).
 """
+import contextlib
 import os
 import sys
 import time
@@ -406,7 +407,7 @@ def _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers
     dataset = img_data.Dataset(path, transform=None, file_names=shard)
     dataloader = torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=False, drop_last=True,
                                              num_workers=dl_workers, collate_fn=img_data.collate_u8,
-                                             pin_memory=True)
+                                             pin_memory=True, worker_init_fn=img_data.worker_init)
     t0 = time.perf_counter()
     out = calculate_activation_statistics(dataloader, model, batch_size, dims, cuda)
     wall = time.perf_counter() - t0
@@ -422,6 +423,23 @@ def _build_model(dims, weights, num_classes, seed):
     from .inception import to_device_flat
     to_device_flat(model, torch.device("cuda", torch.cuda.current_device()))     # model.cuda() (fid_score.py:232-233) in one copy
     return model
+
+
+@contextlib.contextmanager
+def _own_model(dims, weights, num_classes, seed):
+    """The model of ONE call of this module's path-level functions.  _engine_for hangs the engine on the model and the engine
+    holds the model: a reference cycle, which kept each call's ~1.4 GiB of device memory (weights, packed weights, statistics and
+    staging buffers) alive until the garbage collector's next full pass -- 16 calls in one process held 20 GiB
+    (tools/soak_cli_loop.py).  The reference's model dies when calculate_fid_given_paths returns (fid_score.py:229-238);
+    so does this one: the cycle is cut on the way out."""
+    model = _build_model(dims, weights, num_classes, seed)
+    try:
+        yield model
+    finally:
+        try:
+            model._tise_engine = None
+        except Exception:                                              # noqa: BLE001
+            pass
 
 
 def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_classes=1000, seed=0,
@@ -447,34 +465,34 @@ def calculate_fid_given_paths(paths, batch_size, cuda, dims, weights=None, num_c
         torch.cuda.synchronize()
         print(f"[tise timing] prealloc {os.environ['TISE_PREALLOC_GB']} GB: {time.perf_counter() - tp:.3f} s", file=sys.stderr, flush=True)
         del _x
-    model = _build_model(dims, weights, num_classes, seed)
-    _engine_for(model, dims)                               # fold BatchNorm, pack the split weights, load the code objects
-    t = _timing("model + engine ready", t)
-    m1, s1 = _compute_statistics_of_path(paths[0], model, batch_size, dims, cuda, num_workers, u8_cache)
-    t = _timing("first side done", t)
-    # the first side's covariance is complete: factor it on a side stream while the second side's images are decoded
-    # and pushed through the network (Tr sqrtm(S1 S2) is symmetric in its arguments; csrc/frechet.hip)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    solver = frechet_solver(dims, dev)
-    use_pf = tuple(np.shape(s1)) == (dims, dims) and tuple(np.shape(m1)) == (dims,)
-    if use_pf:
-        solver.prefactor(torch.as_tensor(np.ascontiguousarray(s1, dtype=np.float64), device=dev))
-    m2, s2 = _compute_statistics_of_path(paths[1], model, batch_size, dims, cuda, num_workers, u8_cache)
-    t = _timing("second side done", t)
-    if save_stats and tdist.is_main():
-        np.savez(save_stats, mu=np.asarray(m2), sigma=np.asarray(s2))
-    if not use_pf or np.shape(m1) != np.shape(m2) or np.shape(s1) != np.shape(s2):
-        return calculate_frechet_distance(m1, s1, m2, s2)     # generic path (shape asserts :149-150 included)
-    try:
-        res = solver.distance_prefactored(np.atleast_1d(m1), np.atleast_1d(m2), np.atleast_2d(s2))
-    except _lib.TiseStatusError:
-        # the factor is gone: the process-wide solver of this (dims, device) served another distance / factorisation
-        # between prefactor() and here (a model's forward hook, a second thread).  The one-call form needs nothing kept.
-        return calculate_frechet_distance(m1, s1, m2, s2)
-    if res["flags"] & _lib.TISE_FLAG_NONFINITE:          # :156-160 (eps retry) lives in calculate_frechet_distance
-        return calculate_frechet_distance(m1, s1, m2, s2)
-    calculate_frechet_distance.last_result = res
-    return np.float64(res["fid"])
+    with _own_model(dims, weights, num_classes, seed) as model:
+        _engine_for(model, dims)                               # fold BatchNorm, pack the split weights, load the code objects
+        t = _timing("model + engine ready", t)
+        m1, s1 = _compute_statistics_of_path(paths[0], model, batch_size, dims, cuda, num_workers, u8_cache)
+        t = _timing("first side done", t)
+        # the first side's covariance is complete: factor it on a side stream while the second side's images are decoded
+        # and pushed through the network (Tr sqrtm(S1 S2) is symmetric in its arguments; csrc/frechet.hip)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        solver = frechet_solver(dims, dev)
+        use_pf = tuple(np.shape(s1)) == (dims, dims) and tuple(np.shape(m1)) == (dims,)
+        if use_pf:
+            solver.prefactor(torch.as_tensor(np.ascontiguousarray(s1, dtype=np.float64), device=dev))
+        m2, s2 = _compute_statistics_of_path(paths[1], model, batch_size, dims, cuda, num_workers, u8_cache)
+        t = _timing("second side done", t)
+        if save_stats and tdist.is_main():
+            np.savez(save_stats, mu=np.asarray(m2), sigma=np.asarray(s2))
+        if not use_pf or np.shape(m1) != np.shape(m2) or np.shape(s1) != np.shape(s2):
+            return calculate_frechet_distance(m1, s1, m2, s2)     # generic path (shape asserts :149-150 included)
+        try:
+            res = solver.distance_prefactored(np.atleast_1d(m1), np.atleast_1d(m2), np.atleast_2d(s2))
+        except _lib.TiseStatusError:
+            # the factor is gone: the process-wide solver of this (dims, device) served another distance / factorisation
+            # between prefactor() and here (a model's forward hook, a second thread).  The one-call form needs nothing kept.
+            return calculate_frechet_distance(m1, s1, m2, s2)
+        if res["flags"] & _lib.TISE_FLAG_NONFINITE:          # :156-160 (eps retry) lives in calculate_frechet_distance
+            return calculate_frechet_distance(m1, s1, m2, s2)
+        calculate_frechet_distance.last_result = res
+        return np.float64(res["fid"])
 
 
 def save_statistics_of_path(path, out_npz, batch_size, cuda, dims, weights=None, num_classes=1000, seed=0,
@@ -487,11 +505,11 @@ def save_statistics_of_path(path, out_npz, batch_size, cuda, dims, weights=None,
     _check_cuda(cuda)
     if not u8_cache:
         prefetch_png_ring(path, batch_size, num_workers)   # decode overlaps building the model
-    model = _build_model(dims, weights, num_classes, seed)
-    mu, sigma = _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers, u8_cache)
-    if tdist.is_main():
-        np.savez(out_npz, mu=np.asarray(mu), sigma=np.asarray(sigma))
-    return mu, sigma
+    with _own_model(dims, weights, num_classes, seed) as model:
+        mu, sigma = _compute_statistics_of_path(path, model, batch_size, dims, cuda, num_workers, u8_cache)
+        if tdist.is_main():
+            np.savez(out_npz, mu=np.asarray(mu), sigma=np.asarray(sigma))
+        return mu, sigma
 
 
 def class_of_crop(filename):
@@ -518,7 +536,7 @@ def _class_statistics(path, model, batch_size, dims, num_workers, owner=None):
     dataset = img_data.Dataset(path, transform=None, file_names=files[lo:hi])
     loader = torch.utils.data.DataLoader(dataset=dataset, batch_size=batch_size, shuffle=False, drop_last=False,
                                          num_workers=min(32, _num_workers(num_workers, world)), collate_fn=img_data.collate_u8,
-                                         pin_memory=True)
+                                         pin_memory=True, worker_init_fn=img_data.worker_init)
     # The pool3 rows of the directory stay on the device (8 KB per crop); once the walk is complete they are sorted by class
     # and folded into the 80 accumulators by ONE grouped launch (device.stats_update_grouped): every class's S is
     # read-modify-written once per directory.  Round 4 ran one index_select + one 528-workgroup covariance launch per class
@@ -584,37 +602,37 @@ def calculate_per_class_fid(paths, batch_size, cuda, dims, weights=None, num_cla
         if not os.path.isdir(p):
             raise RuntimeError("Invalid path: %s" % p)
     _check_cuda(cuda)
-    model = _build_model(dims, weights, num_classes, seed)
-    # the class list comes from the file names alone: the sorted union over both directories, identical on every rank,
-    # dealt round-robin to the ranks
-    present = [set(class_of_crop(f) for f in img_data.get_filenames(p)) for p in paths]
-    names = sorted(present[0] | present[1])
-    world, me = tdist.world_size(), tdist.rank()
-    owner = tdist.class_owners(names, world)
-    a1 = _class_statistics(paths[0], model, batch_size, dims, num_workers, owner)
-    a2 = _class_statistics(paths[1], model, batch_size, dims, num_workers, owner)
-    dev = torch.device("cuda", torch.cuda.current_device())
-    mine = []
-    status = torch.zeros((len(names), 3), dtype=torch.float64, device=dev)       # [fid, solved, skipped] per class
-    for i, c in enumerate(names):
-        if owner[c] != me:
-            continue
-        if c not in a1 or c not in a2 or a1[c].count() < min_count or a2[c].count() < min_count:
-            status[i, 2] = 1.0
-            continue
-        mine.append((i, c))
-    fids = _solve_classes([(a1[c], a2[c]) for _, c in mine], dims, dev)
-    for (i, _), v in zip(mine, fids):
-        status[i, 0], status[i, 1] = v, 1.0
-    tdist.all_reduce_sum_(status)                                                 # 80 x 3 doubles: every rank gets every class
-    st = status.cpu().numpy()
-    out, skipped = OrderedDict(), []
-    for i, c in enumerate(names):
-        if st[i, 1] > 0:
-            out[c] = float(st[i, 0])
-        else:
-            skipped.append(c)
-    return out, skipped
+    with _own_model(dims, weights, num_classes, seed) as model:
+        # the class list comes from the file names alone: the sorted union over both directories, identical on every rank,
+        # dealt round-robin to the ranks
+        present = [set(class_of_crop(f) for f in img_data.get_filenames(p)) for p in paths]
+        names = sorted(present[0] | present[1])
+        world, me = tdist.world_size(), tdist.rank()
+        owner = tdist.class_owners(names, world)
+        a1 = _class_statistics(paths[0], model, batch_size, dims, num_workers, owner)
+        a2 = _class_statistics(paths[1], model, batch_size, dims, num_workers, owner)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        mine = []
+        status = torch.zeros((len(names), 3), dtype=torch.float64, device=dev)       # [fid, solved, skipped] per class
+        for i, c in enumerate(names):
+            if owner[c] != me:
+                continue
+            if c not in a1 or c not in a2 or a1[c].count() < min_count or a2[c].count() < min_count:
+                status[i, 2] = 1.0
+                continue
+            mine.append((i, c))
+        fids = _solve_classes([(a1[c], a2[c]) for _, c in mine], dims, dev)
+        for (i, _), v in zip(mine, fids):
+            status[i, 0], status[i, 1] = v, 1.0
+        tdist.all_reduce_sum_(status)                                                 # 80 x 3 doubles: every rank gets every class
+        st = status.cpu().numpy()
+        out, skipped = OrderedDict(), []
+        for i, c in enumerate(names):
+            if st[i, 1] > 0:
+                out[c] = float(st[i, 0])
+            else:
+                skipped.append(c)
+        return out, skipped
 
 
 _CLASS_SOLVERS = {}

@@ -260,6 +260,17 @@ class U8CacheLoader:
         return self.first_item_event.elapsed_time(self.last_item_event) * 1e-3
 
 
+def worker_init(_worker_id):
+    """``worker_init_fn`` of every DataLoader of this package.  The workers are FORKED from a process that holds a HIP context:
+    objects the parent had not yet collected (an engine and its device handles in a reference cycle, say) are inherited as
+    garbage, and the first full collection in the child would run their finalisers there -- hipFree and friends in a process that
+    must not touch the parent's context ("DataLoader worker exited unexpectedly", seen once in ~10 runs of the 80-class test).
+    ``gc.freeze()`` moves everything allocated before the fork out of the collector's reach for the life of the worker; what the
+    worker allocates itself is collected as usual.  (The handle classes of device.py also refuse to destroy from another pid.)"""
+    import gc
+    gc.freeze()
+
+
 def collate_u8(samples):
     """Stack equal-sized uint8 images to (B,H,W,3); otherwise keep a list (ragged crops, O-FID)."""
     if all(s.shape == samples[0].shape for s in samples):

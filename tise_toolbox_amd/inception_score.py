@@ -125,7 +125,8 @@ def get_inception_score(images, splits=10):
     def dataloader_feed():
         dataset = img_data.Dataset(None, transform=None, file_names=images[lo:hi])
         loader = torch.utils.data.DataLoader(dataset, batch_size=bs, shuffle=False, drop_last=False,
-                                             num_workers=min(32, workers), collate_fn=img_data.collate_u8, pin_memory=True)
+                                             num_workers=min(32, workers), collate_fn=img_data.collate_u8, pin_memory=True,
+                                             worker_init_fn=img_data.worker_init)
         return coalesce_batches(loader, eng.device, device_batch_images(bs))
 
     if _CONFIG.get("png_feed", "ring") == "ring" and hi > lo:

@@ -75,7 +75,8 @@ def inception_score(imgs, cuda=True, batch_size=32, resize=False, splits=1, weig
     lo, hi = tdist.shard_range(N, rank, world)
     subset = torch.utils.data.Subset(imgs, range(lo, hi))
     loader = torch.utils.data.DataLoader(subset, batch_size=batch_size, num_workers=num_workers,
-                                         collate_fn=img_data.collate_u8 if isinstance(imgs, IgnoreLabelDataset) else None)
+                                         collate_fn=img_data.collate_u8 if isinstance(imgs, IgnoreLabelDataset) else None,
+                                         worker_init_fn=img_data.worker_init)
     eng.begin(n_total=N, temperature=temperature, splits=splits, rule="ois")
     base = lo
     # batch_size (32 in the reference's call, :122) is the loader's batch; a trunk pass takes up to

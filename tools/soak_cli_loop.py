@@ -1,0 +1,36 @@
+"""Soak of the drop-in CLIs inside ONE process: 16 FID runs over two directories of 400 random PNGs (alternating sides) with an IS\* run
+every fourth -- file descriptors, resident memory, child processes and device memory must not grow, the two FID values must repeat to the bit.
+    python tools/soak_cli_loop.py"""
+import os, sys, time, tempfile, resource
+sys.path.insert(0, os.getcwd())
+import numpy as np, torch
+from PIL import Image
+from tise_toolbox_amd import fid_score, inception_score
+root = tempfile.mkdtemp(prefix="tise_soak_")
+rng = np.random.default_rng(0)
+for name in ("a", "b"):
+    os.makedirs(os.path.join(root, name))
+    for i in range(400):
+        Image.fromarray(rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)).save(os.path.join(root, name, f"{i:05d}.png"), compress_level=1)
+def nfd(): return len(os.listdir("/proc/self/fd"))
+def rss(): return int(open("/proc/self/statm").read().split()[1]) * 4096 / 2**20
+def nchild():
+    me = os.getpid(); n = 0
+    for p in os.listdir("/proc"):
+        if p.isdigit():
+            try:
+                if int(open(f"/proc/{p}/stat").read().rsplit(")", 1)[1].split()[1]) == me: n += 1
+            except Exception: pass
+    return n
+vals = []
+for it in range(16):
+    a, b = ("a", "b") if it % 2 == 0 else ("b", "a")
+    v = fid_score.main(["--batch-size", "50", "--path1", os.path.join(root, a), "--path2", os.path.join(root, b), "--synthetic-weights"])
+    vals.append(v)
+    if it % 4 == 3:
+        inception_score.main(["--image_folder", os.path.join(root, "a"), "--batch-size", "50", "--synthetic-weights"])
+    print(f"iter {it}: fid {v:.9f} fds {nfd()} rss {rss():.0f} MiB children {nchild()} torch alloc {torch.cuda.memory_allocated() / 2**20:.0f} MiB reserved {torch.cuda.memory_reserved() / 2**20:.0f} MiB", flush=True)
+assert len(set(round(v, 9) for v in vals[0::2])) == 1 and len(set(round(v, 9) for v in vals[1::2])) == 1, vals
+assert nfd() <= 16 and nchild() == 0, (nfd(), nchild())
+assert torch.cuda.memory_allocated() / 2**20 < 3000, torch.cuda.memory_allocated()          # one call's worth: nothing accumulates
+print("soak ok")
