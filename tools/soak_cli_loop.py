@@ -34,3 +34,25 @@ assert len(set(round(v, 9) for v in vals[0::2])) == 1 and len(set(round(v, 9) fo
 assert nfd() <= 16 and nchild() == 0, (nfd(), nchild())
 assert torch.cuda.memory_allocated() / 2**20 < 3000, torch.cuda.memory_allocated()          # one call's worth: nothing accumulates
 print("soak ok")
+
+# ---- second part: the ragged-crop per-class path (DataLoader workers forked from this process), six runs ----
+crops = {}
+for side in ("gen", "ref"):
+    d = os.path.join(root, "crops_" + side)
+    os.makedirs(d)
+    k = 0
+    for c in ("person", "dog", "traffic light", "cup", "zebra", "pizza"):
+        for j in range(24):
+            hh, ww = 40 + (7 * j + k) % 60, 36 + (11 * j + 3 * k) % 70
+            Image.fromarray(rng.integers(0, 256, (hh, ww, 3), dtype=np.uint8)).save(os.path.join(d, f"im{k}_{c}_{k}.png"), compress_level=1)
+            k += 1
+    crops[side] = d
+pc = []
+for it in range(6):
+    per = fid_score.main(["--batch-size", "16", "--path1", crops["ref"], "--path2", crops["gen"], "--label", "O-FID", "--num-classes", "80",
+                          "--per-class", "--synthetic-weights", "--num-workers", "4"])
+    pc.append(tuple(round(float(v), 9) for v in per.values()))
+    print(f"per-class iter {it}: {len(per)} classes, fds {nfd()} rss {rss():.0f} MiB children {nchild()} torch alloc {torch.cuda.memory_allocated() / 2**20:.0f} MiB", flush=True)
+assert len(set(pc)) == 1, pc
+assert nfd() <= 20 and nchild() == 0, (nfd(), nchild())
+print("per-class soak ok")
