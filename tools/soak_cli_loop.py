@@ -56,3 +56,27 @@ for it in range(6):
 assert len(set(pc)) == 1, pc
 assert nfd() <= 20 and nchild() == 0, (nfd(), nchild())
 print("per-class soak ok")
+
+# ---- third part: the RP-COCO CLI (CLIP stand-in towers), six runs ----
+import pickle  # noqa: E402
+from tise_toolbox_amd import RP_coco  # noqa: E402
+words = ["a", "red", "bus", "dog", "on", "the", "grass", "two", "people", "near", "table"]
+img_dir = os.path.join(root, "rp_images")
+os.makedirs(img_dir)
+items = []
+pool = [" ".join(rng.choice(words, 5)) + f" x{k}" for k in range(30)]
+for i in range(64):
+    items.append({"caption_id": 100 + i, "caption": " ".join(rng.choice(words, 5)) + f" {i}",
+                  "mismatched_captions": [pool[(i * 3 + 5 * j) % 30] for j in range(6)]})
+    Image.fromarray(rng.integers(0, 256, (64, 80, 3), dtype=np.uint8)).save(os.path.join(img_dir, f"{100 + i}.png"))
+pkl = os.path.join(root, "rp.pkl")
+pickle.dump(items, open(pkl, "wb"))
+rp = []
+for it in range(6):
+    mean, std = RP_coco.main(["--image_dir", img_dir, "--rp_input_file", pkl, "--saved_file_path", os.path.join(root, "rp.txt"),
+                              "--synthetic-weights", "--seed", "7"])
+    rp.append((round(float(mean), 9), round(float(std), 9)))
+    print(f"rp iter {it}: {rp[-1]} fds {nfd()} rss {rss():.0f} MiB children {nchild()} torch alloc {torch.cuda.memory_allocated() / 2**20:.0f} MiB", flush=True)
+assert len(set(rp)) == 1, rp
+assert nfd() <= 20 and nchild() == 0, (nfd(), nchild())
+print("rp soak ok")
