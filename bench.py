@@ -698,8 +698,8 @@ def cli_process_leg(png_dir, n, feed_batch, mu_ref, sigma_ref, tmp, fid_feed):
             "dfid_vs_png_feed": (abs(runs[1]["fid"] - fid_feed) if ok and runs[1]["fid"] is not None else None),
             "note": "whole fresh child process, wall clock around subprocess.run: interpreter + imports + HIP context + model / engine + image "
                     "loop from PNG files + Frechet distance + exit; phases from TISE_TIMING=1 (seconds after process start).  The second run starts "
-                    "right after the first one freed ~45 GiB of VRAM: when the driver is still clearing that memory, the new process's first big "
-                    "allocation waits for it (up to ~1 s at ~45 GB/s: DESIGN.md section 4f) -- `seconds` is the common case, `seconds_second_run` the "
+                    "right after the first one freed its device memory (~16 GiB with the feeds' 1000-image device batches; ~45 GiB with round 5's 3000): when the driver "
+                    "is still clearing that memory, the new process's first big allocation waits for it (~45 GB/s: up to ~0.3 s now, ~1 s then; DESIGN.md section 4f) -- `seconds` is the common case, `seconds_second_run` the "
                     "back-to-back case"}
 
 
