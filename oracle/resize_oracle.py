@@ -11,6 +11,8 @@ horizontal pass -> uint8 -> vertical pass -> uint8.
 PINNED bit-exactly against the Pillow installed in the build container
 (tests/golden/pil_resize_*.npz, produced by tests/golden/make_golden.py).
 """
+import functools
+
 import numpy as np
 
 PRECISION_BITS = 32 - 8 - 2   # Resample.c: 22-bit coefficients
@@ -32,10 +34,12 @@ def bicubic_filter(x):
 FILTERS = {"bilinear": (bilinear_filter, 1.0), "bicubic": (bicubic_filter, 2.0)}
 
 
+@functools.lru_cache(maxsize=256)
 def precompute_coeffs(in_size, out_size, filter="bilinear"):
     """Resample.c precompute_coeffs() + normalize_coeffs_8bpc() for the whole axis.
 
-    Returns (bounds int32 [out,2] = (xmin, count), kk int32 [out, ksize]).
+    Returns (bounds int32 [out,2] = (xmin, count), kk int32 [out, ksize]) -- read-only for callers: the tables of a
+    (in_size, out_size, filter) triple are computed once per process (the tests resize thousands of equal-sized images).
     """
     bilinear_filter, support = FILTERS[filter]      # (the name below is the filter function of the chosen kind)
     scale = float(in_size) / out_size
@@ -63,6 +67,8 @@ def precompute_coeffs(in_size, out_size, filter="bilinear"):
         q = np.where(w < 0, -0.5 + w * (1 << PRECISION_BITS), 0.5 + w * (1 << PRECISION_BITS))
         kk[xx, :xmax] = q.astype(np.int64).astype(np.int32)
         bounds[xx] = (xmin, xmax)
+    bounds.setflags(write=False)
+    kk.setflags(write=False)
     return bounds, kk
 
 
@@ -73,15 +79,17 @@ def _clip8(v):
 def _resample_axis0(img, out_size, filter="bilinear"):
     """Resample along axis 0 of an (L, ...) uint8 array."""
     bounds, kk = precompute_coeffs(img.shape[0], out_size, filter)
-    out = np.empty((out_size,) + img.shape[1:], dtype=np.uint8)
+    # Resample.c ImagingResampleHorizontal_8bpc / Vertical_8bpc: ss = 1 << (PRECISION_BITS - 1); ss += pixel * k over the window;
+    # clip8(ss).  Integer arithmetic: the sum does not depend on its order, so all output rows are formed at once -- the window
+    # of output xx is gathered at xmin .. xmin + ksize - 1 (indices clamped into the axis; the coefficients behind a window's
+    # count are zero, so what is read there does not matter).
+    ksize = kk.shape[1]
+    idx = np.minimum(bounds[:, :1].astype(np.int64) + np.arange(ksize, dtype=np.int64)[None, :], img.shape[0] - 1)      # (out, ksize)
     src = img.astype(np.int64)
-    for xx in range(out_size):
-        xmin, cnt = bounds[xx]
-        acc = np.full(img.shape[1:], 1 << (PRECISION_BITS - 1), dtype=np.int64)
-        for x in range(cnt):
-            acc += src[xmin + x] * int(kk[xx, x])
-        out[xx] = _clip8(acc)
-    return out
+    acc = np.full((out_size,) + img.shape[1:], 1 << (PRECISION_BITS - 1), dtype=np.int64)
+    for x in range(ksize):
+        acc += src[idx[:, x]] * kk[:, x].astype(np.int64).reshape((out_size,) + (1,) * (img.ndim - 1))
+    return _clip8(acc)
 
 
 def resize_u8(img, out_h, out_w, filter="bilinear"):

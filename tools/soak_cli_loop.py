@@ -80,3 +80,16 @@ for it in range(6):
 assert len(set(rp)) == 1, rp
 assert nfd() <= 20 and nchild() == 0, (nfd(), nchild())
 print("rp soak ok")
+
+# ---- fourth part: the O-IS CLI on the crop directory (DataLoader workers), the FID CLI through --u8-cache, four runs each ----
+from tise_toolbox_amd import object_centric_inception_score as ois  # noqa: E402
+ov, cv = [], []
+for it in range(4):
+    m, sd = ois.main(["--image_dir", crops["gen"], "--synthetic-weights"])
+    ov.append((round(float(m), 9), round(float(sd), 9)))
+    v = fid_score.main(["--batch-size", "50", "--path1", os.path.join(root, "a"), "--path2", os.path.join(root, "b"), "--synthetic-weights", "--u8-cache"])
+    cv.append(round(float(v), 9))
+    print(f"o-is / u8-cache iter {it}: {ov[-1]} {cv[-1]} fds {nfd()} rss {rss():.0f} MiB children {nchild()} torch alloc {torch.cuda.memory_allocated() / 2**20:.0f} MiB", flush=True)
+assert len(set(ov)) == 1 and len(set(cv)) == 1 and cv[0] == round(vals[1], 9), (ov, cv, vals[1])
+assert nfd() <= 24 and nchild() == 0, (nfd(), nchild())
+print("o-is / u8-cache soak ok")
