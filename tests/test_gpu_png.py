@@ -50,7 +50,8 @@ def _device_unfilter(slots, h, w):
     return out.cpu().numpy()
 
 
-SIZES = [(1, 1), (1, 7), (7, 1), (5, 3), (64, 64), (65, 33), (130, 67), (256, 256), (200, 301), (63, 1024)]
+SIZES = [(1, 1), (1, 7), (7, 1), (5, 3), (64, 64), (65, 33), (130, 67), (256, 256), (200, 301), (63, 1024),
+         (12, 2047)]          # the widest rows the device path takes: 4 * 2047 + 1 = 8189 of TISE_PNG_DEVICE_ROW_MAX = 8192 bytes
 
 
 @pytest.mark.parametrize("h,w", SIZES)
@@ -70,6 +71,22 @@ def test_device_unfilter_equals_pillow(h, w, bpp):
     assert modes == [bpp] * len(blobs)                             # all of them took the device road
     got = _device_unfilter(slots, h, w)
     assert np.array_equal(got, want), np.argwhere((got != want).reshape(len(blobs), -1).any(1)).ravel()
+
+
+def test_rows_beyond_the_device_limit_take_the_host_decode_and_the_copy_mode():
+    """A filtered row longer than TISE_PNG_DEVICE_ROW_MAX (8192 bytes: RGBA at w = 2100 has 8401) is decoded completely on the
+    host (csrc/png_decode.c: tise_png_inflate_slot falls back to mode 0, pixels in the slot) and the kernel only copies it; an
+    RGB file of that width (6301 bytes) beside it in the same launch still takes the device filters."""
+    h, w = 6, 2100
+    rng = np.random.default_rng(77)
+    rgba = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgb = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    blobs = [_png_cases.write_png(rgba, [4, 3, 2, 1, 0, 4]), _png_cases.write_png(rgb, [4, 3, 2, 1, 0, 4])]
+    want = np.stack([_pillow_rgb(b) for b in blobs])
+    slots, modes = _inflate_slots(blobs, h, w, 4)
+    assert modes == [0, 3], modes
+    got = _device_unfilter(slots, h, w)
+    assert np.array_equal(got, want)
 
 
 def test_mixed_ring_rgba_in_rgb_slots_and_pillow_files():
