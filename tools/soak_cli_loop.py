@@ -2,6 +2,7 @@
 every fourth -- file descriptors, resident memory, child processes and device memory must not grow, the two FID values must repeat to the bit.
     python tools/soak_cli_loop.py"""
 import os, sys, time, tempfile, resource
+os.environ.setdefault("TISE_RELEASE_MODEL", "1")      # fid_score._own_model: release a call's model on return (opt-in)
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 from PIL import Image
