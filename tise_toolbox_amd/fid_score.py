@@ -434,7 +434,7 @@ def _own_model(dims, weights, num_classes, seed):
     (tools/soak_cli_loop.py: 16 calls in one process held 20 GiB; the reference's model dies when calculate_fid_given_paths
     returns, fid_score.py:229-238).  TISE_RELEASE_MODEL=1 cuts the cycle on the way out, and memory then stays flat
     (tests/test_gpu_pipeline.py::test_repeated_fid_calls_in_one_process_release_their_model).  It is NOT the default: with the
-    prompt release in place two of eleven runs of tests/test_gpu_pipeline.py failed in tests that had never failed before
+    prompt release in place two of thirteen runs of tests/test_gpu_pipeline.py failed in tests that had never failed before
      and the cause was not found in what was left of round 6 -- the collector-driven release is the
     behaviour of rounds 1-5."""
     model = _build_model(dims, weights, num_classes, seed)
